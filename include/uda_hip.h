@@ -1,0 +1,198 @@
+/* uda_hip.h — C ABI of the MI355X (gfx950) hot path of uncertainty-detection-autolabeling.
+ *
+ * One shared library (uncertainty-detection-autolabeling_amd/csrc/libuda_hip.so), plain
+ * pointers and sizes, no torch / C++ types.  It replaces what the reference reaches
+ * through `infer_lib.ServingDriver` (reference src/infer_lib.py:118-296):
+ *
+ *   uda_create            <- KerasDriver.__init__: build EfficientDetModel + restore weights
+ *                            (infer_lib.py:416-440; efficientdet_keras.py:850-970)
+ *   uda_set_images_u8     <- the uint8 [N,h,w,3] `image_arrays` argument of serve()  (infer_lib.py:337-343,442-448)
+ *   uda_run               <- EfficientDetModel.call: _preprocessing -> EfficientDetNet.call (MC loop)
+ *                            -> _postprocess                     (efficientdet_keras.py:1076-1146, 979-1050)
+ *   uda_get_detections    <- the output tuple of postprocess_global / postprocess_per_class
+ *                            (postprocess.py:472-621, 624-740)
+ *   uda_serve             <- ServingDriver.serve                (set_images + run + get_detections)
+ *   uda_predict           <- ServingDriver.predict with only_network=True: float images -> raw head outputs
+ *                            (infer_lib.py:345-350,450-457)
+ *   uda_postprocess_heads <- ServingDriver._postprocess = postprocess_global on given head outputs
+ *                            (infer_lib.py:263-267)
+ *
+ * Conventions: every function returns 0 on success, non-zero on error (message via
+ * uda_last_error); inputs are borrowed, outputs are caller-allocated; a handle owns one
+ * GPU's weights, workspace and HIP stream, is not thread-safe, and every call that
+ * returns data synchronises its stream before returning.  Host orchestration (config,
+ * topology -> op list, weight packing) stays in Python (plan.py) exactly as the
+ * reference keeps model building in Python above the TF runtime.
+ */
+#ifndef UDA_HIP_H_
+#define UDA_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UDA_ABI_VERSION 1
+#define UDA_MAX_LEVELS 8
+#define UDA_MAX_FUSE_INPUTS 3
+
+/* ---- activation buffers (NHWC float32) ---------------------------------------------- */
+typedef struct uda_buf_desc {
+  int32_t H, W, C;      /* one sample */
+  int32_t per_sample;   /* 0: one row per image (shared by all MC samples); 1: one row per (image, sample) */
+  int64_t offset;       /* float offset inside the per-chunk arena (liveness-planned by plan.py) */
+  int32_t kind;         /* 0 arena, 1 network input image, 2 class head output, 3 box head output */
+  int32_t level;        /* pyramid level index for kind 2/3 */
+} uda_buf_desc_t;
+
+/* ---- ops ------------------------------------------------------------------------------ */
+enum uda_op_kind {
+  UDA_OP_STEM = 1,  /* 3x3 stride-2 conv (Cin=3) + BN + swish          efficientnet_model.py:588-612 */
+  UDA_OP_PW = 2,    /* 1x1 conv (+SE input scale)(+bias)(+BN)(+swish)(+dropout)(+residual)  :358-373,403-418,471-486 */
+  UDA_OP_DW = 3,    /* depthwise kxk stride s SAME (+BN)(+swish)(+dropout)(+SE partial sums) :376-391,459-464 */
+  UDA_OP_SE = 4,    /* mean -> fc+bias -> swish -> fc+bias -> sigmoid   :219-232 */
+  UDA_OP_FUSE = 5,  /* BiFPN weighted fusion of resampled inputs + swish  efficientdet_keras.py:86-127,229-231 */
+  UDA_OP_POOL = 6   /* max pool (stride+1) x (stride+1), stride s, SAME   efficientdet_keras.py:280-290 */
+};
+enum uda_act { UDA_ACT_NONE = 0, UDA_ACT_SWISH = 1 };
+enum uda_resample { UDA_RS_NONE = 0, UDA_RS_NEAREST_UP = 1, UDA_RS_MAXPOOL = 2 };
+
+typedef struct uda_op {
+  int32_t kind;
+  int32_t in[UDA_MAX_FUSE_INPUTS]; /* buffer ids, -1 = unused */
+  int32_t out;                     /* buffer id */
+  int32_t se_scale;                /* PW: buffer id of the [rows, Cin] SE gate applied to the input, or -1 */
+  int32_t se_partial;              /* DW: buffer id receiving per-tile channel sums; SE: the same buffer as input */
+  int32_t residual;                /* PW: buffer id added to the output, or -1 */
+  int32_t k, stride;               /* DW / POOL / STEM */
+  int32_t act;                     /* uda_act, applied after bias/BN, before dropout */
+  int64_t w_off;                   /* float offsets into the weight blob; -1 = absent */
+  int64_t bias_off;                /*   conv bias [Cout]                                */
+  int64_t bn_scale_off;            /*   gamma * rsqrt(var + 1e-3)  [Cout]               */
+  int64_t bn_shift_off;            /*   beta - mean * scale         [Cout]               */
+  int64_t se_w1_off, se_b1_off, se_w2_off, se_b2_off; /* SE: [C][mid], [mid], [mid][C], [C] */
+  int32_t se_mid;
+  int32_t drop_site;               /* index of the MC-dropout site applied to the output, -1 = none */
+  int32_t resample[UDA_MAX_FUSE_INPUTS]; /* FUSE: uda_resample per input */
+  float fuse_w[UDA_MAX_FUSE_INPUTS];     /* FUSE: relu(w_i) / (sum relu(w) + 1e-4) */
+  int32_t n_in;
+  int32_t reserved;
+} uda_op_t;
+
+/* ---- MC dropout sites -------------------------------------------------------------------- */
+typedef struct uda_drop_site {
+  int32_t channels;
+  float rate;            /* keep iff u >= rate, scale 1/(1-rate)  (SpatialDropout2D, noise shape [N,1,1,C]) */
+} uda_drop_site_t;
+
+/* ---- model / post-processing description ---------------------------------------------------- */
+enum uda_decode { UDA_DECODE_PLAIN = 0, UDA_DECODE_LNORM = 1, UDA_DECODE_FALSEDEC = 2 };
+enum uda_post_mode { UDA_POST_GLOBAL = 0, UDA_POST_PER_CLASS = 1 };
+
+typedef struct uda_model {
+  int32_t abi_version;
+  int32_t image_h, image_w;         /* network input size (H, W) = parse_image_size(image_size) */
+  float mean_rgb[3], stddev_rgb[3];
+  int32_t num_levels;
+  int32_t level_h[UDA_MAX_LEVELS], level_w[UDA_MAX_LEVELS];
+  int32_t anchors_per_loc;          /* num_scales * len(aspect_ratios) */
+  int32_t num_classes;
+  int32_t loss_attenuation;         /* box head has 8*A channels: [4A box | 4A sigma]  (postprocess.py:448-462) */
+  int32_t mc_samples;               /* T (1 when mc_dropout is off) */
+  int32_t cls_stacked, box_stacked; /* head outputs carry the T axis                  (efficientdet_keras.py:1026-1049) */
+  int32_t has_uncert;               /* loss_attenuation or mc_dropout: uncertainty columns are emitted (postprocess.py:443) */
+  int32_t decode_method;            /* uda_decode */
+  int32_t enable_softmax;           /* logits output present */
+  /* nms (postprocess.py:373-400) */
+  float nms_soft_sigma;             /* sigma/2 handed to NonMaxSuppressionV5; 0 = hard */
+  float nms_iou_thresh, nms_score_thresh;
+  int32_t max_output_size;
+  int32_t max_nms_inputs;           /* 0: argmax per anchor; >0: top-k over anchors*classes (postprocess.py:96-121) */
+  int32_t post_mode;                /* default uda_post_mode used by uda_run */
+  /* planning */
+  int32_t chunk_images;             /* images processed per pass of the op list */
+  int32_t max_images;               /* capacity of one uda_run */
+  int64_t arena_floats;             /* per-chunk arena size */
+  int32_t n_drop_sites;
+  int32_t reserved;
+} uda_model_t;
+
+typedef struct uda_ctx uda_ctx_t;
+
+/* Build a handle on HIP device `device`: uploads `weights`, the anchor table, allocates
+ * the arena, head-output and NMS workspaces.  Returns NULL-handle + error on failure. */
+int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, int32_t n_bufs,
+               const uda_op_t* ops, int32_t n_ops, const uda_drop_site_t* sites,
+               const float* weights, int64_t n_weights, const float* anchors /* [A_tot*4] */,
+               int32_t device, uda_ctx_t** out);
+void uda_destroy(uda_ctx_t* ctx);
+/* last error of `ctx` (or of the last failed uda_create when ctx == NULL) */
+const char* uda_last_error(const uda_ctx_t* ctx);
+
+/* Raw uint8 images [n,h,w,3] from host memory into the handle's device staging buffer. */
+int uda_set_images_u8(uda_ctx_t* ctx, const uint8_t* images, int32_t n, int32_t h, int32_t w);
+/* Same, from a device pointer the caller owns (device-to-device copy on the stream). */
+int uda_set_images_u8_device(uda_ctx_t* ctx, const void* images_dev, int32_t n, int32_t h, int32_t w);
+/* Preprocessed float images [n,H,W,3] (the `only_network` input); scales default to 1. */
+int uda_set_images_f32(uda_ctx_t* ctx, const float* images, int32_t n, const float* image_scales);
+
+/* Dropout masks: either generated on the device from `seed` (Philox4x32-10)
+ * or injected: `masks` = concatenation over sites of float32 [n*T, channels] keep-scales. */
+int uda_set_dropout_seed(uda_ctx_t* ctx, uint64_t seed);
+int uda_set_dropout_masks(uda_ctx_t* ctx, const float* masks, int64_t n_floats);
+int uda_get_dropout_masks(uda_ctx_t* ctx, float* masks, int64_t n_floats);
+
+/* preprocess (if uint8 images are set) -> network x T -> post-process, asynchronously on the
+ * handle's stream.  post_mode < 0 uses the model default; run_post == 0 stops after the heads. */
+int uda_run(uda_ctx_t* ctx, int32_t post_mode, int32_t run_post);
+int uda_synchronize(uda_ctx_t* ctx);
+
+/* Detections of the last uda_run (synchronises).  Shapes for n images, M = max_output_size:
+ *   boxes   [n, M, box_cols]   box_cols = 4 (+4 aleatoric sigma)(+4 epistemic sigma)
+ *   scores  [n, M]
+ *   classes [n, M, cls_cols]   cls_cols = 1 (+num_classes MC std of the logits)
+ *   valid   [n] int32
+ *   logits  [n, M, num_classes] (may be NULL)                       (postprocess.py:610-621) */
+int uda_get_detections(uda_ctx_t* ctx, float* boxes, float* scores, float* classes,
+                       int32_t* valid, float* logits);
+int uda_detection_cols(const uda_ctx_t* ctx, int32_t post_mode, int32_t* box_cols, int32_t* cls_cols);
+
+/* serve = set_images_u8 + run + get_detections */
+int uda_serve(uda_ctx_t* ctx, const uint8_t* images, int32_t n, int32_t h, int32_t w,
+              float* boxes, float* scores, float* classes, int32_t* valid, float* logits);
+
+/* Raw head outputs of the last run, level `level`: class [T_c, n, h, w, A*C] and
+ * box [T_b, n, h, w, 4A or 8A] in the reference's stacking order (T axis first; T_x = 1
+ * and the axis is dropped by the caller when that head is not stacked). */
+int uda_get_head_outputs(uda_ctx_t* ctx, int32_t level, float* cls, float* box);
+/* Inject head outputs (same layout) and run only the post-process on them. */
+int uda_set_head_outputs(uda_ctx_t* ctx, int32_t level, int32_t n, const float* cls, const float* box);
+int uda_postprocess_heads(uda_ctx_t* ctx, int32_t n, const float* image_scales, int32_t post_mode);
+/* predict = set_images_f32 + run(no post) ; read back with uda_get_head_outputs */
+int uda_predict(uda_ctx_t* ctx, const float* images, int32_t n);
+
+/* Pre-NMS candidates of the last run (debug / parity): boxes [n,K,4], scores [n,K], classes [n,K] int32 */
+int uda_get_candidates(uda_ctx_t* ctx, float* boxes, float* scores, int32_t* classes,
+                       float* u_cls, float* u_al, float* u_ep);
+int32_t uda_num_candidates(const uda_ctx_t* ctx);
+
+/* Read back activation buffer `buf` of the LAST chunk processed (debug / parity). */
+int uda_read_buffer(uda_ctx_t* ctx, int32_t buf, float* host, int64_t n_floats);
+int uda_get_preprocessed(uda_ctx_t* ctx, float* images /* [n,H,W,3] */, float* scales /* [n] */);
+
+/* Standalone NMS on host arrays (parity tests of the NonMaxSuppressionV5 kernel):
+ * boxes [n_img, k, 4], scores [n_img, k] -> idx [n_img, M], out_scores [n_img, M], valid [n_img] */
+int uda_nms(uda_ctx_t* ctx, const float* boxes, const float* scores, int32_t n_img, int32_t k,
+            int32_t max_out, float iou_thresh, float score_thresh, float soft_sigma, int32_t pad,
+            int32_t* idx, float* out_scores, int32_t* valid);
+
+/* Per-op-kind device timing with HIP events recorded on the handle's stream.
+ * kind_mask: bit (1 << uda_op_kind) selects op kinds; bit 16 post-process aggregate, bit 17 NMS. */
+int uda_profile_enable(uda_ctx_t* ctx, uint32_t kind_mask);
+int uda_profile_read(uda_ctx_t* ctx, int32_t kind, double* total_ms, int64_t* launches, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UDA_HIP_H_ */

@@ -110,12 +110,18 @@ def _drop(x, masks, site, t):
 
 
 # ---------------------------------------------------------------- network pieces
-def backbone(w, params, x, masks, t):
+def _tap(taps, name, x):
+    if taps is not None:
+        taps[name] = x.permute(0, 2, 3, 1).contiguous().numpy()
+
+
+def backbone(w, params, x, masks, t, taps=None):
     """Returns block outputs at reduction_1..5 (list of NCHW tensors)."""
     bb = params["backbone_name"]
     table = block_table(bb)
     x = swish(batch_norm(conv2d(x, w[bb + "/stem/conv2d/kernel"], 2),
                          w, bb + "/stem/tpu_batch_normalization"))
+    _tap(taps, "stem", x)
     feats = []
     for i, (k, s, e, cin, cout, _se) in enumerate(table):
         p = "%s/blocks_%d/" % (bb, i)
@@ -126,6 +132,7 @@ def backbone(w, params, x, masks, t):
             x = swish(batch_norm(conv2d(x, w[p + "conv2d/kernel"]), w, bn_name(nb)))
             nb += 1
             x = _drop(x, masks, "blocks_%d/expand" % i, t)
+            _tap(taps, "blocks_%d/expand" % i, x)
             proj = p + "conv2d_1/kernel"
         else:
             proj = p + "conv2d/kernel"
@@ -133,14 +140,17 @@ def backbone(w, params, x, masks, t):
                              w, bn_name(nb)))
         nb += 1
         x = _drop(x, masks, "blocks_%d/dw" % i, t)
+        _tap(taps, "blocks_%d/dw" % i, x)
         # squeeze-excite: global mean -> 1x1+bias -> swish -> 1x1+bias -> sigmoid -> scale
         sq = x.mean(dim=(2, 3), keepdim=True)
         sq = swish(conv2d(sq, w[p + "se/conv2d/kernel"], 1, w[p + "se/conv2d/bias"]))
         sq = conv2d(sq, w[p + "se/conv2d_1/kernel"], 1, w[p + "se/conv2d_1/bias"])
+        _tap(taps, "blocks_%d/se" % i, torch.sigmoid(sq))
         x = torch.sigmoid(sq) * x
         x = batch_norm(conv2d(x, w[proj]), w, bn_name(nb))
         if s == 1 and cin == cout:
             x = x + inp
+        _tap(taps, "blocks_%d/out" % i, x)
         if i == len(table) - 1 or table[i + 1][1] > 1:
             feats.append(x)
     return feats
@@ -190,7 +200,7 @@ def bifpn_nodes(min_level, max_level):
     return nodes
 
 
-def fpn(w, params, feats):
+def fpn(w, params, feats, taps=None):
     F_ch, lo, hi = params["fpn_num_filters"], params["min_level"], params["max_level"]
     nodes = bifpn_nodes(lo, hi)
     method = params.get("fpn_weight_method") or "fastattn"
@@ -219,7 +229,9 @@ def fpn(w, params, feats):
             else:
                 raise ValueError("unknown weight_method %s" % method)
             op = p + "op_after_combine%d" % nf
+            _tap(taps, "cell%d/fnode%d/fused" % (rep, n), swish(new))
             new = batch_norm(_sepconv(swish(new), w, op + "/conv"), w, op + "/bn")
+            _tap(taps, "cell%d/fnode%d/out" % (rep, n), new)
             cell.append(new)
         feats = []
         for lvl in range(lo, hi + 1):
@@ -242,17 +254,18 @@ def head(w, params, feats, net, tag, masks, t):
     return outs
 
 
-def forward_once(w, params, images, masks=None, t=0):
+def forward_once(w, params, images, masks=None, t=0, taps=None):
     """One forward pass. images float32 [N,H,W,3] -> (cls[5], box[5]) as NHWC numpy."""
     x = _t(images).permute(0, 3, 1, 2)
     with torch.no_grad():
-        feats = backbone(w, params, x, masks, t)[params["min_level"] - 1:]
+        feats = backbone(w, params, x, masks, t, taps)[params["min_level"] - 1:]
         F_ch = params["fpn_num_filters"]
         for lvl in range(len(feats) + params["min_level"], params["max_level"] + 1):
             h, wd = feats[-1].shape[-2:]
             feats.append(_resample(w, "resample_p%d" % lvl, feats[-1],
                                    (h + 1) // 2, (wd + 1) // 2, F_ch))
-        pyr = fpn(w, params, feats)
+            _tap(taps, "p%d_in" % lvl, feats[-1])
+        pyr = fpn(w, params, feats, taps)
         cls = head(w, params, pyr, "class_net", "class", masks, t)
         box = head(w, params, pyr, "box_net", "box", masks, t)
     nhwc = lambda v: v.permute(0, 2, 3, 1).contiguous().numpy()

@@ -1,0 +1,205 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against the CPU oracle on the same seeded inputs.
+
+Bars:
+  * Philox masks, preprocessing, anchor table, NMS keep-sets, and the WHOLE post-process given
+    identical head outputs: bit-exact (integer / index work and the pinned-down float order).
+  * network head outputs: float32, |err| <= 2e-4 * max|ref| per level (different summation
+    order in the MFMA GEMM vs the oracle's torch convs).
+  * end-to-end serve: detections compared after matching by candidate index, 1e-3 relative.
+"""
+import numpy as np
+import pytest
+
+from common import (BOX_ONLY_MC, FULL_MC, HEAD_MC, LOSS_ATT, MC_NO_ATT, PLAIN, make_images, make_params,
+                    make_weights)
+
+pytestmark = pytest.mark.gpu
+
+
+def _driver(params, w, batch, **kw):
+    from uda_amd.infer_lib import ServingDriver
+    return ServingDriver("_", False, params["name"], batch_size=batch, only_network=kw.pop("only_network", False),
+                         model_params=params, weights=w, **kw)
+
+
+def _oracle_net(params, w, x, seed):
+    from oracle import effdet_ref as E, philox_ref as R
+    sites = E.dropout_sites(params)
+    T = params["mc_dropoutsamp"] if params["mc_dropout"] else 1
+    masks = R.make_masks(sites, seed, x.shape[0], T) if sites else None
+    return E.forward(w, params, x, masks), masks
+
+
+def test_library_loads_and_reports_errors():
+    from uda_amd import capi
+    lib = capi.load()
+    for name in capi.EXPORTS:
+        assert hasattr(lib, name)
+
+
+@pytest.mark.parametrize("mode", ["full", "head"])
+def test_philox_masks_bit_exact(mode):
+    from oracle import effdet_ref as E, philox_ref as R
+    p = make_params(**(FULL_MC if mode == "full" else HEAD_MC))
+    w = make_weights(p)
+    d = _driver(p, w, 3)
+    d.set_dropout_seed(0x1234567890ABCDEF)
+    d.serve(make_images(3, 128, 192))
+    got = d.dropout_masks(3)
+    want = R.make_masks(E.dropout_sites(p), 0x1234567890ABCDEF, 3, p["mc_dropoutsamp"])
+    assert set(got) == set(want)
+    for k in want:
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    d.close()
+
+
+@pytest.mark.parametrize("hw", [(128, 192), (100, 180), (61, 77), (150, 400), (300, 200)])
+def test_preprocess_bit_exact(hw):
+    from oracle import preprocess_ref as PP
+    p = make_params()
+    w = make_weights(p)
+    d = _driver(p, w, 2)
+    imgs = make_images(2, hw[0], hw[1], seed=hw[0])
+    d.serve(imgs)
+    d._last_n = 2
+    got, scales = d.preprocessed()
+    want, wscales = PP.preprocess(imgs, d.image_size, p["mean_rgb"], p["stddev_rgb"])
+    np.testing.assert_array_equal(scales, wscales)
+    np.testing.assert_array_equal(got, want)
+    d.close()
+
+
+def _check_heads(got, want, tol=2e-4):
+    for lvl, (g, r) in enumerate(zip(got, want)):
+        assert g.shape == r.shape, (lvl, g.shape, r.shape)
+        scale = np.abs(r).max()
+        err = np.abs(g - r).max()
+        assert err <= tol * scale + 1e-6, "level %d: err %g vs scale %g" % (lvl, err, scale)
+
+
+@pytest.mark.parametrize("name,over", [("plain", PLAIN), ("lossatt", LOSS_ATT), ("full_mc", FULL_MC),
+                                       ("head_mc", HEAD_MC), ("mc_noatt", MC_NO_ATT), ("box_only", BOX_ONLY_MC)])
+def test_network_heads_match_oracle(name, over):
+    from oracle import preprocess_ref as PP
+    p = make_params(**over)
+    w = make_weights(p, seed=3)
+    d = _driver(p, w, 2, only_network=True)
+    x, _ = PP.preprocess(make_images(2, 128, 192, seed=5), d.image_size, p["mean_rgb"], p["stddev_rgb"])
+    d.set_dropout_seed(77)
+    cls, box = d.predict(x)
+    (rcls, rbox), _ = _oracle_net(p, w, x, 77)
+    _check_heads(cls, rcls)
+    _check_heads(box, rbox)
+    d.close()
+
+
+def test_network_chunking_is_invisible():
+    """chunk_images only changes how many images go through the op list at once."""
+    from oracle import preprocess_ref as PP
+    p = make_params(**FULL_MC)
+    w = make_weights(p, seed=4)
+    x, _ = PP.preprocess(make_images(3, 128, 192, seed=6), (128, 192), p["mean_rgb"], p["stddev_rgb"])
+    outs = []
+    for chunk in (1, 2, 3):
+        d = _driver(p, w, 3, only_network=True, chunk_images=chunk)
+        d.set_dropout_seed(5)
+        outs.append(d.predict(x))
+        d.close()
+    for o in outs[1:]:
+        for a, b in zip(o[0] + o[1], outs[0][0] + outs[0][1]):
+            np.testing.assert_array_equal(a, b)
+
+
+def test_d2_topology_matches_oracle():
+    p = make_params(model="efficientdet-d2", image_size="128x128", **HEAD_MC)
+    w = make_weights(p, seed=8)
+    from oracle import preprocess_ref as PP
+    d = _driver(p, w, 1, only_network=True)
+    x, _ = PP.preprocess(make_images(1, 128, 128, seed=9), d.image_size, p["mean_rgb"], p["stddev_rgb"])
+    d.set_dropout_seed(3)
+    cls, box = d.predict(x)
+    (rcls, rbox), _ = _oracle_net(p, w, x, 3)
+    _check_heads(cls, rcls)
+    _check_heads(box, rbox)
+    d.close()
+
+
+def _rand_boxes(rng, n, span=400.0, tied=False):
+    c = rng.uniform(0, span, (n, 2))
+    wh = rng.uniform(4, 120, (n, 2))
+    b = np.stack([c[:, 0] - wh[:, 0] / 2, c[:, 1] - wh[:, 1] / 2, c[:, 0] + wh[:, 0] / 2,
+                  c[:, 1] + wh[:, 1] / 2], 1).astype(np.float32)
+    if tied:
+        s = (0.01 + rng.normal(0, 1e-4, n)).astype(np.float32)
+        s[rng.integers(0, n, n // 8)] = s[0]            # exact ties -> index tie-break
+    else:
+        s = rng.uniform(0, 1, n).astype(np.float32)
+    return b, s
+
+
+@pytest.mark.parametrize("n,tied,sigma,thr", [(0, False, 0.25, 0.001), (1, False, 0.25, 0.001),
+                                              (50, False, 0.25, 0.001), (3000, False, 0.25, 0.001),
+                                              (3000, True, 0.25, 0.001), (5000, True, 0.0, float("-inf")),
+                                              (2500, False, 0.0, 0.3), (20000, True, 0.25, 0.001),
+                                              (777, False, 0.5, 0.2)])
+def test_nms_kernel_bit_exact(n, tied, sigma, thr):
+    from oracle import post_ref as P
+    p = make_params()
+    d = _driver(p, make_weights(p), 1)
+    rng = np.random.default_rng(n + int(tied))
+    n_img = 3
+    boxes = np.zeros((n_img, max(n, 1), 4), np.float32)
+    scores = np.zeros((n_img, max(n, 1)), np.float32)
+    for i in range(n_img):
+        if n:
+            boxes[i], scores[i] = _rand_boxes(rng, n, tied=tied)
+    if n == 0:
+        scores[:] = -1.0
+    idx, sc, valid = d.nms(boxes, scores, 100, 0.5, thr, sigma)
+    for i in range(n_img):
+        ridx, rsc, rvalid = P.nms_v5(boxes[i], scores[i], 100, 0.5, thr, sigma, True)
+        assert valid[i] == rvalid
+        np.testing.assert_array_equal(idx[i], ridx)
+        np.testing.assert_array_equal(sc[i], rsc)
+    d.close()
+
+
+@pytest.mark.parametrize("name,over", [("plain", PLAIN), ("lossatt", LOSS_ATT), ("full_mc", FULL_MC),
+                                       ("head_mc", HEAD_MC), ("mc_noatt", MC_NO_ATT), ("box_only", BOX_ONLY_MC)])
+def test_postprocess_bit_exact_on_oracle_heads(name, over):
+    """Same head outputs in -> the HIP post-process must reproduce the oracle's output tuple exactly."""
+    from oracle import post_ref as P, preprocess_ref as PP
+    p = make_params(**over)
+    w = make_weights(p, seed=11, cls_spread=20.0 if name in ("plain", "full_mc") else 1.0)
+    x, scales = PP.preprocess(make_images(2, 100, 180, seed=12), (128, 192), p["mean_rgb"], p["stddev_rgb"])
+    (rcls, rbox), _ = _oracle_net(p, w, x, 21)
+    want = P.postprocess_global(p, rcls, rbox, scales)
+    d = _driver(p, w, 2)
+    got = d.postprocess(rcls, rbox, scales)
+    assert len(got) == len(want)
+    for k, (g, r) in enumerate(zip(got, want)):
+        assert g.shape == r.shape and g.dtype == r.dtype, (k, g.shape, r.shape, g.dtype, r.dtype)
+        np.testing.assert_array_equal(g, r, err_msg="output %d" % k)
+    d.close()
+
+
+def test_serve_end_to_end_close_to_oracle():
+    from oracle import post_ref as P, preprocess_ref as PP
+    p = make_params(**FULL_MC)
+    w = make_weights(p, seed=13, cls_spread=20.0)
+    imgs = make_images(2, 100, 180, seed=14)
+    d = _driver(p, w, 2)
+    d.set_dropout_seed(99)
+    got = d.serve(imgs)
+    x, scales = PP.preprocess(imgs, (128, 192), p["mean_rgb"], p["stddev_rgb"])
+    (rcls, rbox), _ = _oracle_net(p, w, x, 99)
+    want = P.postprocess_global(p, rcls, rbox, scales)
+    np.testing.assert_array_equal(got[3], want[3])
+    # top detections: same boxes within 1e-3 of the box scale, same class, scores within 1e-3 relative
+    for n in range(2):
+        k = min(10, int(want[3][n]))
+        np.testing.assert_allclose(got[1][n, :k], want[1][n, :k], rtol=1e-3)
+        np.testing.assert_allclose(got[0][n, :k, :4], want[0][n, :k, :4], rtol=1e-3, atol=0.2)
+        np.testing.assert_array_equal(got[2][n, :k, 0], want[2][n, :k, 0])
+    d.close()

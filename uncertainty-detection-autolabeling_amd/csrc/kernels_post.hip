@@ -1,0 +1,480 @@
+// Pre/post-processing kernels (gfx950).  Compiled with -ffp-contract=off: every float
+// operation here is an individually rounded IEEE op in the order written, so results are
+// comparable bit for bit with the CPU oracle's statement of the same arithmetic.
+//
+//   preprocess_kernel  normalise + bilinear resize (half-pixel centres) + zero pad
+//                      (reference dataloader.py:69-75,123-152; efficientdet_keras.py:1076-1100)
+//   aggregate_kernel   MC mean / population std of the class logits, argmax + sigmoid,
+//                      per-sample anchor decode (plain f32 or variance-propagating f64),
+//                      mean / std over samples of the decoded corners, mean of decoded sigma
+//                      (utils_extra.py:220-244; postprocess.py:75-141,284-331; anchors.py:41-75;
+//                       utils_box.py:105-276)
+//   nms_*              tf.raw_ops.NonMaxSuppressionV5 as an epoch-synchronous data-parallel
+//                      algorithm (postprocess.py:342-420; see DESIGN.md "NMS")
+//   gather_kernel      gathers by selected index, clips, rescales, packs the output tuple
+//                      (postprocess.py:402-413,599-621)
+//
+// Pinned-down numerics shared with the oracle (oracle/post_ref.py header):
+//   exp32(x) = float(exp(double(x))), sigmoid(x) = float(1/(1+exp(-double(x)))),
+//   MC reductions are sequential float32 sums over t = 0..T-1.
+#include "uda_internal.h"
+
+namespace uda {
+
+// ------------------------------------------------------------------------------------ preprocess
+__device__ __forceinline__ float norm_px(const uint8_t* p, int c, const PreprocArgs& a) {
+  return ((float)p[c] - a.mean[c]) / a.stdv[c];
+}
+
+__global__ __launch_bounds__(256) void preprocess_kernel(PreprocArgs a) {
+  const int64_t total = (int64_t)a.n * a.H * a.W;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  const int x = (int)(gid % a.W);
+  const int y = (int)((gid / a.W) % a.H);
+  const int n = (int)(gid / ((int64_t)a.W * a.H));
+  float* o = a.out + (size_t)gid * 3;
+  if (y >= a.sh || x >= a.sw) {
+    o[0] = 0.f; o[1] = 0.f; o[2] = 0.f;
+    return;
+  }
+  const uint8_t* img = a.in + (size_t)n * a.h * a.w * 3;
+  if (a.sh == a.h && a.sw == a.w) {
+    const uint8_t* p = img + ((size_t)y * a.w + x) * 3;
+    for (int c = 0; c < 3; ++c) o[c] = norm_px(p, c, a);
+    return;
+  }
+  const float fy = ((float)y + 0.5f) * a.scale_y - 0.5f;
+  const float fx = ((float)x + 0.5f) * a.scale_x - 0.5f;
+  const float fly = floorf(fy), flx = floorf(fx);
+  const int ylo = (int)fmaxf(fly, 0.f), yhi = min((int)ceilf(fy), a.h - 1);
+  const int xlo = (int)fmaxf(flx, 0.f), xhi = min((int)ceilf(fx), a.w - 1);
+  const float ly = fy - fly, lx = fx - flx;
+  const uint8_t* ptl = img + ((size_t)ylo * a.w + xlo) * 3;
+  const uint8_t* ptr = img + ((size_t)ylo * a.w + xhi) * 3;
+  const uint8_t* pbl = img + ((size_t)yhi * a.w + xlo) * 3;
+  const uint8_t* pbr = img + ((size_t)yhi * a.w + xhi) * 3;
+  for (int c = 0; c < 3; ++c) {
+    const float tl = norm_px(ptl, c, a), tr = norm_px(ptr, c, a);
+    const float bl = norm_px(pbl, c, a), br = norm_px(pbr, c, a);
+    const float top = tl + (tr - tl) * lx;
+    const float bot = bl + (br - bl) * lx;
+    o[c] = top + (bot - top) * ly;
+  }
+}
+
+void launch_preprocess(const PreprocArgs& a, hipStream_t s) {
+  const int64_t total = (int64_t)a.n * a.H * a.W;
+  hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------ aggregate + decode
+__device__ __forceinline__ float exp32(float x) { return (float)exp((double)x); }
+
+struct Dec {
+  float box[4];
+  float sig[4];
+};
+
+__device__ __forceinline__ void decode_plain(const float* t, const float* an, Dec& d) {
+  const float ya = (an[0] + an[2]) / 2.0f, xa = (an[1] + an[3]) / 2.0f;
+  const float ha = an[2] - an[0], wa = an[3] - an[1];
+  const float w = exp32(t[3]) * wa;
+  const float h = exp32(t[2]) * ha;
+  const float yc = t[0] * ha + ya;
+  const float xc = t[1] * wa + xa;
+  d.box[0] = yc - h / 2.0f;
+  d.box[1] = xc - w / 2.0f;
+  d.box[2] = yc + h / 2.0f;
+  d.box[3] = xc + w / 2.0f;
+}
+
+__device__ __forceinline__ void decode_uncert(const float* t, const float* sg, const float* an,
+                                              int method, Dec& d) {
+  const double a0 = an[0], a1 = an[1], a2 = an[2], a3 = an[3];
+  const double ya = (a0 + a2) / 2, xa = (a1 + a3) / 2;
+  const double ha = a2 - a0, wa = a3 - a1;
+  const double ty = t[0], tx = t[1], th = t[2], tw = t[3];
+  const double s0 = sg[0], s1 = sg[1], s2 = sg[2], s3 = sg[3];
+  const double dty = s0 * s0, dtx = s1 * s1, dth = s2 * s2, dtw = s3 * s3;
+  double w, h, yc, xc, dymin, dxmin, dymax, dxmax;
+  if (method == UDA_DECODE_LNORM) {
+    w = exp(tw + dtw / 2) * wa;
+    h = exp(th + dth / 2) * ha;
+    yc = ty * ha + ya;
+    xc = tx * wa + xa;
+    const double dw = (exp(dtw) - 1) * exp(2 * tw + dtw) * (wa * wa);
+    const double dh = (exp(dth) - 1) * exp(2 * th + dth) * (ha * ha);
+    const double dyc = dty * (ha * ha);
+    const double dxc = dtx * (wa * wa);
+    dymin = dyc + dh / 4.0;
+    dxmin = dxc + dw / 4.0;
+    dymax = dymin;
+    dxmax = dxmin;
+  } else {  // falsedec
+    w = exp(tw) * wa;
+    h = exp(th) * ha;
+    yc = ty * ha + ya;
+    xc = tx * wa + xa;
+    const double dw = exp(dtw) * wa;
+    const double dh = exp(dth) * ha;
+    const double dyc = dty * ha + ya;
+    const double dxc = dtx * wa + xa;
+    dymin = fabs(dyc - dh / 2.0);
+    dxmin = fabs(dxc - dw / 2.0);
+    dymax = dyc + dh / 2.0;
+    dxmax = dxc + dw / 2.0;
+  }
+  d.box[0] = (float)(yc - h / 2.0);
+  d.box[1] = (float)(xc - w / 2.0);
+  d.box[2] = (float)(yc + h / 2.0);
+  d.box[3] = (float)(xc + w / 2.0);
+  d.sig[0] = (float)sqrt(dymin);
+  d.sig[1] = (float)sqrt(dxmin);
+  d.sig[2] = (float)sqrt(dymax);
+  d.sig[3] = (float)sqrt(dxmax);
+}
+
+__device__ __forceinline__ void decode_one(const AggArgs& a, const float* bp, int A, const float* an,
+                                           Dec& d) {
+  float t[4] = {bp[0], bp[1], bp[2], bp[3]};
+  if (a.loss_att) {
+    const float* sp = bp + 4 * A;
+    float sg[4] = {sp[0], sp[1], sp[2], sp[3]};
+    decode_uncert(t, sg, an, a.decode, d);
+  } else {
+    decode_plain(t, an, d);
+    d.sig[0] = d.sig[1] = d.sig[2] = d.sig[3] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)a.n_img * a.A_tot) return;
+  const int n = (int)(gid / a.A_tot);
+  const int ai = (int)(gid % a.A_tot);
+  int lvl = 0;
+  while (lvl + 1 < a.lv.num_levels && ai >= a.lv.a_off[lvl + 1]) ++lvl;
+  const int loc = ai - a.lv.a_off[lvl];
+  const int p = loc / a.A, al = loc % a.A;
+  const int hw = a.lv.hw[lvl];
+  const int C = a.C;
+
+  // ---- class logits: mean / population std over the T axis, first-max argmax
+  const int cch = a.A * C;
+  const float* cbase = a.lv.cls[lvl] + ((size_t)n * a.Tc * hw + p) * cch + al * C;
+  const size_t cstride = (size_t)hw * cch;
+  const float fT = (float)a.Tc;
+  float best = -INFINITY;
+  int best_c = 0;
+  for (int c = 0; c < C; ++c) {
+    float m = cbase[c];
+    if (a.Tc > 1) {
+      for (int t = 1; t < a.Tc; ++t) m = m + cbase[t * cstride + c];
+      m = m / fT;
+      float v = 0.f;
+      for (int t = 0; t < a.Tc; ++t) {
+        const float dlt = cbase[t * cstride + c] - m;
+        v = v + dlt * dlt;
+      }
+      if (a.u_cls) a.u_cls[(size_t)gid * C + c] = sqrtf(v / fT);
+    } else if (a.u_cls) {
+      a.u_cls[(size_t)gid * C + c] = 0.f;
+    }
+    a.logits[(size_t)gid * C + c] = m;
+    if (m > best) {
+      best = m;
+      best_c = c;
+    }
+  }
+  a.scores[gid] = (float)(1.0 / (1.0 + exp(-(double)best)));
+  a.classes[gid] = best_c;
+
+  // ---- boxes: per-sample decode, then mean / std over samples
+  const int bch = a.A * (a.loss_att ? 8 : 4);
+  const float* bbase = a.lv.box[lvl] + ((size_t)n * a.Tb * hw + p) * bch + al * 4;
+  const size_t bstride = (size_t)hw * bch;
+  const float an[4] = {a.anchors[ai * 4 + 0], a.anchors[ai * 4 + 1], a.anchors[ai * 4 + 2],
+                       a.anchors[ai * 4 + 3]};
+  Dec d;
+  decode_one(a, bbase, a.A, an, d);
+  if (a.Tb == 1) {
+    for (int k = 0; k < 4; ++k) a.boxes[(size_t)gid * 4 + k] = d.box[k];
+    if (a.u_al) for (int k = 0; k < 4; ++k) a.u_al[(size_t)gid * 4 + k] = d.sig[k];
+    if (a.u_ep) for (int k = 0; k < 4; ++k) a.u_ep[(size_t)gid * 4 + k] = 0.f;
+    return;
+  }
+  const float fTb = (float)a.Tb;
+  float sb[4] = {d.box[0], d.box[1], d.box[2], d.box[3]};
+  float ss[4] = {d.sig[0], d.sig[1], d.sig[2], d.sig[3]};
+  for (int t = 1; t < a.Tb; ++t) {
+    decode_one(a, bbase + t * bstride, a.A, an, d);
+    for (int k = 0; k < 4; ++k) {
+      sb[k] = sb[k] + d.box[k];
+      ss[k] = ss[k] + d.sig[k];
+    }
+  }
+  float mb[4];
+  for (int k = 0; k < 4; ++k) {
+    mb[k] = sb[k] / fTb;
+    a.boxes[(size_t)gid * 4 + k] = mb[k];
+    if (a.u_al) a.u_al[(size_t)gid * 4 + k] = ss[k] / fTb;
+  }
+  if (a.u_ep) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < a.Tb; ++t) {
+      decode_one(a, bbase + t * bstride, a.A, an, d);
+      for (int k = 0; k < 4; ++k) {
+        const float dlt = d.box[k] - mb[k];
+        v[k] = v[k] + dlt * dlt;
+      }
+    }
+    for (int k = 0; k < 4; ++k) a.u_ep[(size_t)gid * 4 + k] = sqrtf(v[k] / fTb);
+  }
+}
+
+void launch_aggregate(const AggArgs& a, hipStream_t s) {
+  const int64_t total = (int64_t)a.n_img * a.A_tot;
+  hipLaunchKernelGGL(aggregate_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------ NMS (NonMaxSuppressionV5)
+// Epoch k (k boxes already selected) of the reference's lazy max-heap algorithm is exactly:
+//   winner_k  = argmax over live candidates of the UPDATED priority (score after the pending
+//               suppression chain j = k-1 .. begin, ties -> smaller index)
+//   commit    = every candidate whose STALE priority outranks winner_k is popped once in this
+//               epoch: its score becomes the updated one (dropped if <= threshold / hard-suppressed)
+//               and its begin index becomes k.  Nothing else is touched.
+// (proof sketch in DESIGN.md).  Three data-parallel passes per epoch:
+//   A bound : each 2048-candidate chunk evaluates its stale-best candidate -> lower bound on the winner
+//   B eval  : evaluate every candidate whose stale priority >= bound; global max -> winner
+//   C commit: apply the commit rule, record the winner.
+constexpr int NMS_ITEMS = 8;
+constexpr int NMS_CHUNK = 256 * NMS_ITEMS;
+
+__device__ __forceinline__ unsigned long long nms_key(float s, int idx) {
+  const uint32_t b = __float_as_uint(s);
+  const uint32_t o = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+  return ((unsigned long long)o << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)idx);
+}
+
+__device__ __forceinline__ float nms_iou(const float* a, const float* b) {
+  const float ymin_i = fminf(a[0], a[2]), xmin_i = fminf(a[1], a[3]);
+  const float ymax_i = fmaxf(a[0], a[2]), xmax_i = fmaxf(a[1], a[3]);
+  const float ymin_j = fminf(b[0], b[2]), xmin_j = fminf(b[1], b[3]);
+  const float ymax_j = fmaxf(b[0], b[2]), xmax_j = fmaxf(b[1], b[3]);
+  const float area_i = (ymax_i - ymin_i) * (xmax_i - xmin_i);
+  const float area_j = (ymax_j - ymin_j) * (xmax_j - xmin_j);
+  if (area_i <= 0.f || area_j <= 0.f) return 0.0f;
+  const float iy0 = fmaxf(ymin_i, ymin_j), ix0 = fmaxf(xmin_i, xmin_j);
+  const float iy1 = fminf(ymax_i, ymax_j), ix1 = fminf(xmax_i, xmax_j);
+  const float inter = fmaxf(iy1 - iy0, 0.0f) * fmaxf(ix1 - ix0, 0.0f);
+  return inter / (area_i + area_j - inter);
+}
+
+// pending suppression chain of one candidate; returns false when the candidate is dropped
+__device__ __forceinline__ bool nms_chain(const NmsArgs& a, const float* box, const float* sel_box,
+                                          int begin, int k, float& score) {
+  for (int j = k - 1; j >= begin; --j) {
+    const float sim = nms_iou(box, sel_box + 4 * j);
+    float w;
+    if (a.soft || sim <= a.iou_thr) {
+      const float e = a.scale * sim * sim;
+      w = (e == 0.0f) ? 1.0f : (float)exp((double)e);
+    } else {
+      w = 0.0f;
+    }
+    score *= w;
+    if (!a.soft && sim > a.iou_thr) return false;
+    if (score <= a.score_thr) return false;
+  }
+  return true;
+}
+
+__device__ __forceinline__ unsigned long long block_max_key(unsigned long long v) {
+  __shared__ unsigned long long wmax[4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = v;
+  __syncthreads();
+  unsigned long long r = wmax[0];
+#pragma unroll
+  for (int i = 1; i < 4; ++i) r = wmax[i] > r ? wmax[i] : r;
+  return r;
+}
+
+__global__ __launch_bounds__(256) void nms_init_kernel(NmsArgs a, const float* scores) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)a.n_img * a.K;
+  if (gid < total) {
+    const float s = scores[gid];
+    a.stale[gid] = (s > a.score_thr) ? s : -INFINITY;
+    a.begin[gid] = 0;
+  }
+  if (gid < (int64_t)a.n_img * a.M) {
+    a.bound_key[gid] = 0ull;
+    a.win_key[gid] = 0ull;
+    a.sel_idx[gid] = 0;
+    a.sel_score[gid] = 0.f;
+  }
+  if (gid < a.n_img) {
+    a.nsel[gid] = 0;
+    a.done[gid] = 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void nms_bound_kernel(NmsArgs a, int k) {
+  const int n = blockIdx.y;
+  if (a.done[n]) return;
+  const size_t base = (size_t)n * a.K;
+  const int i0 = blockIdx.x * NMS_CHUNK;
+  unsigned long long best = 0ull;
+#pragma unroll
+  for (int it = 0; it < NMS_ITEMS; ++it) {
+    const int i = i0 + it * 256 + threadIdx.x;
+    if (i < a.K) {
+      const float s = a.stale[base + i];
+      if (s != -INFINITY) {
+        const unsigned long long key = nms_key(s, i);
+        best = key > best ? key : best;
+      }
+    }
+  }
+  best = block_max_key(best);
+  if (threadIdx.x == 0 && best != 0ull) {
+    const int idx = (int)(0xFFFFFFFFu - (uint32_t)best);
+    float score = a.stale[base + idx];
+    const int bg = a.begin[base + idx];
+    bool alive = true;
+    if (bg < k) alive = nms_chain(a, a.boxes + (base + idx) * 4, a.sel_box + (size_t)n * a.M * 4, bg, k, score);
+    if (alive) atomicMax(&a.bound_key[(size_t)n * a.M + k], nms_key(score, idx));
+  }
+}
+
+__global__ __launch_bounds__(256) void nms_eval_kernel(NmsArgs a, int k) {
+  const int n = blockIdx.y;
+  if (a.done[n]) return;
+  const size_t base = (size_t)n * a.K;
+  const unsigned long long bound = a.bound_key[(size_t)n * a.M + k];
+  const int i0 = blockIdx.x * NMS_CHUNK;
+  unsigned long long best = 0ull;
+#pragma unroll
+  for (int it = 0; it < NMS_ITEMS; ++it) {
+    const int i = i0 + it * 256 + threadIdx.x;
+    if (i < a.K) {
+      float s = a.stale[base + i];
+      if (s != -INFINITY && nms_key(s, i) >= bound) {
+        const int bg = a.begin[base + i];
+        bool alive = true;
+        if (bg < k) alive = nms_chain(a, a.boxes + (base + i) * 4, a.sel_box + (size_t)n * a.M * 4, bg, k, s);
+        a.tent[base + i] = alive ? s : -INFINITY;
+        if (alive) {
+          const unsigned long long key = nms_key(s, i);
+          best = key > best ? key : best;
+        }
+      }
+    }
+  }
+  best = block_max_key(best);
+  if (threadIdx.x == 0 && best != 0ull) atomicMax(&a.win_key[(size_t)n * a.M + k], best);
+}
+
+__global__ __launch_bounds__(256) void nms_commit_kernel(NmsArgs a, int k) {
+  const int n = blockIdx.y;
+  if (a.done[n]) return;
+  const size_t base = (size_t)n * a.K;
+  const unsigned long long wk = a.win_key[(size_t)n * a.M + k];
+  if (wk == 0ull) {
+    // no live candidate left: finished (every block sees the same wk; only one writes the flag,
+    // and no block of THIS launch reads it after its entry check)
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.done[n] = 1;
+    return;
+  }
+  const int widx = (int)(0xFFFFFFFFu - (uint32_t)wk);
+  const int i0 = blockIdx.x * NMS_CHUNK;
+#pragma unroll
+  for (int it = 0; it < NMS_ITEMS; ++it) {
+    const int i = i0 + it * 256 + threadIdx.x;
+    if (i < a.K) {
+      const float s = a.stale[base + i];
+      if (s == -INFINITY) continue;
+      if (i == widx) {
+        const size_t o = (size_t)n * a.M + k;
+        a.sel_idx[o] = i;
+        a.sel_score[o] = a.tent[base + i];
+        const float* bx = a.boxes + (base + i) * 4;
+        a.sel_box[o * 4 + 0] = bx[0];
+        a.sel_box[o * 4 + 1] = bx[1];
+        a.sel_box[o * 4 + 2] = bx[2];
+        a.sel_box[o * 4 + 3] = bx[3];
+        a.stale[base + i] = -INFINITY;
+        a.nsel[n] = k + 1;
+      } else if (nms_key(s, i) > wk) {
+        a.stale[base + i] = a.tent[base + i];
+        a.begin[base + i] = k;
+      }
+    }
+  }
+}
+
+void launch_nms_init(const NmsArgs& a, const float* scores, hipStream_t s) {
+  int64_t total = (int64_t)a.n_img * a.K;
+  const int64_t t2 = (int64_t)a.n_img * a.M;
+  if (t2 > total) total = t2;
+  hipLaunchKernelGGL(nms_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, scores);
+}
+
+void launch_nms_epoch(const NmsArgs& a, int epoch, hipStream_t s) {
+  const dim3 grid((a.K + NMS_CHUNK - 1) / NMS_CHUNK, a.n_img), block(256);
+  hipLaunchKernelGGL(nms_bound_kernel, grid, block, 0, s, a, epoch);
+  hipLaunchKernelGGL(nms_eval_kernel, grid, block, 0, s, a, epoch);
+  hipLaunchKernelGGL(nms_commit_kernel, grid, block, 0, s, a, epoch);
+}
+
+void launch_nms_finish(const NmsArgs&, int, hipStream_t) {}
+
+// ------------------------------------------------------------------------------------ gather / pack
+__global__ __launch_bounds__(128) void gather_kernel(GatherArgs a) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= a.n_img * a.M) return;
+  const int n = gid / a.M, i = gid % a.M;
+  const int valid = a.nsel[n];
+  if (i == 0) a.out_valid[n] = valid;
+  const int idx = (i < valid) ? a.sel_idx[gid] : 0;   // padded slots replicate candidate 0
+  const size_t src = (size_t)n * a.K + idx;
+  const float sc = a.scales ? a.scales[n] : 1.0f;
+  float* ob = a.out_boxes + (size_t)gid * a.box_cols;
+  const float hi[4] = {a.clip_h, a.clip_w, a.clip_h, a.clip_w};
+  for (int k = 0; k < 4; ++k) {
+    float v = a.boxes[src * 4 + k];
+    if (a.clip) v = fminf(fmaxf(v, 0.0f), hi[k]);
+    ob[k] = a.scales ? v * sc : v;
+  }
+  int col = 4;
+  if (a.u_al) {
+    for (int k = 0; k < 4; ++k) ob[col + k] = a.scales ? a.u_al[src * 4 + k] * sc : a.u_al[src * 4 + k];
+    col += 4;
+  }
+  if (a.u_ep) {
+    for (int k = 0; k < 4; ++k) ob[col + k] = a.scales ? a.u_ep[src * 4 + k] * sc : a.u_ep[src * 4 + k];
+    col += 4;
+  }
+  a.out_scores[gid] = (i < valid) ? a.sel_score[gid] : 0.0f;
+  float* oc = a.out_classes + (size_t)gid * a.cls_cols;
+  oc[0] = (float)(a.classes[src] + 1);
+  if (a.u_cls)
+    for (int c = 0; c < a.C; ++c) oc[1 + c] = a.u_cls[src * a.C + c];
+  if (a.out_logits)
+    for (int c = 0; c < a.C; ++c) a.out_logits[(size_t)gid * a.C + c] = a.logits[src * a.C + c];
+}
+
+void launch_gather(const GatherArgs& a, hipStream_t s) {
+  const int total = a.n_img * a.M;
+  hipLaunchKernelGGL(gather_kernel, dim3((total + 127) / 128), dim3(128), 0, s, a);
+}
+
+}  // namespace uda

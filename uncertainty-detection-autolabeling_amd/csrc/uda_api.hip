@@ -1,0 +1,910 @@
+// Host side of the C ABI (include/uda_hip.h): owns one GPU's weights, arena, head-output and
+// post-process workspaces and a HIP stream, and executes the op list that plan.py lowered
+// from the reference's model description.  No torch, no Python types.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "uda_internal.h"
+
+using namespace uda;
+
+static thread_local std::string g_create_error;
+
+struct ProfSlot {
+  double total_ms = 0;
+  int64_t launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct uda_ctx {
+  uda_model_t model;
+  std::vector<uda_buf_desc_t> bufs;
+  std::vector<uda_op_t> ops;
+  std::vector<uda_drop_site_t> sites;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  float* d_weights = nullptr;
+  int64_t n_weights = 0;
+  float* d_arena = nullptr;
+  float* d_anchors = nullptr;
+  int A_tot = 0;
+  int a_off[UDA_MAX_LEVELS + 1];
+
+  // inputs
+  uint8_t* d_u8 = nullptr;
+  size_t u8_cap = 0;
+  int raw_h = 0, raw_w = 0;
+  bool have_u8 = false;
+  float* d_images = nullptr;   // [max_images, H, W, 3]
+  float* d_scales = nullptr;   // [max_images]
+  std::vector<float> h_scales;
+  int n_images = 0;
+  int sh = 0, sw = 0;
+
+  // dropout
+  float* d_masks = nullptr;
+  int64_t mask_cap = 0;        // floats
+  int64_t sum_site_ch = 0;
+  int max_c4 = 0;
+  std::vector<int64_t> site_off;
+  int64_t* d_site_off = nullptr;
+  int32_t* d_site_ch = nullptr;
+  float* d_site_rate = nullptr;
+  bool masks_injected = false;
+  int masks_rows = 0;
+  uint64_t seed = 0;
+
+  // head outputs [max_images * Tx, hw, ch] per level
+  float* d_cls[UDA_MAX_LEVELS] = {};
+  float* d_box[UDA_MAX_LEVELS] = {};
+  int cls_ch = 0, box_ch = 0;
+
+  // candidates
+  float *d_cboxes = nullptr, *d_cscores = nullptr, *d_clogits = nullptr;
+  int32_t* d_cclasses = nullptr;
+  float *d_ucls = nullptr, *d_ual = nullptr, *d_uep = nullptr;
+  // nms workspace
+  float *d_stale = nullptr, *d_tent = nullptr, *d_sel_score = nullptr, *d_sel_box = nullptr;
+  int32_t *d_begin = nullptr, *d_sel_idx = nullptr, *d_nsel = nullptr, *d_done = nullptr;
+  unsigned long long *d_bound = nullptr, *d_win = nullptr;
+  // outputs
+  float *d_oboxes = nullptr, *d_oscores = nullptr, *d_oclasses = nullptr, *d_ologits = nullptr;
+  int32_t* d_ovalid = nullptr;
+  int last_post_mode = 0;
+  int last_n = 0;
+  int last_chunk_i0 = 0, last_chunk_n = 0;
+
+  uint32_t prof_mask = 0;
+  ProfSlot prof[32];
+};
+
+static int fail(uda_ctx* c, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else g_create_error = buf;
+  return 1;
+}
+
+#define HIPC(ctx, expr)                                                                   \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(ctx, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+template <typename T>
+static hipError_t dalloc(T** p, size_t n) {
+  return hipMalloc((void**)p, (n ? n : 1) * sizeof(T));
+}
+
+static inline int same_pad_before(int in, int out, int k, int s) {
+  int total = (out - 1) * s + k - in;
+  if (total < 0) total = 0;
+  return total / 2;
+}
+
+// ------------------------------------------------------------------------------------ profiling helpers
+struct ProfScope {
+  uda_ctx* c;
+  int kind;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool on;
+  ProfScope(uda_ctx* c_, int kind_) : c(c_), kind(kind_) {
+    on = (c->prof_mask >> kind) & 1u;
+    if (on) {
+      hipEventCreate(&e0);
+      hipEventCreate(&e1);
+      hipEventRecord(e0, c->stream);
+    }
+  }
+  ~ProfScope() {
+    if (on) {
+      hipEventRecord(e1, c->stream);
+      c->prof[kind].pending.emplace_back(e0, e1);
+    }
+  }
+};
+
+static void prof_collect(uda_ctx* c, int kind) {
+  ProfSlot& s = c->prof[kind];
+  for (auto& pr : s.pending) {
+    hipEventSynchronize(pr.second);
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+      s.total_ms += ms;
+      s.launches += 1;
+    }
+    hipEventDestroy(pr.first);
+    hipEventDestroy(pr.second);
+  }
+  s.pending.clear();
+}
+
+// ------------------------------------------------------------------------------------ create / destroy
+extern "C" const char* uda_last_error(const uda_ctx_t* ctx) {
+  return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+extern "C" void uda_destroy(uda_ctx_t* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  for (int k = 0; k < 32; ++k) prof_collect(c, k);
+  void* ptrs[] = {c->d_weights, c->d_arena, c->d_anchors, c->d_u8, c->d_images, c->d_scales, c->d_masks,
+                  c->d_site_off, c->d_site_ch, c->d_site_rate, c->d_cboxes, c->d_cscores, c->d_clogits,
+                  c->d_cclasses, c->d_ucls, c->d_ual, c->d_uep, c->d_stale, c->d_tent, c->d_sel_score,
+                  c->d_sel_box, c->d_begin, c->d_sel_idx, c->d_nsel, c->d_done, c->d_bound, c->d_win,
+                  c->d_oboxes, c->d_oscores, c->d_oclasses, c->d_ologits, c->d_ovalid};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  for (int l = 0; l < UDA_MAX_LEVELS; ++l) {
+    if (c->d_cls[l]) hipFree(c->d_cls[l]);
+    if (c->d_box[l]) hipFree(c->d_box[l]);
+  }
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+static int box_cols_of(const uda_model_t& m, int post_mode) {
+  if (post_mode == UDA_POST_PER_CLASS) return 4;
+  int cols = 4;
+  if (m.has_uncert && m.loss_attenuation) cols += 4;
+  if (m.has_uncert && m.box_stacked) cols += 4;
+  return cols;
+}
+static int cls_cols_of(const uda_model_t& m, int post_mode) {
+  if (post_mode == UDA_POST_PER_CLASS) return 1;
+  return 1 + ((m.has_uncert && m.cls_stacked) ? m.num_classes : 0);
+}
+
+extern "C" int uda_detection_cols(const uda_ctx_t* c, int32_t post_mode, int32_t* box_cols, int32_t* cls_cols) {
+  if (!c) return 1;
+  const int pm = post_mode < 0 ? c->model.post_mode : post_mode;
+  if (box_cols) *box_cols = box_cols_of(c->model, pm);
+  if (cls_cols) *cls_cols = cls_cols_of(c->model, pm);
+  return 0;
+}
+
+extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, int32_t n_bufs,
+                          const uda_op_t* ops, int32_t n_ops, const uda_drop_site_t* sites,
+                          const float* weights, int64_t n_weights, const float* anchors,
+                          int32_t device, uda_ctx_t** out) {
+  if (!out) return fail(nullptr, "uda_create: out is NULL");
+  *out = nullptr;
+  if (!model || !bufs || !ops || !weights || !anchors) return fail(nullptr, "uda_create: NULL argument");
+  if (model->abi_version != UDA_ABI_VERSION)
+    return fail(nullptr, "uda_create: ABI version %d, library has %d", model->abi_version, UDA_ABI_VERSION);
+  if (model->num_levels < 1 || model->num_levels > UDA_MAX_LEVELS)
+    return fail(nullptr, "uda_create: num_levels %d out of range", model->num_levels);
+  if (model->chunk_images < 1 || model->max_images < 1 || model->mc_samples < 1)
+    return fail(nullptr, "uda_create: chunk_images/max_images/mc_samples must be >= 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, "uda_create: no HIP device available (the HIP path has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(nullptr, "uda_create: device %d of %d", device, ndev);
+
+  uda_ctx* c = new uda_ctx();
+  c->model = *model;
+  c->bufs.assign(bufs, bufs + n_bufs);
+  c->ops.assign(ops, ops + n_ops);
+  if (model->n_drop_sites > 0 && sites) c->sites.assign(sites, sites + model->n_drop_sites);
+  c->device = device;
+  c->n_weights = n_weights;
+#define CK(expr)                                                                                  \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      fail(nullptr, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);  \
+      uda_destroy(c);                                                                             \
+      return 1;                                                                                   \
+    }                                                                                             \
+  } while (0)
+  CK(hipSetDevice(device));
+  CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+
+  const uda_model_t& m = c->model;
+  const int T = m.mc_samples;
+  // validate the op list against the buffer table before anything is launched
+  for (int i = 0; i < n_ops; ++i) {
+    const uda_op_t& o = ops[i];
+    auto okbuf = [&](int id) { return id >= 0 && id < n_bufs; };
+    if (!okbuf(o.out)) { fail(nullptr, "op %d: bad out buffer %d", i, o.out); uda_destroy(c); return 1; }
+    for (int j = 0; j < o.n_in; ++j)
+      if (!okbuf(o.in[j])) { fail(nullptr, "op %d: bad in[%d] buffer %d", i, j, o.in[j]); uda_destroy(c); return 1; }
+    if (o.drop_site >= m.n_drop_sites) { fail(nullptr, "op %d: bad drop site %d", i, o.drop_site); uda_destroy(c); return 1; }
+    if (o.drop_site >= 0 && c->sites[o.drop_site].channels != bufs[o.out].C) {
+      fail(nullptr, "op %d: drop site %d has %d channels, output has %d", i, o.drop_site,
+           c->sites[o.drop_site].channels, bufs[o.out].C);
+      uda_destroy(c);
+      return 1;
+    }
+    const int64_t offs[] = {o.w_off, o.bias_off, o.bn_scale_off, o.bn_shift_off, o.se_w1_off, o.se_b1_off, o.se_w2_off, o.se_b2_off};
+    for (int64_t off : offs)
+      if (off >= n_weights) { fail(nullptr, "op %d: weight offset %lld beyond blob (%lld)", i, (long long)off, (long long)n_weights); uda_destroy(c); return 1; }
+    if ((o.kind == UDA_OP_PW || o.kind == UDA_OP_DW) && (bufs[o.in[0]].C % 4 || bufs[o.out].C % 1)) {
+      fail(nullptr, "op %d: channel count %d not a multiple of 4", i, bufs[o.in[0]].C);
+      uda_destroy(c);
+      return 1;
+    }
+  }
+  for (int i = 0; i < n_bufs; ++i) {
+    const uda_buf_desc_t& b = bufs[i];
+    if (b.kind == 0) {
+      const int64_t rows = (int64_t)m.chunk_images * (b.per_sample ? T : 1);
+      const int64_t end = b.offset + rows * b.H * b.W * b.C;
+      if (b.offset < 0 || end > m.arena_floats) {
+        fail(nullptr, "buffer %d [%dx%dx%d] exceeds the arena (%lld > %lld)", i, b.H, b.W, b.C,
+             (long long)end, (long long)m.arena_floats);
+        uda_destroy(c);
+        return 1;
+      }
+    }
+  }
+
+  CK(dalloc(&c->d_weights, (size_t)n_weights));
+  CK(hipMemcpy(c->d_weights, weights, (size_t)n_weights * sizeof(float), hipMemcpyHostToDevice));
+  CK(dalloc(&c->d_arena, (size_t)m.arena_floats));
+
+  c->a_off[0] = 0;
+  for (int l = 0; l < m.num_levels; ++l)
+    c->a_off[l + 1] = c->a_off[l] + m.level_h[l] * m.level_w[l] * m.anchors_per_loc;
+  c->A_tot = c->a_off[m.num_levels];
+  CK(dalloc(&c->d_anchors, (size_t)c->A_tot * 4));
+  CK(hipMemcpy(c->d_anchors, anchors, (size_t)c->A_tot * 4 * sizeof(float), hipMemcpyHostToDevice));
+
+  const size_t N = (size_t)m.max_images;
+  CK(dalloc(&c->d_images, N * m.image_h * m.image_w * 3));
+  CK(dalloc(&c->d_scales, N));
+  c->h_scales.assign(N, 1.0f);
+
+  // dropout sites
+  c->sum_site_ch = 0;
+  c->max_c4 = 0;
+  std::vector<int32_t> ch;
+  std::vector<float> rate;
+  for (auto& s : c->sites) {
+    c->sum_site_ch += s.channels;
+    ch.push_back(s.channels);
+    rate.push_back(s.rate);
+    if ((s.channels + 3) / 4 > c->max_c4) c->max_c4 = (s.channels + 3) / 4;
+  }
+  c->mask_cap = c->sum_site_ch * (int64_t)N * T;
+  c->site_off.assign(c->sites.size() + 1, 0);
+  if (!c->sites.empty()) {
+    CK(dalloc(&c->d_masks, (size_t)c->mask_cap));
+    CK(dalloc(&c->d_site_off, c->sites.size()));
+    CK(dalloc(&c->d_site_ch, c->sites.size()));
+    CK(dalloc(&c->d_site_rate, c->sites.size()));
+    CK(hipMemcpy(c->d_site_ch, ch.data(), ch.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    CK(hipMemcpy(c->d_site_rate, rate.data(), rate.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+
+  // head outputs
+  c->cls_ch = m.anchors_per_loc * m.num_classes;
+  c->box_ch = m.anchors_per_loc * (m.loss_attenuation ? 8 : 4);
+  for (int l = 0; l < m.num_levels; ++l) {
+    const size_t hw = (size_t)m.level_h[l] * m.level_w[l];
+    CK(dalloc(&c->d_cls[l], N * (m.cls_stacked ? T : 1) * hw * c->cls_ch));
+    CK(dalloc(&c->d_box[l], N * (m.box_stacked ? T : 1) * hw * c->box_ch));
+  }
+
+  // candidates + nms + outputs
+  const size_t K = (size_t)c->A_tot, M = (size_t)m.max_output_size, C = (size_t)m.num_classes;
+  CK(dalloc(&c->d_cboxes, N * K * 4));
+  CK(dalloc(&c->d_cscores, N * K));
+  CK(dalloc(&c->d_cclasses, N * K));
+  CK(dalloc(&c->d_clogits, N * K * C));
+  if (m.has_uncert && m.cls_stacked) CK(dalloc(&c->d_ucls, N * K * C));
+  if (m.has_uncert && m.loss_attenuation) CK(dalloc(&c->d_ual, N * K * 4));
+  if (m.has_uncert && m.box_stacked) CK(dalloc(&c->d_uep, N * K * 4));
+  CK(dalloc(&c->d_stale, N * K));
+  CK(dalloc(&c->d_tent, N * K));
+  CK(dalloc(&c->d_begin, N * K));
+  CK(dalloc(&c->d_sel_idx, N * M));
+  CK(dalloc(&c->d_sel_score, N * M));
+  CK(dalloc(&c->d_sel_box, N * M * 4));
+  CK(dalloc(&c->d_bound, N * M));
+  CK(dalloc(&c->d_win, N * M));
+  CK(dalloc(&c->d_nsel, N));
+  CK(dalloc(&c->d_done, N));
+  CK(dalloc(&c->d_oboxes, N * M * 12));
+  CK(dalloc(&c->d_oscores, N * M));
+  CK(dalloc(&c->d_oclasses, N * M * (1 + C)));
+  CK(dalloc(&c->d_ologits, N * M * C));
+  CK(dalloc(&c->d_ovalid, N));
+#undef CK
+  *out = c;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ inputs
+static int set_scales_for_raw(uda_ctx* c, int n, int h, int w) {
+  // scale = min(H/h, W/w) in float32; scaled size = int(h*scale), int(w*scale)  (dataloader.py:123-135)
+  const float sy = (float)c->model.image_h / (float)h;
+  const float sx = (float)c->model.image_w / (float)w;
+  const float s = sx < sy ? sx : sy;
+  c->sh = (int)((float)h * s);
+  c->sw = (int)((float)w * s);
+  if (c->sh > c->model.image_h) c->sh = c->model.image_h;
+  if (c->sw > c->model.image_w) c->sw = c->model.image_w;
+  for (int i = 0; i < n; ++i) c->h_scales[i] = 1.0f / s;
+  return 0;
+}
+
+static int stage_u8(uda_ctx* c, const void* src, int n, int h, int w, hipMemcpyKind kind) {
+  if (!c) return 1;
+  if (n < 1 || n > c->model.max_images) return fail(c, "set_images: n=%d outside [1, %d]", n, c->model.max_images);
+  if (h < 1 || w < 1) return fail(c, "set_images: bad image size %dx%d", h, w);
+  HIPC(c, hipSetDevice(c->device));
+  const size_t bytes = (size_t)n * h * w * 3;
+  if (bytes > c->u8_cap) {
+    if (c->d_u8) HIPC(c, hipFree(c->d_u8));
+    c->d_u8 = nullptr;
+    HIPC(c, hipMalloc((void**)&c->d_u8, bytes));
+    c->u8_cap = bytes;
+  }
+  HIPC(c, hipMemcpyAsync(c->d_u8, src, bytes, kind, c->stream));
+  c->raw_h = h;
+  c->raw_w = w;
+  c->n_images = n;
+  c->have_u8 = true;
+  set_scales_for_raw(c, n, h, w);
+  HIPC(c, hipMemcpyAsync(c->d_scales, c->h_scales.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+extern "C" int uda_set_images_u8(uda_ctx_t* c, const uint8_t* images, int32_t n, int32_t h, int32_t w) {
+  if (!c || !images) return c ? fail(c, "set_images_u8: NULL images") : 1;
+  return stage_u8(c, images, n, h, w, hipMemcpyHostToDevice);
+}
+
+extern "C" int uda_set_images_u8_device(uda_ctx_t* c, const void* images_dev, int32_t n, int32_t h, int32_t w) {
+  if (!c || !images_dev) return c ? fail(c, "set_images_u8_device: NULL images") : 1;
+  return stage_u8(c, images_dev, n, h, w, hipMemcpyDeviceToDevice);
+}
+
+extern "C" int uda_set_images_f32(uda_ctx_t* c, const float* images, int32_t n, const float* image_scales) {
+  if (!c || !images) return c ? fail(c, "set_images_f32: NULL images") : 1;
+  if (n < 1 || n > c->model.max_images) return fail(c, "set_images_f32: n=%d outside [1, %d]", n, c->model.max_images);
+  HIPC(c, hipSetDevice(c->device));
+  const size_t fl = (size_t)n * c->model.image_h * c->model.image_w * 3;
+  HIPC(c, hipMemcpyAsync(c->d_images, images, fl * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  for (int i = 0; i < n; ++i) c->h_scales[i] = image_scales ? image_scales[i] : 1.0f;
+  HIPC(c, hipMemcpyAsync(c->d_scales, c->h_scales.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  c->n_images = n;
+  c->have_u8 = false;
+  return 0;
+}
+
+extern "C" int uda_set_dropout_seed(uda_ctx_t* c, uint64_t seed) {
+  if (!c) return 1;
+  c->seed = seed;
+  c->masks_injected = false;
+  return 0;
+}
+
+extern "C" int uda_set_dropout_masks(uda_ctx_t* c, const float* masks, int64_t n_floats) {
+  if (!c || !masks) return c ? fail(c, "set_dropout_masks: NULL") : 1;
+  if (n_floats > c->mask_cap || (c->sum_site_ch && n_floats % c->sum_site_ch))
+    return fail(c, "set_dropout_masks: %lld floats is not rows*%lld (capacity %lld)", (long long)n_floats,
+                (long long)c->sum_site_ch, (long long)c->mask_cap);
+  HIPC(c, hipSetDevice(c->device));
+  if (n_floats) HIPC(c, hipMemcpyAsync(c->d_masks, masks, n_floats * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  c->masks_injected = true;
+  c->masks_rows = c->sum_site_ch ? (int)(n_floats / c->sum_site_ch) : 0;
+  return 0;
+}
+
+extern "C" int uda_get_dropout_masks(uda_ctx_t* c, float* masks, int64_t n_floats) {
+  if (!c || !masks) return 1;
+  if (n_floats > c->mask_cap) return fail(c, "get_dropout_masks: too many floats");
+  HIPC(c, hipSetDevice(c->device));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  if (n_floats) HIPC(c, hipMemcpy(masks, c->d_masks, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ op execution
+struct ChunkView {
+  uda_ctx* c;
+  int i0, nc;
+  int rows(const uda_buf_desc_t& b) const { return nc * (b.per_sample ? c->model.mc_samples : 1); }
+  float* ptr(int id) const {
+    const uda_buf_desc_t& b = c->bufs[id];
+    const size_t per = (size_t)b.H * b.W * b.C;
+    const int T = c->model.mc_samples;
+    switch (b.kind) {
+      case 1: return c->d_images + (size_t)i0 * per;
+      case 2: return c->d_cls[b.level] + (size_t)i0 * (b.per_sample ? T : 1) * per;
+      case 3: return c->d_box[b.level] + (size_t)i0 * (b.per_sample ? T : 1) * per;
+      default: return c->d_arena + b.offset;
+    }
+  }
+  const float* wt(int64_t off) const { return off < 0 ? nullptr : c->d_weights + off; }
+  const float* mask(int site) const {
+    if (site < 0) return nullptr;
+    return c->d_masks + c->site_off[site] + (size_t)i0 * c->model.mc_samples * c->sites[site].channels;
+  }
+  int div(const uda_buf_desc_t& in, const uda_buf_desc_t& out) const {
+    return (out.per_sample && !in.per_sample) ? c->model.mc_samples : 1;
+  }
+};
+
+static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
+  const uda_op_t& o = c->ops[oi];
+  const uda_buf_desc_t& ob = c->bufs[o.out];
+  const int rows = v.rows(ob);
+  ProfScope ps(c, o.kind);
+  switch (o.kind) {
+    case UDA_OP_STEM: {
+      const uda_buf_desc_t& ib = c->bufs[o.in[0]];
+      if (ib.C != 3 || ob.C % 4) return fail(c, "op %d: stem needs 3 -> 4k channels", oi);
+      if (ib.per_sample != ob.per_sample) return fail(c, "op %d: stem cannot change the sample axis", oi);
+      StemArgs a{};
+      a.in = v.ptr(o.in[0]);
+      a.out = v.ptr(o.out);
+      a.w = v.wt(o.w_off);
+      a.bn_scale = v.wt(o.bn_scale_off);
+      a.bn_shift = v.wt(o.bn_shift_off);
+      a.H = ib.H; a.W = ib.W; a.Ho = ob.H; a.Wo = ob.W; a.Co = ob.C;
+      a.pad_t = same_pad_before(ib.H, ob.H, 3, 2);
+      a.pad_l = same_pad_before(ib.W, ob.W, 3, 2);
+      a.rows = rows;
+      launch_stem(a, c->stream);
+      break;
+    }
+    case UDA_OP_PW: {
+      const uda_buf_desc_t& ib = c->bufs[o.in[0]];
+      if (ib.H != ob.H || ib.W != ob.W) return fail(c, "op %d: 1x1 conv changes the spatial size", oi);
+      PwArgs a{};
+      a.in = v.ptr(o.in[0]);
+      a.out = v.ptr(o.out);
+      a.w = v.wt(o.w_off);
+      a.bias = v.wt(o.bias_off);
+      a.bn_scale = v.wt(o.bn_scale_off);
+      a.bn_shift = v.wt(o.bn_shift_off);
+      a.se = o.se_scale >= 0 ? v.ptr(o.se_scale) : nullptr;
+      if (o.se_scale >= 0 && c->bufs[o.se_scale].per_sample != ib.per_sample)
+        return fail(c, "op %d: SE gate and input disagree on the sample axis", oi);
+      a.mask = v.mask(o.drop_site);
+      a.res = o.residual >= 0 ? v.ptr(o.residual) : nullptr;
+      a.HW = ob.H * ob.W; a.Cin = ib.C; a.Cout = ob.C;
+      a.in_div = v.div(ib, ob);
+      a.res_div = o.residual >= 0 ? v.div(c->bufs[o.residual], ob) : 1;
+      a.act = o.act;
+      launch_pw(a, rows, c->stream);
+      break;
+    }
+    case UDA_OP_DW: {
+      const uda_buf_desc_t& ib = c->bufs[o.in[0]];
+      if (ib.C != ob.C) return fail(c, "op %d: depthwise changes channels", oi);
+      if (!((o.k == 3 || o.k == 5) && (o.stride == 1 || o.stride == 2)))
+        return fail(c, "op %d: depthwise k=%d s=%d unsupported", oi, o.k, o.stride);
+      DwArgs a{};
+      a.in = v.ptr(o.in[0]);
+      a.out = v.ptr(o.out);
+      a.w = v.wt(o.w_off);
+      a.bn_scale = v.wt(o.bn_scale_off);
+      a.bn_shift = v.wt(o.bn_shift_off);
+      a.mask = v.mask(o.drop_site);
+      a.H = ib.H; a.W = ib.W; a.Ho = ob.H; a.Wo = ob.W; a.C = ob.C;
+      a.pad_t = same_pad_before(ib.H, ob.H, o.k, o.stride);
+      a.pad_l = same_pad_before(ib.W, ob.W, o.k, o.stride);
+      a.in_div = v.div(ib, ob);
+      a.act = o.act;
+      if (o.se_partial >= 0) {
+        int tc, pxb, ncc, gx, xb;
+        dw_geometry(ob.C, ob.W, o.stride, &tc, &pxb, &ncc, &gx, &xb);
+        const uda_buf_desc_t& pb = c->bufs[o.se_partial];
+        if ((int64_t)pb.H * pb.W < (int64_t)ob.H * gx || pb.C != ob.C || pb.per_sample != ob.per_sample)
+          return fail(c, "op %d: SE partial buffer [%d,%d,%d] too small for %d tiles", oi, pb.H, pb.W, pb.C, ob.H * gx);
+        a.se_partial = v.ptr(o.se_partial);
+      }
+      launch_dw(a, rows, o.k, o.stride, c->stream);
+      break;
+    }
+    case UDA_OP_SE: {
+      const uda_buf_desc_t& pb = c->bufs[o.in[0]];   // partial sums written by the DW op
+      const uda_buf_desc_t& src = c->bufs[o.in[1]];  // the DW output (for H*W and geometry)
+      int tc, pxb, ncc, gx, xb;
+      dw_geometry(src.C, src.W, o.stride, &tc, &pxb, &ncc, &gx, &xb);
+      SeArgs a{};
+      a.partial = v.ptr(o.in[0]);
+      a.scale = v.ptr(o.out);
+      a.w1 = v.wt(o.se_w1_off); a.b1 = v.wt(o.se_b1_off);
+      a.w2 = v.wt(o.se_w2_off); a.b2 = v.wt(o.se_b2_off);
+      a.C = src.C; a.mid = o.se_mid; a.n_tiles = src.H * gx;
+      a.inv_hw = 1.0f / (float)(src.H * src.W);
+      if (pb.C != src.C || ob.C != src.C) return fail(c, "op %d: SE channel mismatch", oi);
+      launch_se(a, rows, c->stream);
+      break;
+    }
+    case UDA_OP_FUSE:
+    case UDA_OP_POOL: {
+      FuseArgs a{};
+      a.n_in = o.n_in;
+      a.H = ob.H; a.W = ob.W; a.C = ob.C;
+      a.out = v.ptr(o.out);
+      a.act = o.act;
+      a.total = (int64_t)rows * ob.H * ob.W * (ob.C / 4);
+      if (ob.C % 4) return fail(c, "op %d: fuse needs channels %% 4 == 0", oi);
+      for (int i = 0; i < o.n_in; ++i) {
+        const uda_buf_desc_t& ib = c->bufs[o.in[i]];
+        if (ib.C != ob.C) return fail(c, "op %d: fuse input %d has %d channels, output %d", oi, i, ib.C, ob.C);
+        a.in[i] = v.ptr(o.in[i]);
+        a.wgt[i] = (o.kind == UDA_OP_POOL) ? 1.0f : o.fuse_w[i];
+        a.mode[i] = o.resample[i];
+        a.Hi[i] = ib.H; a.Wi[i] = ib.W;
+        a.in_div[i] = v.div(ib, ob);
+        if (a.mode[i] == UDA_RS_NONE) {
+          if (ib.H != ob.H || ib.W != ob.W) return fail(c, "op %d: fuse input %d size mismatch", oi, i);
+        } else if (a.mode[i] == UDA_RS_NEAREST_UP) {
+          if (ib.H > ob.H || ib.W > ob.W) return fail(c, "op %d: nearest-up input %d larger than output", oi, i);
+          a.sy[i] = (float)ib.H / (float)ob.H;
+          a.sx[i] = (float)ib.W / (float)ob.W;
+        } else {
+          const int sh_ = (ib.H - 1) / ob.H + 1, sw_ = (ib.W - 1) / ob.W + 1;
+          if (sh_ != sw_) return fail(c, "op %d: non-square pooling window", oi);
+          a.ps[i] = sh_;
+          a.pk[i] = sh_ + 1;
+          if ((ib.H + sh_ - 1) / sh_ != ob.H || (ib.W + sh_ - 1) / sh_ != ob.W)
+            return fail(c, "op %d: pooled size mismatch", oi);
+          a.ppt[i] = same_pad_before(ib.H, ob.H, a.pk[i], a.ps[i]);
+          a.ppl[i] = same_pad_before(ib.W, ob.W, a.pk[i], a.ps[i]);
+        }
+      }
+      launch_fuse(a, c->stream);
+      break;
+    }
+    default:
+      return fail(c, "op %d: unknown kind %d", oi, o.kind);
+  }
+  return 0;
+}
+
+static int run_network(uda_ctx* c) {
+  const uda_model_t& m = c->model;
+  const int n = c->n_images, T = m.mc_samples;
+  if (c->have_u8) {
+    ProfScope ps(c, 18);
+    PreprocArgs a{};
+    a.in = c->d_u8; a.out = c->d_images;
+    a.n = n; a.h = c->raw_h; a.w = c->raw_w; a.H = m.image_h; a.W = m.image_w;
+    a.sh = c->sh; a.sw = c->sw;
+    for (int k = 0; k < 3; ++k) { a.mean[k] = m.mean_rgb[k]; a.stdv[k] = m.stddev_rgb[k]; }
+    a.scale_y = (float)c->raw_h / (float)c->sh;
+    a.scale_x = (float)c->raw_w / (float)c->sw;
+    launch_preprocess(a, c->stream);
+  }
+  if (!c->sites.empty()) {
+    const int rows = n * T;
+    if (c->masks_injected && c->masks_rows != rows)
+      return fail(c, "injected dropout masks cover %d sample rows, the run has %d", c->masks_rows, rows);
+    int64_t off = 0;
+    for (size_t s = 0; s < c->sites.size(); ++s) {
+      c->site_off[s] = off;
+      off += (int64_t)rows * c->sites[s].channels;
+    }
+    if (!c->masks_injected) {
+      HIPC(c, hipMemcpyAsync(c->d_site_off, c->site_off.data(), c->sites.size() * sizeof(int64_t),
+                             hipMemcpyHostToDevice, c->stream));
+      launch_philox_masks(c->d_masks, c->d_site_off, c->d_site_ch, c->d_site_rate, (int)c->sites.size(), rows,
+                          c->max_c4, c->seed, c->stream);
+    }
+  }
+  for (int i0 = 0; i0 < n; i0 += m.chunk_images) {
+    ChunkView v{c, i0, (n - i0 < m.chunk_images) ? n - i0 : m.chunk_images};
+    for (int oi = 0; oi < (int)c->ops.size(); ++oi) {
+      const int rc = run_op(c, v, oi);
+      if (rc) return rc;
+    }
+    c->last_chunk_i0 = i0;
+    c->last_chunk_n = v.nc;
+  }
+  HIPC(c, hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ post-process
+static NmsArgs nms_args_of(uda_ctx* c, int n, int K, int M, const float* boxes) {
+  NmsArgs a{};
+  a.boxes = boxes;
+  a.stale = c->d_stale; a.begin = c->d_begin; a.tent = c->d_tent;
+  a.sel_idx = c->d_sel_idx; a.sel_score = c->d_sel_score; a.sel_box = c->d_sel_box;
+  a.bound_key = c->d_bound; a.win_key = c->d_win; a.nsel = c->d_nsel; a.done = c->d_done;
+  a.n_img = n; a.K = K; a.M = M;
+  return a;
+}
+
+static void nms_params(NmsArgs& a, float iou_thr, float score_thr, float soft_sigma) {
+  a.iou_thr = iou_thr;
+  a.score_thr = score_thr;
+  a.soft = soft_sigma > 0.0f;
+  a.scale = a.soft ? -0.5f / soft_sigma : 0.0f;
+}
+
+static int run_post_global(uda_ctx* c, int n) {
+  const uda_model_t& m = c->model;
+  if (m.max_nms_inputs > 0) return fail(c, "max_nms_inputs > 0 (top-k pre-selection) is not built yet");
+  {
+    ProfScope ps(c, 16);
+    AggArgs a{};
+    a.lv.num_levels = m.num_levels;
+    for (int l = 0; l < m.num_levels; ++l) {
+      a.lv.hw[l] = m.level_h[l] * m.level_w[l];
+      a.lv.a_off[l] = c->a_off[l];
+      a.lv.cls[l] = c->d_cls[l];
+      a.lv.box[l] = c->d_box[l];
+    }
+    a.lv.a_off[m.num_levels] = c->A_tot;
+    a.anchors = c->d_anchors;
+    a.n_img = n; a.A_tot = c->A_tot; a.A = m.anchors_per_loc; a.C = m.num_classes;
+    a.Tc = m.cls_stacked ? m.mc_samples : 1;
+    a.Tb = m.box_stacked ? m.mc_samples : 1;
+    a.loss_att = m.loss_attenuation;
+    a.decode = m.decode_method;
+    a.boxes = c->d_cboxes; a.scores = c->d_cscores; a.classes = c->d_cclasses; a.logits = c->d_clogits;
+    a.u_cls = c->d_ucls; a.u_al = c->d_ual; a.u_ep = c->d_uep;
+    launch_aggregate(a, c->stream);
+  }
+  const int K = c->A_tot, M = m.max_output_size;
+  {
+    ProfScope ps(c, 17);
+    NmsArgs na = nms_args_of(c, n, K, M, c->d_cboxes);
+    nms_params(na, m.nms_iou_thresh, m.nms_score_thresh, m.nms_soft_sigma);
+    launch_nms_init(na, c->d_cscores, c->stream);
+    for (int k = 0; k < M; ++k) launch_nms_epoch(na, k, c->stream);
+  }
+  GatherArgs g{};
+  g.sel_idx = c->d_sel_idx; g.sel_score = c->d_sel_score; g.nsel = c->d_nsel;
+  g.boxes = c->d_cboxes; g.classes = c->d_cclasses; g.logits = c->d_clogits;
+  g.u_cls = c->d_ucls; g.u_al = c->d_ual; g.u_ep = c->d_uep;
+  g.scales = c->d_scales;
+  g.out_boxes = c->d_oboxes; g.out_scores = c->d_oscores; g.out_classes = c->d_oclasses;
+  g.out_valid = c->d_ovalid; g.out_logits = c->d_ologits;
+  g.n_img = n; g.K = K; g.M = M; g.C = m.num_classes;
+  g.box_cols = box_cols_of(m, UDA_POST_GLOBAL);
+  g.cls_cols = cls_cols_of(m, UDA_POST_GLOBAL);
+  g.clip_h = (float)m.image_h; g.clip_w = (float)m.image_w; g.clip = 1;
+  launch_gather(g, c->stream);
+  HIPC(c, hipGetLastError());
+  c->last_post_mode = UDA_POST_GLOBAL;
+  c->last_n = n;
+  return 0;
+}
+
+static int run_post(uda_ctx* c, int n, int post_mode) {
+  const int pm = post_mode < 0 ? c->model.post_mode : post_mode;
+  if (pm == UDA_POST_GLOBAL) return run_post_global(c, n);
+  return fail(c, "post mode %d (per-class NMS) is not built yet", pm);
+}
+
+extern "C" int uda_run(uda_ctx_t* c, int32_t post_mode, int32_t do_post) {
+  if (!c) return 1;
+  if (c->n_images < 1) return fail(c, "uda_run: no images set");
+  HIPC(c, hipSetDevice(c->device));
+  int rc = run_network(c);
+  if (rc) return rc;
+  if (do_post) rc = run_post(c, c->n_images, post_mode);
+  return rc;
+}
+
+extern "C" int uda_synchronize(uda_ctx_t* c) {
+  if (!c) return 1;
+  HIPC(c, hipSetDevice(c->device));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int uda_get_detections(uda_ctx_t* c, float* boxes, float* scores, float* classes,
+                                  int32_t* valid, float* logits) {
+  if (!c) return 1;
+  HIPC(c, hipSetDevice(c->device));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  const size_t n = c->last_n, M = c->model.max_output_size, C = c->model.num_classes;
+  const int bc = box_cols_of(c->model, c->last_post_mode), cc = cls_cols_of(c->model, c->last_post_mode);
+  if (boxes) HIPC(c, hipMemcpy(boxes, c->d_oboxes, n * M * bc * sizeof(float), hipMemcpyDeviceToHost));
+  if (scores) HIPC(c, hipMemcpy(scores, c->d_oscores, n * M * sizeof(float), hipMemcpyDeviceToHost));
+  if (classes) HIPC(c, hipMemcpy(classes, c->d_oclasses, n * M * cc * sizeof(float), hipMemcpyDeviceToHost));
+  if (valid) HIPC(c, hipMemcpy(valid, c->d_ovalid, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (logits) HIPC(c, hipMemcpy(logits, c->d_ologits, n * M * C * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int uda_serve(uda_ctx_t* c, const uint8_t* images, int32_t n, int32_t h, int32_t w,
+                         float* boxes, float* scores, float* classes, int32_t* valid, float* logits) {
+  int rc = uda_set_images_u8(c, images, n, h, w);
+  if (rc) return rc;
+  rc = uda_run(c, -1, 1);
+  if (rc) return rc;
+  return uda_get_detections(c, boxes, scores, classes, valid, logits);
+}
+
+// ------------------------------------------------------------------------------------ head outputs
+// device layout [n, Tx, hw, ch]  <->  API layout [Tx, n, hw, ch]
+extern "C" int uda_get_head_outputs(uda_ctx_t* c, int32_t level, float* cls, float* box) {
+  if (!c) return 1;
+  if (level < 0 || level >= c->model.num_levels) return fail(c, "get_head_outputs: bad level %d", level);
+  HIPC(c, hipSetDevice(c->device));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  const uda_model_t& m = c->model;
+  const size_t hw = (size_t)m.level_h[level] * m.level_w[level];
+  const int n = c->n_images;
+  struct { float* dst; const float* src; int T; size_t ch; } jobs[2] = {
+      {cls, c->d_cls[level], m.cls_stacked ? m.mc_samples : 1, (size_t)c->cls_ch},
+      {box, c->d_box[level], m.box_stacked ? m.mc_samples : 1, (size_t)c->box_ch}};
+  for (auto& j : jobs) {
+    if (!j.dst) continue;
+    const size_t per = hw * j.ch;
+    for (int i = 0; i < n; ++i)
+      for (int t = 0; t < j.T; ++t)
+        HIPC(c, hipMemcpy(j.dst + ((size_t)t * n + i) * per, j.src + ((size_t)i * j.T + t) * per,
+                          per * sizeof(float), hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+extern "C" int uda_set_head_outputs(uda_ctx_t* c, int32_t level, int32_t n, const float* cls, const float* box) {
+  if (!c) return 1;
+  if (level < 0 || level >= c->model.num_levels) return fail(c, "set_head_outputs: bad level %d", level);
+  if (n < 1 || n > c->model.max_images) return fail(c, "set_head_outputs: n=%d", n);
+  HIPC(c, hipSetDevice(c->device));
+  const uda_model_t& m = c->model;
+  const size_t hw = (size_t)m.level_h[level] * m.level_w[level];
+  struct { const float* src; float* dst; int T; size_t ch; } jobs[2] = {
+      {cls, c->d_cls[level], m.cls_stacked ? m.mc_samples : 1, (size_t)c->cls_ch},
+      {box, c->d_box[level], m.box_stacked ? m.mc_samples : 1, (size_t)c->box_ch}};
+  for (auto& j : jobs) {
+    if (!j.src) continue;
+    const size_t per = hw * j.ch;
+    for (int i = 0; i < n; ++i)
+      for (int t = 0; t < j.T; ++t)
+        HIPC(c, hipMemcpy(j.dst + ((size_t)i * j.T + t) * per, j.src + ((size_t)t * n + i) * per,
+                          per * sizeof(float), hipMemcpyHostToDevice));
+  }
+  c->n_images = n;
+  return 0;
+}
+
+extern "C" int uda_postprocess_heads(uda_ctx_t* c, int32_t n, const float* image_scales, int32_t post_mode) {
+  if (!c) return 1;
+  if (n < 1 || n > c->model.max_images) return fail(c, "postprocess_heads: n=%d", n);
+  HIPC(c, hipSetDevice(c->device));
+  for (int i = 0; i < n; ++i) c->h_scales[i] = image_scales ? image_scales[i] : 1.0f;
+  HIPC(c, hipMemcpyAsync(c->d_scales, c->h_scales.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  c->n_images = n;
+  return run_post(c, n, post_mode);
+}
+
+extern "C" int uda_predict(uda_ctx_t* c, const float* images, int32_t n) {
+  int rc = uda_set_images_f32(c, images, n, nullptr);
+  if (rc) return rc;
+  rc = uda_run(c, -1, 0);
+  if (rc) return rc;
+  return uda_synchronize(c);
+}
+
+extern "C" int32_t uda_num_candidates(const uda_ctx_t* c) { return c ? c->A_tot : 0; }
+
+extern "C" int uda_get_candidates(uda_ctx_t* c, float* boxes, float* scores, int32_t* classes,
+                                  float* u_cls, float* u_al, float* u_ep) {
+  if (!c) return 1;
+  HIPC(c, hipSetDevice(c->device));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  const size_t n = c->last_n, K = c->A_tot, C = c->model.num_classes;
+  if (boxes) HIPC(c, hipMemcpy(boxes, c->d_cboxes, n * K * 4 * sizeof(float), hipMemcpyDeviceToHost));
+  if (scores) HIPC(c, hipMemcpy(scores, c->d_cscores, n * K * sizeof(float), hipMemcpyDeviceToHost));
+  if (classes) HIPC(c, hipMemcpy(classes, c->d_cclasses, n * K * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (u_cls && c->d_ucls) HIPC(c, hipMemcpy(u_cls, c->d_ucls, n * K * C * sizeof(float), hipMemcpyDeviceToHost));
+  if (u_al && c->d_ual) HIPC(c, hipMemcpy(u_al, c->d_ual, n * K * 4 * sizeof(float), hipMemcpyDeviceToHost));
+  if (u_ep && c->d_uep) HIPC(c, hipMemcpy(u_ep, c->d_uep, n * K * 4 * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int uda_read_buffer(uda_ctx_t* c, int32_t buf, float* host, int64_t n_floats) {
+  if (!c || !host) return 1;
+  if (buf < 0 || buf >= (int)c->bufs.size()) return fail(c, "read_buffer: bad buffer %d", buf);
+  HIPC(c, hipSetDevice(c->device));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  ChunkView v{c, c->last_chunk_i0, c->last_chunk_n};
+  const uda_buf_desc_t& b = c->bufs[buf];
+  const int64_t have = (int64_t)v.rows(b) * b.H * b.W * b.C;
+  if (n_floats > have) return fail(c, "read_buffer: asked %lld floats, buffer holds %lld", (long long)n_floats, (long long)have);
+  HIPC(c, hipMemcpy(host, v.ptr(buf), n_floats * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int uda_get_preprocessed(uda_ctx_t* c, float* images, float* scales) {
+  if (!c) return 1;
+  HIPC(c, hipSetDevice(c->device));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  const size_t n = c->n_images;
+  if (images)
+    HIPC(c, hipMemcpy(images, c->d_images, n * c->model.image_h * c->model.image_w * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  if (scales) memcpy(scales, c->h_scales.data(), n * sizeof(float));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ standalone NMS
+extern "C" int uda_nms(uda_ctx_t* c, const float* boxes, const float* scores, int32_t n_img, int32_t k,
+                       int32_t max_out, float iou_thresh, float score_thresh, float soft_sigma, int32_t pad,
+                       int32_t* idx, float* out_scores, int32_t* valid) {
+  if (!c || !boxes || !scores || !idx || !out_scores || !valid) return c ? fail(c, "uda_nms: NULL argument") : 1;
+  if (n_img < 1 || k < 0 || max_out < 1) return fail(c, "uda_nms: bad sizes");
+  HIPC(c, hipSetDevice(c->device));
+  const size_t NK = (size_t)n_img * (k ? k : 1), NM = (size_t)n_img * max_out;
+  float *d_boxes, *d_scores, *d_stale, *d_tent, *d_ss, *d_sb;
+  int32_t *d_begin, *d_si, *d_nsel, *d_done;
+  unsigned long long *d_bound, *d_win;
+  HIPC(c, dalloc(&d_boxes, NK * 4)); HIPC(c, dalloc(&d_scores, NK)); HIPC(c, dalloc(&d_stale, NK));
+  HIPC(c, dalloc(&d_tent, NK)); HIPC(c, dalloc(&d_begin, NK)); HIPC(c, dalloc(&d_si, NM));
+  HIPC(c, dalloc(&d_ss, NM)); HIPC(c, dalloc(&d_sb, NM * 4)); HIPC(c, dalloc(&d_bound, NM));
+  HIPC(c, dalloc(&d_win, NM)); HIPC(c, dalloc(&d_nsel, (size_t)n_img)); HIPC(c, dalloc(&d_done, (size_t)n_img));
+  if (k) {
+    HIPC(c, hipMemcpyAsync(d_boxes, boxes, NK * 4 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(d_scores, scores, NK * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  }
+  NmsArgs a{};
+  a.boxes = d_boxes; a.stale = d_stale; a.begin = d_begin; a.tent = d_tent;
+  a.sel_idx = d_si; a.sel_score = d_ss; a.sel_box = d_sb; a.bound_key = d_bound; a.win_key = d_win;
+  a.nsel = d_nsel; a.done = d_done; a.n_img = n_img; a.K = k; a.M = max_out;
+  nms_params(a, iou_thresh, score_thresh, soft_sigma);
+  launch_nms_init(a, d_scores, c->stream);
+  if (k > 0)
+    for (int e = 0; e < max_out; ++e) launch_nms_epoch(a, e, c->stream);
+  HIPC(c, hipStreamSynchronize(c->stream));
+  HIPC(c, hipGetLastError());
+  HIPC(c, hipMemcpy(valid, d_nsel, n_img * sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIPC(c, hipMemcpy(idx, d_si, NM * sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIPC(c, hipMemcpy(out_scores, d_ss, NM * sizeof(float), hipMemcpyDeviceToHost));
+  (void)pad;  // slots >= valid already hold index 0 / score 0.0 (the padded form); callers slice when pad == 0
+  void* frees[] = {d_boxes, d_scores, d_stale, d_tent, d_begin, d_si, d_ss, d_sb, d_bound, d_win, d_nsel, d_done};
+  for (void* p : frees) hipFree(p);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ profiling
+extern "C" int uda_profile_enable(uda_ctx_t* c, uint32_t kind_mask) {
+  if (!c) return 1;
+  c->prof_mask = kind_mask;
+  return 0;
+}
+
+extern "C" int uda_profile_read(uda_ctx_t* c, int32_t kind, double* total_ms, int64_t* launches, int32_t reset) {
+  if (!c || kind < 0 || kind >= 32) return 1;
+  hipSetDevice(c->device);
+  prof_collect(c, kind);
+  if (total_ms) *total_ms = c->prof[kind].total_ms;
+  if (launches) *launches = c->prof[kind].launches;
+  if (reset) { c->prof[kind].total_ms = 0; c->prof[kind].launches = 0; }
+  return 0;
+}

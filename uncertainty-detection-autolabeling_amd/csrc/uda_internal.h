@@ -1,0 +1,171 @@
+// Internal declarations shared by the host executor and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/uda_hip.h"
+
+namespace uda {
+
+// ---------------------------------------------------------------- kernel argument blocks
+struct StemArgs {
+  const float* in;    // [rows, H, W, 3]
+  float* out;         // [rows, Ho, Wo, Co]
+  const float* w;     // [27, Co]
+  const float* bn_scale;
+  const float* bn_shift;
+  int H, W, Ho, Wo, Co;
+  int pad_t, pad_l;
+  int rows;
+};
+
+struct PwArgs {
+  const float* in;       // [rows_in, HW, Cin]
+  float* out;            // [rows, HW, Cout]
+  const float* w;        // [Cin, Cout]
+  const float* bias;     // [Cout] or null
+  const float* bn_scale; // [Cout] or null
+  const float* bn_shift;
+  const float* se;       // [rows_in, Cin] gate on the input or null
+  const float* mask;     // [rows, Cout] dropout keep-scale or null
+  const float* res;      // [rows, HW, Cout] residual or null
+  int HW, Cin, Cout;
+  int in_div;            // rows_in = rows / in_div (input shared by the MC samples of an image)
+  int res_div;
+  int act;
+};
+
+struct DwArgs {
+  const float* in;       // [rows_in, H, W, C]
+  float* out;            // [rows, Ho, Wo, C]
+  const float* w;        // [k*k, C]
+  const float* bn_scale; // or null
+  const float* bn_shift;
+  const float* mask;     // [rows, C] or null
+  float* se_partial;     // [rows, n_tiles, C] or null
+  int H, W, Ho, Wo, C;
+  int pad_t, pad_l;
+  int in_div;
+  int act;
+  int tc;                // threads along channel quads
+  int pxb;               // x-groups per block
+  int n_cchunk;          // channel chunks (grid.z = rows * n_cchunk)
+  int n_tiles;           // Ho * gridDim.x
+};
+
+struct SeArgs {
+  const float* partial;  // [rows, n_tiles, C]
+  float* scale;          // [rows, C]
+  const float* w1;       // [C, mid]
+  const float* b1;       // [mid]
+  const float* w2;       // [mid, C]
+  const float* b2;       // [C]
+  int C, mid, n_tiles;
+  float inv_hw;
+};
+
+struct FuseArgs {
+  const float* in[UDA_MAX_FUSE_INPUTS];
+  float* out;
+  float wgt[UDA_MAX_FUSE_INPUTS];
+  int mode[UDA_MAX_FUSE_INPUTS];   // uda_resample
+  int Hi[UDA_MAX_FUSE_INPUTS], Wi[UDA_MAX_FUSE_INPUTS];
+  int in_div[UDA_MAX_FUSE_INPUTS];
+  float sy[UDA_MAX_FUSE_INPUTS], sx[UDA_MAX_FUSE_INPUTS];       // nearest: in/out
+  int pk[UDA_MAX_FUSE_INPUTS], ps[UDA_MAX_FUSE_INPUTS];         // pool size / stride
+  int ppt[UDA_MAX_FUSE_INPUTS], ppl[UDA_MAX_FUSE_INPUTS];       // pool pad before
+  int n_in;
+  int H, W, C;
+  int act;
+  int64_t total;  // rows*H*W*C/4
+};
+
+// ---------------------------------------------------------------- launchers (kernels_conv.hip)
+void launch_stem(const StemArgs& a, hipStream_t s);
+void launch_pw(const PwArgs& a, int rows, hipStream_t s);
+void launch_dw(DwArgs a, int rows, int k, int stride, hipStream_t s);
+void dw_geometry(int C, int Wo, int stride, int* tc, int* pxb, int* n_cchunk, int* grid_x, int* xb);
+void launch_se(const SeArgs& a, int rows, hipStream_t s);
+void launch_fuse(const FuseArgs& a, hipStream_t s);
+void launch_philox_masks(float* masks, const int64_t* site_off_dev, const int32_t* site_ch_dev,
+                         const float* site_rate_dev, int n_sites, int rows, int max_c4,
+                         uint64_t seed, hipStream_t s);
+
+// ---------------------------------------------------------------- post-process (kernels_post.hip)
+struct LevelTable {
+  int num_levels;
+  int hw[UDA_MAX_LEVELS];
+  int a_off[UDA_MAX_LEVELS + 1];   // anchor offset of each level; a_off[num_levels] = A_tot
+  const float* cls[UDA_MAX_LEVELS]; // [n*Tc, hw, A*C]
+  const float* box[UDA_MAX_LEVELS]; // [n*Tb, hw, boxch]
+};
+
+struct AggArgs {
+  LevelTable lv;
+  const float* anchors;  // [A_tot, 4]
+  int n_img, A_tot, A, C;
+  int Tc, Tb;            // samples carried by the class / box head outputs (1 = not stacked)
+  int loss_att;
+  int decode;            // uda_decode
+  float* boxes;          // [n, A_tot, 4]
+  float* scores;         // [n, A_tot]
+  int32_t* classes;      // [n, A_tot]
+  float* logits;         // [n, A_tot, C]  mean logits
+  float* u_cls;          // [n, A_tot, C] or null
+  float* u_al;           // [n, A_tot, 4] or null
+  float* u_ep;           // [n, A_tot, 4] or null
+};
+void launch_aggregate(const AggArgs& a, hipStream_t s);
+
+struct PreprocArgs {
+  const uint8_t* in;   // [n, h, w, 3]
+  float* out;          // [n, H, W, 3]
+  int n, h, w, H, W, sh, sw;
+  float mean[3], stdv[3];
+  float scale_y, scale_x;  // in/out ratios for the bilinear sampler
+};
+void launch_preprocess(const PreprocArgs& a, hipStream_t s);
+
+struct NmsArgs {
+  const float* boxes;    // [n, K, 4]
+  float* stale;          // [n, K]  working scores (dead = -inf)
+  int32_t* begin;        // [n, K]
+  float* tent;           // [n, K]
+  int32_t* sel_idx;      // [n, M]
+  float* sel_score;      // [n, M]
+  float* sel_box;        // [n, M, 4]
+  unsigned long long* bound_key;  // [n, M]
+  unsigned long long* win_key;    // [n, M]
+  int32_t* nsel;         // [n]
+  int32_t* done;         // [n]
+  int n_img, K, M;
+  float iou_thr, score_thr, scale;  // scale = soft ? -0.5/sigma : 0
+  int soft;
+};
+void launch_nms_init(const NmsArgs& a, const float* scores, hipStream_t s);
+void launch_nms_epoch(const NmsArgs& a, int epoch, hipStream_t s);
+void launch_nms_finish(const NmsArgs& a, int pad, hipStream_t s);
+
+struct GatherArgs {
+  const int32_t* sel_idx;   // [n, M]
+  const float* sel_score;   // [n, M]
+  const int32_t* nsel;      // [n]
+  const float* boxes;       // [n, K, 4]
+  const int32_t* classes;   // [n, K]
+  const float* logits;      // [n, K, C]
+  const float* u_cls;       // or null
+  const float* u_al;
+  const float* u_ep;
+  const float* scales;      // [n] image scales or null
+  float* out_boxes;         // [n, M, box_cols]
+  float* out_scores;        // [n, M]
+  float* out_classes;       // [n, M, cls_cols]
+  int32_t* out_valid;       // [n]
+  float* out_logits;        // [n, M, C] or null
+  int n_img, K, M, C, box_cols, cls_cols;
+  float clip_h, clip_w;
+  int clip;
+};
+void launch_gather(const GatherArgs& a, hipStream_t s);
+
+}  // namespace uda

@@ -1,0 +1,329 @@
+"""ServingDriver-shaped boundary over the HIP C-ABI library.
+
+Drop-in for the members of the reference's `infer_lib.ServingDriver`
+(src/infer_lib.py:118-296, 299-350, 416-491) that its callers use
+(inspector.py:161-169; validate_model.py:155; infer_model.py:581,787;
+calibrate_model.py:89; utils_extra.py:130-133):
+
+    driver = ServingDriver.create(model_dir, debug, saved_model_dir, model_name,
+                                  batch_size, only_network, model_params)
+    boxes, scores, classes, valid_len[, logits] = driver.serve(uint8_images)
+    cls_outputs, box_outputs = driver.predict(float_images)      # only_network=True
+    driver.benchmark(images, bm_runs=10)
+
+Output layout = `postprocess_global` (src/postprocess.py:610-621):
+boxes [N,100,4(+4 aleatoric)(+4 epistemic)], scores [N,100], classes [N,100] or
+[N,100,1+C], valid_len [N] int32, logits [N,100,C] when `enable_softmax`.
+Arrays are fresh numpy arrays owned by the caller; errors are Python exceptions.
+
+Weights: there is no TF checkpoint reader here.  `model_dir` / `saved_model_dir`
+name an `.npz` weight set with the reference's variable names (weights.py); "_"
+(the reference's "running test: do not load any ckpt", utils_keras.py:142-144)
+or an empty path draws a random-init set.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+
+from . import capi, hparams_config, plan as plan_mod, weights as weights_mod
+from .dataset_data import get_label_map
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class ServingDriver:
+    """One GPU, one handle, synchronous calls (same threading contract as the reference)."""
+
+    @classmethod
+    def create(cls, model_dir, debug, saved_model_dir, *args, **kwargs):
+        path = saved_model_dir or model_dir
+        return cls(path, debug, *args, **kwargs)
+
+    def __init__(self, weights_path, debug=False, model_name="efficientdet-d0", batch_size=1,
+                 only_network=False, model_params=None, device=0, chunk_images=None,
+                 weights=None, post_mode="global"):
+        self.model_name = model_name
+        self.batch_size = int(batch_size or 1)
+        self.only_network = bool(only_network)
+        self.debug = debug
+        self.params = hparams_config.get_detection_config(model_name).as_dict()
+        if model_params:
+            cfg = hparams_config.Config(self.params)
+            cfg.update(dict(model_params))
+            self.params = cfg.as_dict()
+        self.params.update(dict(is_training_bn=False))
+        self.label_map = get_label_map(self.params.get("label_map", None))
+        if self.params["nms_configs"].get("pyfunc", False):
+            raise ValueError("nms_configs.pyfunc=True selects the numpy NMS path (nms_np), "
+                             "which is dead in the reference (postprocess.py:806) and not served here")
+
+        if weights is None:
+            if weights_path and str(weights_path).endswith(".npz"):
+                weights = weights_mod.load_weights(weights_path)
+            else:  # "_" / "" : test mode, random init
+                weights = weights_mod.init_weights(self.params, seed=int(self.params.get("uda_seed", 0)))
+        self.weights = weights
+        if chunk_images is None:
+            chunk_images = min(self.batch_size, int(self.params.get("uda_chunk_images", 2)))
+        self.plan = plan_mod.Plan(self.params, weights, chunk_images=chunk_images, max_images=self.batch_size)
+        self._post_mode = capi.POST_PER_CLASS if post_mode == "per_class" else capi.POST_GLOBAL
+        self._lib = capi.load()
+        m, bufs, ops, sites, blob, anchors = self.plan.to_c(self._post_mode)
+        self._keep = (m, bufs, ops, sites, blob, anchors)
+        handle = C.c_void_p()
+        rc = self._lib.uda_create(C.byref(m), bufs, len(bufs), ops, len(ops), sites, _ptr(blob), blob.size,
+                                  _ptr(anchors), int(device), C.byref(handle))
+        if rc != 0:
+            raise capi.UdaError("uda_create failed: %s" % self._lib.uda_last_error(None).decode())
+        self._h = handle
+        self.image_size = hparams_config.parse_image_size(self.params["image_size"])
+        self.T = self.plan.T
+        self.M = int(self.params["nms_configs"]["max_output_size"])
+        self.num_classes = int(self.params["num_classes"])
+        self._seed_counter = int(self.params.get("uda_dropout_seed", 0))
+        self._fixed_seed = None
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.uda_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        capi.check(self._lib, self._h, rc, what)
+
+    # ------------------------------------------------------------------ MC dropout control
+    def set_dropout_seed(self, seed):
+        """Fix the Philox seed (every call then draws the same masks); None = advance per call."""
+        self._fixed_seed = None if seed is None else int(seed)
+
+    def set_dropout_masks(self, masks):
+        """Inject masks: {site name: float32 [N, T, C]} (see plan.Plan.sites for the names)."""
+        parts = []
+        for name, ch, _ in self.plan.sites:
+            a = np.ascontiguousarray(masks[name], dtype=np.float32)
+            parts.append(a.reshape(-1, ch).reshape(-1))
+        flat = np.concatenate(parts) if parts else np.zeros(0, np.float32)
+        self._ck(self._lib.uda_set_dropout_masks(self._h, _ptr(flat), flat.size), "uda_set_dropout_masks")
+        self._injected = True
+
+    def _next_seed(self):
+        if getattr(self, "_injected", False):
+            return
+        if self._fixed_seed is not None:
+            seed = self._fixed_seed
+        else:
+            seed = self._seed_counter
+            self._seed_counter += 1
+        self._ck(self._lib.uda_set_dropout_seed(self._h, C.c_uint64(seed)), "uda_set_dropout_seed")
+
+    # ------------------------------------------------------------------ serve / predict
+    def _as_u8_batch(self, image_arrays):
+        if isinstance(image_arrays, (list, tuple)):
+            image_arrays = np.stack([np.asarray(a) for a in image_arrays])
+        a = np.asarray(image_arrays)
+        if a.ndim == 3:
+            a = a[None]
+        if a.ndim != 4 or a.shape[-1] != 3:
+            raise ValueError("images must be [N, h, w, 3], got %s" % (a.shape,))
+        if a.dtype != np.uint8:
+            raise ValueError("serve() takes uint8 images, got %s" % a.dtype)
+        if a.shape[0] > self.batch_size:
+            raise ValueError("batch of %d images exceeds batch_size=%d" % (a.shape[0], self.batch_size))
+        return np.ascontiguousarray(a)
+
+    def _collect(self, n):
+        bc, cc = C.c_int32(), C.c_int32()
+        self._ck(self._lib.uda_detection_cols(self._h, -1, C.byref(bc), C.byref(cc)), "uda_detection_cols")
+        boxes = np.empty((n, self.M, bc.value), np.float32)
+        scores = np.empty((n, self.M), np.float32)
+        classes = np.empty((n, self.M, cc.value), np.float32)
+        valid = np.empty((n,), np.int32)
+        logits = np.empty((n, self.M, self.num_classes), np.float32) if self.params["enable_softmax"] else None
+        self._ck(self._lib.uda_get_detections(self._h, _ptr(boxes), _ptr(scores), _ptr(classes), _ptr(valid),
+                                              _ptr(logits)), "uda_get_detections")
+        if cc.value == 1:
+            classes = classes[..., 0]
+        out = [boxes, scores, classes, valid]
+        if logits is not None:
+            out.append(logits)
+        return tuple(out)
+
+    def serve(self, image_arrays):
+        """uint8 [N,h,w,3] -> (boxes, scores, classes, valid_len[, logits])."""
+        a = self._as_u8_batch(image_arrays)
+        n, h, w = a.shape[:3]
+        self._next_seed()
+        self._ck(self._lib.uda_set_images_u8(self._h, _ptr(a), n, h, w), "uda_set_images_u8")
+        self._ck(self._lib.uda_run(self._h, -1, 1), "uda_run")
+        return self._collect(n)
+
+    def predict(self, image_arrays):
+        """only_network: float32 [N,H,W,3] -> (cls_outputs[levels], box_outputs[levels]) with the
+        reference's shapes ([N,h,w,ch], or [T,N,h,w,ch] for a head that is MC-stacked);
+        otherwise identical to serve()."""
+        if not self.only_network:
+            return self.serve(image_arrays)
+        a = np.ascontiguousarray(image_arrays, dtype=np.float32)
+        H, W = self.image_size
+        if a.ndim != 4 or a.shape[1:] != (H, W, 3):
+            raise ValueError("predict() takes float images [N,%d,%d,3], got %s" % (H, W, a.shape))
+        if a.shape[0] > self.batch_size:
+            raise ValueError("batch of %d images exceeds batch_size=%d" % (a.shape[0], self.batch_size))
+        self._next_seed()
+        self._ck(self._lib.uda_predict(self._h, _ptr(a), a.shape[0]), "uda_predict")
+        return self.head_outputs(a.shape[0])
+
+    def head_outputs(self, n):
+        """Raw head outputs of the last run in the reference's layout."""
+        p = self.plan
+        A = len(self.params["aspect_ratios"]) * self.params["num_scales"]
+        cls_ch = A * self.num_classes
+        box_ch = A * (8 if self.params["loss_attenuation"] else 4)
+        cls_out, box_out = [], []
+        for lvl, (h, w) in enumerate(p.level_hw):
+            tc = self.T if p.cls_stacked_dev else 1
+            tb = self.T if p.box_stacked_dev else 1
+            c = np.empty((tc, n, h, w, cls_ch), np.float32)
+            b = np.empty((tb, n, h, w, box_ch), np.float32)
+            self._ck(self._lib.uda_get_head_outputs(self._h, lvl, _ptr(c), _ptr(b)), "uda_get_head_outputs")
+            # the reference stacks a head iff its (or the global) rate is non-zero
+            cls_out.append(c if p.cls_stacked else c[0])
+            box_out.append(b if p.box_stacked else b[0])
+        return cls_out, box_out
+
+    def postprocess(self, cls_outputs, box_outputs, image_scales=None):
+        """`ServingDriver._postprocess` = postprocess_global on given head outputs (infer_lib.py:263-267)."""
+        p = self.plan
+        n = cls_outputs[0].shape[-4]
+        for lvl in range(len(p.level_hw)):
+            c = np.ascontiguousarray(cls_outputs[lvl], dtype=np.float32)
+            b = np.ascontiguousarray(box_outputs[lvl], dtype=np.float32)
+            if c.ndim == 4:
+                c = c[None]
+            if b.ndim == 4:
+                b = b[None]
+            self._ck(self._lib.uda_set_head_outputs(self._h, lvl, n, _ptr(c), _ptr(b)), "uda_set_head_outputs")
+        s = None if image_scales is None else np.ascontiguousarray(image_scales, dtype=np.float32)
+        self._ck(self._lib.uda_postprocess_heads(self._h, n, _ptr(s), -1), "uda_postprocess_heads")
+        return self._collect(n)
+
+    # ------------------------------------------------------------------ debug / parity accessors
+    def preprocessed(self):
+        n = self._n_last()
+        H, W = self.image_size
+        imgs = np.empty((n, H, W, 3), np.float32)
+        scales = np.empty((n,), np.float32)
+        self._ck(self._lib.uda_get_preprocessed(self._h, _ptr(imgs), _ptr(scales)), "uda_get_preprocessed")
+        return imgs, scales
+
+    def _n_last(self):
+        return getattr(self, "_last_n", self.batch_size)
+
+    def read_buffer(self, name, n_chunk):
+        """Activation `name` (plan.buffer_names) of the last chunk: [rows, H, W, C]."""
+        bi = self.plan.buffer_names[name]
+        b = self.plan.bufs[bi]
+        rows = n_chunk * (self.T if b.per_sample else 1)
+        out = np.empty((rows, b.H, b.W, b.C), np.float32)
+        self._ck(self._lib.uda_read_buffer(self._h, bi, _ptr(out), out.size), "uda_read_buffer")
+        return out
+
+    def candidates(self, n):
+        K = self._lib.uda_num_candidates(self._h)
+        boxes = np.empty((n, K, 4), np.float32)
+        scores = np.empty((n, K), np.float32)
+        classes = np.empty((n, K), np.int32)
+        ucls = np.zeros((n, K, self.num_classes), np.float32)
+        ual = np.zeros((n, K, 4), np.float32)
+        uep = np.zeros((n, K, 4), np.float32)
+        self._ck(self._lib.uda_get_candidates(self._h, _ptr(boxes), _ptr(scores), _ptr(classes), _ptr(ucls),
+                                              _ptr(ual), _ptr(uep)), "uda_get_candidates")
+        return dict(boxes=boxes, scores=scores, classes=classes, u_cls=ucls, u_al=ual, u_ep=uep)
+
+    def dropout_masks(self, n):
+        """{site: [N, T, C]} masks used by the last run."""
+        total = sum(ch for _, ch, _ in self.plan.sites) * n * self.T
+        flat = np.empty(total, np.float32)
+        self._ck(self._lib.uda_get_dropout_masks(self._h, _ptr(flat), flat.size), "uda_get_dropout_masks")
+        out, off = {}, 0
+        for name, ch, _ in self.plan.sites:
+            sz = n * self.T * ch
+            out[name] = flat[off:off + sz].reshape(n, self.T, ch)
+            off += sz
+        return out
+
+    def nms(self, boxes, scores, max_out=100, iou_thresh=0.5, score_thresh=0.001, soft_sigma=0.25, pad=True):
+        """NonMaxSuppressionV5 kernel on host arrays: boxes [n,k,4], scores [n,k]."""
+        boxes = np.ascontiguousarray(boxes, dtype=np.float32)
+        scores = np.ascontiguousarray(scores, dtype=np.float32)
+        n, k = scores.shape
+        idx = np.zeros((n, max_out), np.int32)
+        sc = np.zeros((n, max_out), np.float32)
+        valid = np.zeros((n,), np.int32)
+        self._ck(self._lib.uda_nms(self._h, _ptr(boxes), _ptr(scores), n, k, max_out, iou_thresh, score_thresh,
+                                   soft_sigma, int(pad), _ptr(idx), _ptr(sc), _ptr(valid)), "uda_nms")
+        return idx, sc, valid
+
+    # ------------------------------------------------------------------ resident-input fast path (bench)
+    def stage_images(self, image_arrays):
+        """Upload uint8 images once (the PCIe leg); `run_resident` then re-runs the path on them."""
+        a = self._as_u8_batch(image_arrays)
+        n, h, w = a.shape[:3]
+        self._ck(self._lib.uda_set_images_u8(self._h, _ptr(a), n, h, w), "uda_set_images_u8")
+        self._ck(self._lib.uda_synchronize(self._h), "uda_synchronize")
+        self._last_n = n
+        return n
+
+    def run_resident(self, sync=True):
+        self._next_seed()
+        self._ck(self._lib.uda_run(self._h, -1, 1), "uda_run")
+        if sync:
+            self._ck(self._lib.uda_synchronize(self._h), "uda_synchronize")
+
+    def synchronize(self):
+        self._ck(self._lib.uda_synchronize(self._h), "uda_synchronize")
+
+    def profile_enable(self, kinds):
+        mask = 0
+        for k in kinds:
+            mask |= 1 << k
+        self._ck(self._lib.uda_profile_enable(self._h, mask), "uda_profile_enable")
+
+    def profile_read(self, kind, reset=True):
+        ms, cnt = C.c_double(), C.c_int64()
+        self._ck(self._lib.uda_profile_read(self._h, kind, C.byref(ms), C.byref(cnt), int(reset)), "uda_profile_read")
+        return ms.value, cnt.value
+
+    # ------------------------------------------------------------------ benchmark (infer_lib.py:206-230)
+    def benchmark(self, image_arrays, bm_runs=10, trace_filename=None):
+        """3 warm-up calls, `bm_runs` timed calls of predict(); prints per-batch latency and FPS."""
+        for _ in range(3):
+            self.predict(image_arrays)
+        start = time.perf_counter()
+        for _ in range(bm_runs):
+            self.predict(image_arrays)
+        end = time.perf_counter()
+        inference_time = (end - start) / bm_runs
+        print("Per batch inference time: ", inference_time)
+        print("FPS: ", (self.batch_size or 1) / inference_time)
+        if trace_filename:
+            print("trace_filename is ignored: profile with rocprofv3 (see DESIGN.md)")
+        return inference_time
+
+    def visualize(self, image, boxes, classes, scores, uncertainty=None, **kwargs):
+        raise NotImplementedError("host-side drawing (visualize/vis_utils.py) is outside the hot path")
+
+
+# the reference's concrete driver names resolve to the same implementation
+KerasDriver = ServingDriver
+SavedModelDriver = ServingDriver

@@ -1,0 +1,454 @@
+"""Lower the detector (config + reference-named weights) to the C-ABI op list.
+
+This is the Python host orchestration that the reference keeps in
+`EfficientDetNet.__init__/call` (efficientdet_keras.py:850-1070) and
+`efficientnet_model.Model._build/call` (backbone/efficientnet_model.py:731-909):
+it decides *which* ops run on *which* tensors; the C-ABI library executes them.
+
+What the lowering adds over the reference's graph:
+  * the MC sample axis is explicit.  A tensor is "per sample" (rows = images x T) only
+    downstream of an active dropout site; everything upstream is computed once per image
+    and shared by the T samples (stem for full MC; backbone + BiFPN for head-only MC,
+    where SpatialDropout2D(0.0) in the backbone is the identity).  The reference re-runs
+    the whole network T times (efficientdet_keras.py:999-1024).
+  * BN is folded to one scale/shift pair per channel; BiFPN fusion weights are
+    pre-normalised (relu(w_i)/(sum+1e-4), efficientdet_keras.py:101-108).
+  * activation memory is planned by liveness into one arena per chunk of images.
+"""
+import numpy as np
+
+from . import arch, capi
+from .hparams_config import get_feat_sizes, parse_image_size
+
+ALIGN = 256  # floats
+
+
+def dw_tiles_x(C, Wo, stride):
+    """gridDim.x of the depthwise kernel (mirror of dw_geometry in csrc/kernels_conv.hip)."""
+    C4 = C // 4
+    ncc = (C4 + 255) // 256
+    t = (C4 + ncc - 1) // ncc
+    p = max(1, 256 // t)
+    x = 4 if stride == 1 else 2
+    p = min(p, (Wo + x - 1) // x)
+    return (Wo + p * x - 1) // (p * x)
+
+
+def same_out(n, s):
+    return -(-n // s)
+
+
+class _Buf:
+    __slots__ = ("H", "W", "C", "per_sample", "kind", "level", "offset", "first", "last", "name")
+
+    def __init__(self, H, W, C, per_sample, kind=0, level=0, name=""):
+        self.H, self.W, self.C, self.per_sample = int(H), int(W), int(C), bool(per_sample)
+        self.kind, self.level, self.offset = kind, level, 0
+        self.first, self.last, self.name = None, None, name
+
+
+class Plan:
+    """bufs / ops / drop sites / weight blob / anchors ready for `uda_create`."""
+
+    def __init__(self, config, weights, chunk_images=1, max_images=1):
+        self.cfg = dict(config)
+        self.w = weights
+        self.T = arch.mc_flags(self.cfg)[2]
+        self.cls_stacked, self.box_stacked, _ = arch.mc_flags(self.cfg)
+        self.chunk_images = int(chunk_images)
+        self.max_images = int(max_images)
+        self.bufs, self.ops, self.blob, self.blob_len = [], [], [], 0
+        self.sites = []          # (name, channels, rate)
+        self.site_index = {}
+        self.buffer_names = {}
+        self._build_sites()
+        self._lower()
+        self._plan_memory()
+
+    # ------------------------------------------------------------------ weights
+    def _pack(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)
+        off = self.blob_len
+        pad = (-arr.size) % 4
+        self.blob.append(arr)
+        if pad:
+            self.blob.append(np.zeros(pad, np.float32))
+        self.blob_len += arr.size + pad
+        return off
+
+    def _bn(self, prefix):
+        g, b = self.w[prefix + "/gamma"], self.w[prefix + "/beta"]
+        m, v = self.w[prefix + "/moving_mean"], self.w[prefix + "/moving_variance"]
+        scale = (g / np.sqrt(v + np.float32(arch.BN_EPS))).astype(np.float32)
+        shift = (b - m * scale).astype(np.float32)
+        return self._pack(scale), self._pack(shift)
+
+    # ------------------------------------------------------------------ dropout sites
+    def _build_sites(self):
+        cfg = self.cfg
+        if not cfg["mc_dropout"]:
+            return
+        r_bb, r_cls, r_box = arch.dropout_rates(cfg)
+        for i, b in enumerate(arch.backbone_blocks(cfg["backbone_name"])):
+            mid = b["cin"] * b["expand"]
+            if b["expand"] != 1:
+                self.sites.append(("blocks_%d/expand" % i, mid, r_bb))
+            self.sites.append(("blocks_%d/dw" % i, mid, r_bb))
+        F = cfg["fpn_num_filters"]
+        for tag, r in (("class", r_cls), ("box", r_box)):
+            for i in range(cfg["box_class_repeats"]):
+                for lvl in range(cfg["min_level"], cfg["max_level"] + 1):
+                    self.sites.append(("%s-%d-%d" % (tag, i, lvl), F, r))
+        self.site_index = {name: i for i, (name, _, _) in enumerate(self.sites)}
+
+    def _site(self, name):
+        """site index if the site is active (rate > 0), else -1."""
+        if name not in self.site_index:
+            return -1
+        i = self.site_index[name]
+        return i if self.sites[i][2] > 0 else -1
+
+    # ------------------------------------------------------------------ graph building
+    def _buf(self, H, W, C, per_sample, kind=0, level=0, name=""):
+        self.bufs.append(_Buf(H, W, C, per_sample and self.T > 1, kind, level, name))
+        if name:
+            self.buffer_names[name] = len(self.bufs) - 1
+        return len(self.bufs) - 1
+
+    def _op(self, kind, ins, out, **kw):
+        o = dict(kind=kind, ins=list(ins), out=out, se_scale=-1, se_partial=-1, residual=-1, k=0,
+                 stride=1, act=capi.ACT_NONE, w_off=-1, bias_off=-1, bn_scale_off=-1, bn_shift_off=-1,
+                 se_w1_off=-1, se_b1_off=-1, se_w2_off=-1, se_b2_off=-1, se_mid=0, drop_site=-1,
+                 resample=[0, 0, 0], fuse_w=[0.0, 0.0, 0.0])
+        o.update(kw)
+        self.ops.append(o)
+        return out
+
+    def _pw(self, x, cout, kernel, name, bias=None, bn=None, act=capi.ACT_NONE, site=-1, se=-1,
+            residual=-1, out_kind=0, level=0):
+        xb = self.bufs[x]
+        ps = xb.per_sample or site >= 0
+        out = self._buf(xb.H, xb.W, cout, ps, out_kind, level, name)
+        kw = dict(w_off=self._pack(self.w[kernel]), act=act, drop_site=site, se_scale=se, residual=residual)
+        if bias is not None:
+            kw["bias_off"] = self._pack(self.w[bias])
+        if bn is not None:
+            kw["bn_scale_off"], kw["bn_shift_off"] = self._bn(bn)
+        return self._op(capi.OP_PW, [x], out, **kw)
+
+    def _dw(self, x, k, stride, kernel, name, bn=None, act=capi.ACT_NONE, site=-1, with_se=False):
+        xb = self.bufs[x]
+        Ho, Wo = same_out(xb.H, stride), same_out(xb.W, stride)
+        ps = xb.per_sample or site >= 0
+        out = self._buf(Ho, Wo, xb.C, ps, name=name)
+        kw = dict(k=k, stride=stride, w_off=self._pack(self.w[kernel]), act=act, drop_site=site)
+        if bn is not None:
+            kw["bn_scale_off"], kw["bn_shift_off"] = self._bn(bn)
+        if with_se:
+            kw["se_partial"] = self._buf(Ho * dw_tiles_x(xb.C, Wo, stride), 1, xb.C, ps, name=name + "/se_partial")
+        self._op(capi.OP_DW, [x], out, **kw)
+        return out, kw.get("se_partial", -1)
+
+    def _resample(self, x, th, tw, prefix, name):
+        """ResampleFeatureMap.call: optional 1x1+BN to F channels, then (mode for the consumer)."""
+        F = self.cfg["fpn_num_filters"]
+        xb = self.bufs[x]
+        if xb.C != F:
+            x = self._pw(x, F, prefix + "/conv2d/kernel", name + "/conv", bias=prefix + "/conv2d/bias",
+                         bn=prefix + "/bn")
+            xb = self.bufs[x]
+        if xb.H > th and xb.W > tw:
+            return x, capi.RS_MAXPOOL
+        if xb.H <= th and xb.W <= tw:
+            return x, (capi.RS_NEAREST_UP if (xb.H < th or xb.W < tw) else capi.RS_NONE)
+        raise ValueError("Incompatible Resampling : feat shape {}x{} target_shape: {}x{}".format(
+            xb.H, xb.W, th, tw))
+
+    def _lower(self):
+        cfg, w = self.cfg, self.w
+        bb = cfg["backbone_name"]
+        H, W = parse_image_size(cfg["image_size"])
+        blocks = arch.backbone_blocks(bb)
+        img = self._buf(H, W, 3, False, kind=1, name="image")
+        # ---- backbone
+        sc, sh = self._bn(bb + "/stem/tpu_batch_normalization")
+        x = self._op(capi.OP_STEM, [img],
+                     self._buf(same_out(H, 2), same_out(W, 2), arch.stem_filters(bb), False, name="stem"),
+                     w_off=self._pack(w[bb + "/stem/conv2d/kernel"]), bn_scale_off=sc, bn_shift_off=sh,
+                     act=capi.ACT_SWISH, k=3, stride=2)
+        reductions = []
+        red_ids = set(arch.reduction_block_ids(blocks))
+        for i, b in enumerate(blocks):
+            p = "%s/blocks_%d/" % (bb, i)
+            bn_names = [p + "tpu_batch_normalization" + ("" if j == 0 else "_%d" % j) for j in range(3)]
+            inp, nb = x, 0
+            if b["expand"] != 1:
+                x = self._pw(x, b["cin"] * b["expand"], p + "conv2d/kernel", "blocks_%d/expand" % i,
+                             bn=bn_names[nb], act=capi.ACT_SWISH, site=self._site("blocks_%d/expand" % i))
+                nb += 1
+                proj = p + "conv2d_1/kernel"
+            else:
+                proj = p + "conv2d/kernel"
+            x, part = self._dw(x, b["kernel"], b["stride"], p + "depthwise_conv2d/depthwise_kernel",
+                               "blocks_%d/dw" % i, bn=bn_names[nb], act=capi.ACT_SWISH,
+                               site=self._site("blocks_%d/dw" % i), with_se=bool(b["se"]))
+            nb += 1
+            gate = -1
+            if b["se"]:
+                xb = self.bufs[x]
+                gate = self._op(capi.OP_SE, [part, x], self._buf(1, 1, xb.C, xb.per_sample, name="blocks_%d/se" % i),
+                                stride=b["stride"], se_mid=b["se"],
+                                se_w1_off=self._pack(w[p + "se/conv2d/kernel"]),
+                                se_b1_off=self._pack(w[p + "se/conv2d/bias"]),
+                                se_w2_off=self._pack(w[p + "se/conv2d_1/kernel"]),
+                                se_b2_off=self._pack(w[p + "se/conv2d_1/bias"]))
+            x = self._pw(x, b["cout"], proj, "blocks_%d/out" % i, bn=bn_names[nb], se=gate,
+                         residual=inp if b["skip"] else -1)
+            if i in red_ids:
+                reductions.append(x)
+        lo, hi = cfg["min_level"], cfg["max_level"]
+        feats = reductions[lo - 1:]
+        # ---- extra levels P6, P7 (efficientdet_keras.py:886-899, 1004-1005)
+        F = cfg["fpn_num_filters"]
+        for lvl in range(len(feats) + lo, hi + 1):
+            src = self.bufs[feats[-1]]
+            th, tw = (src.H + 1) // 2, (src.W + 1) // 2
+            xr, mode = self._resample(feats[-1], th, tw, "resample_p%d" % lvl, "resample_p%d" % lvl)
+            assert mode == capi.RS_MAXPOOL
+            out = self._buf(th, tw, F, self.bufs[xr].per_sample, name="p%d_in" % lvl)
+            feats.append(self._op(capi.OP_POOL, [xr], out, resample=[capi.RS_MAXPOOL, 0, 0], fuse_w=[1.0, 0, 0]))
+        # ---- BiFPN
+        nodes = arch.bifpn_nodes(lo, hi)
+        method = cfg.get("fpn_weight_method") or "fastattn"
+        for rep in range(cfg["fpn_cell_repeats"]):
+            cell = list(feats)
+            for n, node in enumerate(nodes):
+                p = "fpn_cells/cell_%d/fnode%d/" % (rep, n)
+                nf = len(cell)
+                tgt = self.bufs[cell[node["feat_level"] - lo]]
+                ins, modes = [], []
+                for i, off in enumerate(node["inputs_offsets"]):
+                    xi, mode = self._resample(cell[off], tgt.H, tgt.W, p + "resample_%d_%d_%d" % (i, off, nf),
+                                              "cell%d/fnode%d/in%d" % (rep, n, i))
+                    ins.append(xi)
+                    modes.append(mode)
+                if method == "fastattn":
+                    ew = [np.maximum(np.float32(np.asarray(w[p + "WSM" + ("" if i == 0 else "_%d" % i)]).reshape(())), np.float32(0))
+                          for i in range(len(ins))]
+                    tot = np.float32(0)
+                    for e in ew:
+                        tot = np.float32(tot + e)
+                    fw = [float(np.float32(e / np.float32(tot + np.float32(0.0001)))) for e in ew]
+                elif method == "sum":
+                    fw = [1.0] * len(ins)
+                else:
+                    raise ValueError("unknown weight_method %s" % method)
+                ps = any(self.bufs[i].per_sample for i in ins)
+                fused = self._op(capi.OP_FUSE, ins, self._buf(tgt.H, tgt.W, F, ps, name="cell%d/fnode%d/fused" % (rep, n)),
+                                 act=capi.ACT_SWISH, resample=(modes + [0, 0, 0])[:3], fuse_w=(fw + [0, 0, 0])[:3])
+                op = p + "op_after_combine%d" % nf
+                d, _ = self._dw(fused, 3, 1, op + "/conv/depthwise_kernel", "cell%d/fnode%d/dw" % (rep, n))
+                cell.append(self._pw(d, F, op + "/conv/pointwise_kernel", "cell%d/fnode%d/out" % (rep, n),
+                                     bias=op + "/conv/bias", bn=op + "/bn"))
+            feats = []
+            for lvl in range(lo, hi + 1):
+                for i, node in enumerate(reversed(nodes)):
+                    if node["feat_level"] == lvl:
+                        feats.append(cell[-1 - i])
+                        break
+        self.fpn_out = list(feats)
+        # ---- heads
+        self.level_hw = [(self.bufs[f].H, self.bufs[f].W) for f in feats]
+        A = len(cfg["aspect_ratios"]) * cfg["num_scales"]
+        cls_ch = A * cfg["num_classes"]
+        box_ch = A * (8 if cfg["loss_attenuation"] else 4)
+        self.head_out = {"class": [], "box": []}
+        for net, tag, outc, kind in (("class_net", "class", cls_ch, 2), ("box_net", "box", box_ch, 3)):
+            for li, f in enumerate(feats):
+                x = f
+                for i in range(cfg["box_class_repeats"]):
+                    pre = "%s/%s-%d" % (net, tag, i)
+                    d, _ = self._dw(x, 3, 1, pre + "/depthwise_kernel", "%s-%d-%d/dw" % (tag, i, lo + li))
+                    x = self._pw(d, F, pre + "/pointwise_kernel", "%s-%d-%d" % (tag, i, lo + li),
+                                 bias=pre + "/bias", bn="%s/%s-%d-bn-%d" % (net, tag, i, lo + li),
+                                 act=capi.ACT_SWISH, site=self._site("%s-%d-%d" % (tag, i, lo + li)))
+                pre = "%s/%s-predict" % (net, tag)
+                d, _ = self._dw(x, 3, 1, pre + "/depthwise_kernel", "%s-predict-%d/dw" % (tag, lo + li))
+                out = self._pw(d, outc, pre + "/pointwise_kernel", "%s-predict-%d" % (tag, lo + li),
+                               bias=pre + "/bias", out_kind=kind, level=li)
+                self.head_out[tag].append(out)
+        # the head buffers must carry the sample axis exactly when the reference stacks them
+        for tag, stacked in (("class", self.cls_stacked), ("box", self.box_stacked)):
+            for o in self.head_out[tag]:
+                want = bool(stacked and self.T > 1)
+                if self.bufs[o].per_sample != want:
+                    # stacked in the reference but every sample identical here (all rates zero):
+                    # keep one copy; the driver broadcasts when it returns `predict` outputs.
+                    assert not self.bufs[o].per_sample, "unexpected sample axis on head %s" % tag
+        self.cls_stacked_dev = bool(self.bufs[self.head_out["class"][0]].per_sample)
+        self.box_stacked_dev = bool(self.bufs[self.head_out["box"][0]].per_sample)
+
+    # ------------------------------------------------------------------ memory planning
+    def _rows(self, b):
+        return self.chunk_images * (self.T if b.per_sample else 1)
+
+    def _plan_memory(self):
+        for oi, o in enumerate(self.ops):
+            touched = list(o["ins"]) + [o["out"]] + [o[k] for k in ("se_scale", "se_partial", "residual") if o[k] >= 0]
+            for b in touched:
+                buf = self.bufs[b]
+                if buf.first is None:
+                    buf.first = oi
+                buf.last = oi
+        for f in self.fpn_out:
+            self.bufs[f].last = len(self.ops)
+        free, top = [], 0  # free: list of (offset, size)
+
+        def alloc(size):
+            nonlocal top
+            for i, (off, sz) in enumerate(free):
+                if sz >= size:
+                    if sz == size:
+                        free.pop(i)
+                    else:
+                        free[i] = (off + size, sz - size)
+                    return off
+            off = top
+            top += size
+            return off
+
+        def release(off, size):
+            free.append((off, size))
+            free.sort()
+            merged = []
+            for o_, s_ in free:
+                if merged and merged[-1][0] + merged[-1][1] == o_:
+                    merged[-1] = (merged[-1][0], merged[-1][1] + s_)
+                else:
+                    merged.append((o_, s_))
+            free[:] = merged
+
+        sizes = {}
+        for oi in range(len(self.ops)):
+            for bi, b in enumerate(self.bufs):
+                if b.kind == 0 and b.first == oi:
+                    size = -(-(self._rows(b) * b.H * b.W * b.C) // ALIGN) * ALIGN
+                    sizes[bi] = size
+                    b.offset = alloc(size)
+            for bi, b in enumerate(self.bufs):
+                if b.kind == 0 and b.last == oi and bi in sizes:
+                    release(b.offset, sizes[bi])
+        self.arena_floats = int(top)
+
+    # ------------------------------------------------------------------ C structures
+    def anchors(self):
+        """[A_tot, 4] float32 (ymin, xmin, ymax, xmax); order level, y, x, (octave, aspect)
+        (reference anchors.py:138-218)."""
+        cfg = self.cfg
+        lo, hi = cfg["min_level"], cfg["max_level"]
+        H, W = parse_image_size(cfg["image_size"])
+        fs = get_feat_sizes(cfg["image_size"], hi)
+        scales = cfg["anchor_scale"]
+        if not isinstance(scales, (list, tuple)):
+            scales = [scales] * (hi - lo + 1)
+        levels = []
+        for lvl in range(lo, hi + 1):
+            sy, sx = H / float(fs[lvl][0]), W / float(fs[lvl][1])
+            ys = np.arange(sy / 2, H, sy)
+            xs = np.arange(sx / 2, W, sx)
+            yv, xv = np.meshgrid(ys, xs, indexing="ij")
+            per = []
+            for octave in range(cfg["num_scales"]):
+                for aspect in cfg["aspect_ratios"]:
+                    base_x = scales[lvl - lo] * sx * 2 ** (octave / float(cfg["num_scales"]))
+                    base_y = scales[lvl - lo] * sy * 2 ** (octave / float(cfg["num_scales"]))
+                    if isinstance(aspect, (list, tuple)):
+                        ax, ay = aspect
+                    else:
+                        ax = np.sqrt(aspect)
+                        ay = 1.0 / ax
+                    hx, hy = base_x * ax / 2.0, base_y * ay / 2.0
+                    per.append(np.stack([yv - hy, xv - hx, yv + hy, xv + hx], axis=-1))
+            levels.append(np.stack(per, axis=2).reshape(-1, 4))
+        return np.concatenate(levels).astype(np.float32)
+
+    def to_c(self, post_mode=capi.POST_GLOBAL):
+        cfg = self.cfg
+        H, W = parse_image_size(cfg["image_size"])
+        m = capi.Model()
+        m.abi_version = capi.UDA_ABI_VERSION
+        m.image_h, m.image_w = H, W
+        mean, std = cfg["mean_rgb"], cfg["stddev_rgb"]
+        if not isinstance(mean, (list, tuple)):
+            mean, std = [mean] * 3, [std] * 3
+        for i in range(3):
+            m.mean_rgb[i] = np.float32(mean[i])
+            m.stddev_rgb[i] = np.float32(std[i])
+        m.num_levels = len(self.level_hw)
+        for i, (h, w_) in enumerate(self.level_hw):
+            m.level_h[i], m.level_w[i] = h, w_
+        m.anchors_per_loc = len(cfg["aspect_ratios"]) * cfg["num_scales"]
+        m.num_classes = cfg["num_classes"]
+        m.loss_attenuation = int(bool(cfg["loss_attenuation"]))
+        m.mc_samples = self.T
+        m.cls_stacked = int(self.cls_stacked_dev)
+        m.box_stacked = int(self.box_stacked_dev)
+        m.has_uncert = int(bool(cfg["loss_attenuation"] or cfg["mc_dropout"]))
+        method = cfg["uncert_adjust_method"]
+        if not cfg["loss_attenuation"]:
+            m.decode_method = capi.DECODE_PLAIN
+        elif method in ("l-norm", "n-flow"):     # n-flow is analytically the l-norm closed form
+            m.decode_method = capi.DECODE_LNORM
+        elif method == "falsedec":
+            m.decode_method = capi.DECODE_FALSEDEC
+        else:
+            raise ValueError("uncert_adjust_method %r is not available on the HIP path" % method)
+        m.enable_softmax = int(bool(cfg["enable_softmax"]))
+        sigma2, iou, thr = nms_params(cfg)
+        m.nms_soft_sigma, m.nms_iou_thresh, m.nms_score_thresh = sigma2, iou, thr
+        m.max_output_size = int(cfg["nms_configs"]["max_output_size"])
+        m.max_nms_inputs = int(cfg["nms_configs"].get("max_nms_inputs", 0) or 0)
+        m.post_mode = post_mode
+        m.chunk_images, m.max_images = self.chunk_images, self.max_images
+        m.arena_floats = self.arena_floats
+        m.n_drop_sites = len(self.sites)
+
+        bufs = (capi.BufDesc * len(self.bufs))()
+        for i, b in enumerate(self.bufs):
+            bufs[i].H, bufs[i].W, bufs[i].C = b.H, b.W, b.C
+            bufs[i].per_sample = int(b.per_sample)
+            bufs[i].offset, bufs[i].kind, bufs[i].level = int(b.offset), b.kind, b.level
+        ops = (capi.Op * len(self.ops))()
+        for i, o in enumerate(self.ops):
+            c = ops[i]
+            c.kind = o["kind"]
+            ins = (o["ins"] + [-1, -1, -1])[:3]
+            for j in range(3):
+                c.in_[j] = ins[j]
+                c.resample[j] = o["resample"][j]
+                c.fuse_w[j] = o["fuse_w"][j]
+            c.n_in = len(o["ins"])
+            for k in ("out", "se_scale", "se_partial", "residual", "k", "stride", "act", "w_off", "bias_off",
+                      "bn_scale_off", "bn_shift_off", "se_w1_off", "se_b1_off", "se_w2_off", "se_b2_off",
+                      "se_mid", "drop_site"):
+                setattr(c, k, int(o[k]))
+        sites = (capi.DropSite * max(1, len(self.sites)))()
+        for i, (_, ch, r) in enumerate(self.sites):
+            sites[i].channels, sites[i].rate = ch, np.float32(r)
+        blob = np.concatenate(self.blob) if self.blob else np.zeros(4, np.float32)
+        return m, bufs, ops, sites, blob, self.anchors()
+
+    def summary(self):
+        return dict(n_ops=len(self.ops), n_bufs=len(self.bufs), arena_mb=self.arena_floats * 4 / 2 ** 20,
+                    weights_mb=self.blob_len * 4 / 2 ** 20, sites=len(self.sites), T=self.T)
+
+
+def nms_params(cfg):
+    """(sigma/2, iou_thresh, score_thresh) exactly as postprocess.nms derives them (:373-398)."""
+    nc = cfg["nms_configs"]
+    method = nc["method"]
+    if method == "hard" or not method:
+        return 0.0, float(nc["iou_thresh"] or 0.5), float(nc["score_thresh"] or float("-inf"))
+    if method == "gaussian":
+        return float(nc["sigma"] or 0.5) / 2, 0.5, float(nc["score_thresh"] or 0.001)
+    raise ValueError("Inference has invalid nms method {}".format(method))
