@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""Headline benchmark: images x MC-samples / s (and p50 serve latency) of the MC-dropout
+EfficientDet-D0 path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one pass of the hot path over one batch of synthetic input already resident in HBM:
+preprocess -> EfficientDet-D0 x T (Philox MC dropout) -> MC mean/std + variance-propagating
+decode -> NonMaxSuppressionV5 -> packed detections, for `--batch` images per GPU (weak scaling:
+every rank owns its own shard of images; the only exchange is the all-gather of the KB-scale
+detection records at the end of each step).  Workload = BASELINE.json configs[1]: D0, 32 synthetic
+KITTI-resolution images (1280x768), T=10, full MC dropout + loss attenuation, C=7.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus
+  roofline     dominant kernel kind: algorithmic bytes / HIP-event device time vs the 8 TB/s HBM peak
+  cpu_baseline the CPU oracle (restatement, not TF) timed on a bounded sample in a subprocess
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+KIND_NAMES = {1: "stem_kernel", 2: "pw_kernel", 3: "dw_kernel", 4: "se_kernel", 5: "fuse_kernel",
+              6: "fuse_kernel(pool)", 16: "aggregate_kernel", 17: "nms_*", 18: "preprocess_kernel"}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--samples", type=int, default=10, help="MC samples T")
+    ap.add_argument("--image-size", default="1280x768", help="WxH as the reference writes it")
+    ap.add_argument("--classes", type=int, default=7)
+    ap.add_argument("--variant", default="full", choices=["full", "head"],
+                    help="full: mc_dropoutrate=0.05 everywhere; head: class/box head dropout only")
+    ap.add_argument("--chunk", type=int, default=2, help="images per pass of the op list")
+    ap.add_argument("--model", default="efficientdet-d0")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-t", type=int, default=10)
+    ap.add_argument("--cpu-sample-images", type=int, default=1)
+    return ap.parse_args()
+
+
+def make_params(a):
+    from uda_amd import hparams_config
+    cfg = hparams_config.get_efficientdet_config(a.model)
+    over = dict(image_size=a.image_size, num_classes=a.classes, mc_dropout=True, mc_dropoutsamp=a.samples,
+                loss_attenuation=True, enable_softmax=True)
+    if a.variant == "full":
+        over.update(mc_dropoutrate=0.05)
+    else:
+        over.update(mc_classheadrate=0.05, mc_boxheadrate=0.05)
+    cfg.override(over)
+    p = cfg.as_dict()
+    p["is_training_bn"] = False
+    return p
+
+
+def cpu_baseline(a):
+    """Oracle timed in a clean subprocess (no GPU runtime in that process)."""
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--image-size", a.image_size,
+           "--classes", str(a.classes), "--samples", str(a.cpu_sample_t), "--images", str(a.cpu_sample_images), "--variant", a.variant,
+           "--model", a.model]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
+        return {"value": None, "unit": "images*MC-samples/s", "cores": None, "kind": "port",
+                "sample": "failed: %r" % (e,)}
+
+
+def log(msg):
+    print("[bench %.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1 or a.gpus > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch                    # torch first: the HIP library then binds to the same runtime
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        tdev = torch.device("cuda", local_rank)
+
+    from uda_amd import capi, plan as plan_mod, weights as weights_mod
+    from uda_amd.infer_lib import ServingDriver
+
+    params = make_params(a)
+    w = weights_mod.init_weights(params, seed=0)
+    drv = ServingDriver("_", False, a.model, batch_size=a.batch, model_params=params, weights=w,
+                        device=local_rank, chunk_images=min(a.chunk, a.batch))
+    W_, H_ = [int(v) for v in a.image_size.lower().split("x")]
+    images = np.random.default_rng(2 + rank).integers(0, 256, (a.batch, H_, W_, 3), dtype=np.uint8)
+
+    log("driver ready: %s" % (drv.plan.summary(),))
+    t_up = time.perf_counter()
+    drv.stage_images(images)                       # PCIe leg, outside the timed region
+    upload_s = time.perf_counter() - t_up
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        drv.synchronize()
+
+    def step():
+        drv.run_resident(sync=True)
+        det = drv._collect(a.batch)
+        if dist is not None:
+            from uda_amd.dist import all_gather_detections
+            det = all_gather_detections(det, device=tdev)
+        return det
+
+    # warm-up; the first warm-up step also ranks the kernel kinds by device time
+    kinds = [1, 2, 3, 4, 5, 6, 16, 17, 18]
+    calib = {}
+    for i in range(max(1, a.warmup)):
+        if i == 0:
+            drv.profile_enable(kinds)
+        step()
+        if i == 0:
+            calib = {k: drv.profile_read(k) for k in kinds}
+            drv.profile_enable([])
+        log("warm-up step %d done; kernel ms by kind: %s" % (i, {KIND_NAMES[k]: round(v[0], 1) for k, v in calib.items()}))
+    dominant = max(calib, key=lambda k: calib[k][0])
+    drv.profile_enable([dominant])                 # HIP events around that kind only, inside the timed region
+
+    barrier()
+    lat = []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ts = time.perf_counter()
+        step()
+        lat.append(time.perf_counter() - ts)
+        log("timed step %d: %.1f ms" % (len(lat), lat[-1] * 1e3))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    dom_ms, dom_launches = drv.profile_read(dominant)
+    costs = plan_mod.op_costs(drv.plan, a.batch)
+    units = world * a.batch * a.samples * a.steps
+    value = units / elapsed
+
+    if rank == 0:
+        roof = None
+        if dominant in costs and dom_launches:
+            cst = costs[dominant]
+            per_launch_bytes = cst["bytes"] / cst["launches"]
+            avg_ms = dom_ms / dom_launches
+            achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": KIND_NAMES.get(dominant, str(dominant)),
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 4), "launches": int(dom_launches),
+                    "algorithmic_bytes_per_launch": int(per_launch_bytes),
+                    "tflops": round(cst["flops"] / cst["launches"] / (avg_ms * 1e-3) / 1e12, 2),
+                    "share_of_step": round(dom_ms / a.steps / (elapsed / a.steps * 1e3), 3)}
+            tf = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tf):
+                try:
+                    roof["traffic"] = json.load(open(tf)).get(KIND_NAMES.get(dominant, ""), None)
+                except Exception:
+                    pass
+        line = {
+            "metric": "images*MC-samples/sec, EfficientDet-D0 MC-dropout serve (preprocess+net xT+decode+NMS)",
+            "value": round(value, 2), "unit": "images*MC-samples/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "p50_serve_latency_ms": round(float(np.median(lat)) * 1e3, 2),
+            "config": {"workload": "BASELINE configs[1]: %s, %d synthetic KITTI-res images (%s) per GPU, "
+                                   "MC-dropout T=%d (%s), loss attenuation, C=%d, global soft-NMS"
+                                   % (a.model, a.batch, a.image_size, a.samples, a.variant, a.classes),
+                       "images_per_gpu": a.batch, "mc_samples": a.samples, "chunk_images": a.chunk,
+                       "weights": "random init (reference initialisers), seed 0",
+                       "sharding": "images across ranks, all-gather of detections"},
+            "kernel_ms_per_step": {KIND_NAMES.get(k, str(k)): round(v[0], 2) for k, v in calib.items()},
+            "h2d_upload_ms": round(upload_s * 1e3, 1),
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            log("GPU part done (%.2f units/s); timing the CPU oracle on a bounded sample ..." % value)
+            line["cpu_baseline"] = cpu_baseline(a)
+        print(json.dumps(line), flush=True)
+    drv.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

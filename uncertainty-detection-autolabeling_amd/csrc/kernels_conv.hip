@@ -174,10 +174,12 @@ void launch_pw(const PwArgs& a, int rows, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------ depthwise
-// Thread = 4 channels x XB consecutive output columns of one output row.  Consecutive
+// Thread = 4 channels x XB consecutive output columns x DW_ROWS output rows.  Consecutive
 // threads walk the channel quads of a pixel first (16-byte loads, fully coalesced NHWC),
 // then the x-groups.  The per-tile channel sums for squeeze-excite are reduced in a fixed
 // order (deterministic; no float atomics).
+constexpr int DW_ROWS = 8;  // output rows per block: 8x fewer SE tile sums, weights stay hot in L1
+
 template <int K, int S, int XB>
 __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
   __shared__ float4 red[256];
@@ -186,45 +188,15 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
   const int b = blockIdx.z / a.n_cchunk, cc = blockIdx.z % a.n_cchunk;
   const int c4 = cc * a.tc + c4l;
   const int C4 = a.C >> 2;
-  const int y = blockIdx.y;
   const int x0 = (blockIdx.x * a.pxb + pg) * XB;
   const bool active = (pg < a.pxb) && (c4 < C4) && (x0 < a.Wo);
   constexpr int NCOL = (XB - 1) * S + K;
-  float4 acc[XB];
-#pragma unroll
-  for (int o = 0; o < XB; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f);
 
   if (active) {
     const int b_in = b / a.in_div;
     const float* inb = a.in + (size_t)b_in * a.H * a.W * a.C + c4 * 4;
     const float* wb = a.w + c4 * 4;
-    const int iy0 = y * S - a.pad_t, ix0 = x0 * S - a.pad_l;
-#pragma unroll
-    for (int ky = 0; ky < K; ++ky) {
-      const int iy = iy0 + ky;
-      if (iy < 0 || iy >= a.H) continue;
-      const float* rowp = inb + (size_t)iy * a.W * a.C;
-      float4 col[NCOL];
-#pragma unroll
-      for (int j = 0; j < NCOL; ++j) {
-        const int ix = ix0 + j;
-        col[j] = (ix >= 0 && ix < a.W) ? *(const float4*)(rowp + (size_t)ix * a.C)
-                                        : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-#pragma unroll
-      for (int kx = 0; kx < K; ++kx) {
-        const float4 w = *(const float4*)(wb + (size_t)(ky * K + kx) * a.C);
-#pragma unroll
-        for (int o = 0; o < XB; ++o) {
-          const float4 v = col[o * S + kx];
-          acc[o].x = fmaf(v.x, w.x, acc[o].x);
-          acc[o].y = fmaf(v.y, w.y, acc[o].y);
-          acc[o].z = fmaf(v.z, w.z, acc[o].z);
-          acc[o].w = fmaf(v.w, w.w, acc[o].w);
-        }
-      }
-    }
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.bn_scale) {
       sc = *(const float4*)(a.bn_scale + c4 * 4);
@@ -232,22 +204,56 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
     }
     float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
     if (a.mask) mk = *(const float4*)(a.mask + (size_t)b * a.C + c4 * 4);
-    float* outp = a.out + (((size_t)b * a.Ho + y) * a.Wo) * a.C + c4 * 4;
+    const int ix0 = x0 * S - a.pad_l;
+    for (int r = 0; r < DW_ROWS; ++r) {
+      const int y = blockIdx.y * DW_ROWS + r;
+      if (y >= a.Ho) break;
+      float4 acc[XB];
 #pragma unroll
-    for (int o = 0; o < XB; ++o) {
-      const int x = x0 + o;
-      if (x >= a.Wo) break;
-      float4 v;
-      v.x = fmaf(acc[o].x, sc.x, sh.x);
-      v.y = fmaf(acc[o].y, sc.y, sh.y);
-      v.z = fmaf(acc[o].z, sc.z, sh.z);
-      v.w = fmaf(acc[o].w, sc.w, sh.w);
-      if (a.act == UDA_ACT_SWISH) {
-        v.x = swishf(v.x); v.y = swishf(v.y); v.z = swishf(v.z); v.w = swishf(v.w);
+      for (int o = 0; o < XB; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int iy0 = y * S - a.pad_t;
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        const int iy = iy0 + ky;
+        if (iy < 0 || iy >= a.H) continue;
+        const float* rowp = inb + (size_t)iy * a.W * a.C;
+        float4 col[NCOL];
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) {
+          const int ix = ix0 + j;
+          col[j] = (ix >= 0 && ix < a.W) ? *(const float4*)(rowp + (size_t)ix * a.C)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          const float4 w = *(const float4*)(wb + (size_t)(ky * K + kx) * a.C);
+#pragma unroll
+          for (int o = 0; o < XB; ++o) {
+            const float4 v = col[o * S + kx];
+            acc[o].x = fmaf(v.x, w.x, acc[o].x);
+            acc[o].y = fmaf(v.y, w.y, acc[o].y);
+            acc[o].z = fmaf(v.z, w.z, acc[o].z);
+            acc[o].w = fmaf(v.w, w.w, acc[o].w);
+          }
+        }
       }
-      v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
-      *(float4*)(outp + (size_t)x * a.C) = v;
-      ssum.x += v.x; ssum.y += v.y; ssum.z += v.z; ssum.w += v.w;
+      float* outp = a.out + (((size_t)b * a.Ho + y) * a.Wo) * a.C + c4 * 4;
+#pragma unroll
+      for (int o = 0; o < XB; ++o) {
+        const int x = x0 + o;
+        if (x >= a.Wo) break;
+        float4 v;
+        v.x = fmaf(acc[o].x, sc.x, sh.x);
+        v.y = fmaf(acc[o].y, sc.y, sh.y);
+        v.z = fmaf(acc[o].z, sc.z, sh.z);
+        v.w = fmaf(acc[o].w, sc.w, sh.w);
+        if (a.act == UDA_ACT_SWISH) {
+          v.x = swishf(v.x); v.y = swishf(v.y); v.z = swishf(v.z); v.w = swishf(v.w);
+        }
+        v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
+        *(float4*)(outp + (size_t)x * a.C) = v;
+        ssum.x += v.x; ssum.y += v.y; ssum.z += v.z; ssum.w += v.w;
+      }
     }
   }
   if (a.se_partial) {
@@ -259,7 +265,7 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
         const float4 u = red[g * a.tc + c4l];
         t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
       }
-      const size_t tile = (size_t)y * gridDim.x + blockIdx.x;
+      const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
       *(float4*)(a.se_partial + ((size_t)b * a.n_tiles + tile) * a.C + c4 * 4) = t;
     }
   }
@@ -282,13 +288,20 @@ void dw_geometry(int C, int Wo, int stride, int* tc, int* pxb, int* n_cchunk, in
   *grid_x = (Wo + p * x - 1) / (p * x);
 }
 
+int dw_tiles(int C, int Ho, int Wo, int stride) {
+  int tc, pxb, ncc, gx, xb;
+  dw_geometry(C, Wo, stride, &tc, &pxb, &ncc, &gx, &xb);
+  return ((Ho + DW_ROWS - 1) / DW_ROWS) * gx;
+}
+
 void launch_dw(DwArgs a, int rows, int k, int stride, hipStream_t s) {
   int gx, xb;
   dw_geometry(a.C, a.Wo, stride, &a.tc, &a.pxb, &a.n_cchunk, &gx, &xb);
-  a.n_tiles = a.Ho * gx;
+  const int gy = (a.Ho + DW_ROWS - 1) / DW_ROWS;
+  a.n_tiles = gy * gx;
   int threads = a.tc * a.pxb;
   threads = (threads + 63) / 64 * 64;
-  const dim3 grid(gx, a.Ho, rows * a.n_cchunk), block(threads);
+  const dim3 grid(gx, gy, rows * a.n_cchunk), block(threads);
   if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_kernel<3, 1, 4>), grid, block, 0, s, a);
   else if (k == 3 && stride == 2) hipLaunchKernelGGL((dw_kernel<3, 2, 2>), grid, block, 0, s, a);
   else if (k == 5 && stride == 1) hipLaunchKernelGGL((dw_kernel<5, 1, 4>), grid, block, 0, s, a);
@@ -299,24 +312,47 @@ void launch_dw(DwArgs a, int rows, int k, int stride, hipStream_t s) {
 // One block per sample row: channel means from the depthwise kernel's tile sums (fixed
 // order), then the two tiny dense layers.
 __global__ __launch_bounds__(256) void se_kernel(SeArgs a) {
-  extern __shared__ float sm[];  // mean[C] | mid[mid]
-  float* mean = sm;
-  float* mid = sm + a.C;
+  extern __shared__ float sm[];  // red[256 float4] | mean[C] | mid[mid]
+  float4* red = (float4*)sm;
+  float* mean = sm + 1024;
+  float* mid = mean + a.C;
+  const int tid = threadIdx.x;
   const int b = blockIdx.x;
   const float* part = a.partial + (size_t)b * a.n_tiles * a.C;
-  for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
-    float s = 0.f;
-    for (int t = 0; t < a.n_tiles; ++t) s += part[(size_t)t * a.C + c];
-    mean[c] = s * a.inv_hw;
+  const int C4 = a.C >> 2;
+  // channel sums: thread = (channel quad, tile group); groups are combined in a fixed order
+  for (int cbase = 0; cbase < C4; cbase += 256) {
+    const int cw = min(256, C4 - cbase);
+    const int G = 256 / cw;
+    const int c4 = cbase + tid % cw, g = tid / cw;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g < G) {
+      for (int t = g; t < a.n_tiles; t += G) {
+        const float4 v = *(const float4*)(part + (size_t)t * a.C + c4 * 4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (g == 0) {
+      for (int g2 = 1; g2 < G; ++g2) {
+        const float4 v = red[g2 * cw + tid];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      mean[c4 * 4 + 0] = s.x * a.inv_hw;
+      mean[c4 * 4 + 1] = s.y * a.inv_hw;
+      mean[c4 * 4 + 2] = s.z * a.inv_hw;
+      mean[c4 * 4 + 3] = s.w * a.inv_hw;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  for (int j = threadIdx.x; j < a.mid; j += blockDim.x) {
+  for (int j = tid; j < a.mid; j += blockDim.x) {
     float s = 0.f;
     for (int c = 0; c < a.C; ++c) s = fmaf(mean[c], a.w1[(size_t)c * a.mid + j], s);
     mid[j] = swishf(s + a.b1[j]);
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+  for (int c = tid; c < a.C; c += blockDim.x) {
     float s = 0.f;
     for (int j = 0; j < a.mid; ++j) s = fmaf(mid[j], a.w2[(size_t)j * a.C + c], s);
     a.scale[(size_t)b * a.C + c] = sigmoidf_(s + a.b2[c]);
@@ -324,7 +360,7 @@ __global__ __launch_bounds__(256) void se_kernel(SeArgs a) {
 }
 
 void launch_se(const SeArgs& a, int rows, hipStream_t s) {
-  hipLaunchKernelGGL(se_kernel, dim3(rows), dim3(256), (a.C + a.mid) * sizeof(float), s, a);
+  hipLaunchKernelGGL(se_kernel, dim3(rows), dim3(256), (1024 + a.C + a.mid) * sizeof(float), s, a);
 }
 
 // ------------------------------------------------------------------------------------ fusion / pooling

@@ -522,11 +522,10 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       a.in_div = v.div(ib, ob);
       a.act = o.act;
       if (o.se_partial >= 0) {
-        int tc, pxb, ncc, gx, xb;
-        dw_geometry(ob.C, ob.W, o.stride, &tc, &pxb, &ncc, &gx, &xb);
+        const int nt = dw_tiles(ob.C, ob.H, ob.W, o.stride);
         const uda_buf_desc_t& pb = c->bufs[o.se_partial];
-        if ((int64_t)pb.H * pb.W < (int64_t)ob.H * gx || pb.C != ob.C || pb.per_sample != ob.per_sample)
-          return fail(c, "op %d: SE partial buffer [%d,%d,%d] too small for %d tiles", oi, pb.H, pb.W, pb.C, ob.H * gx);
+        if ((int64_t)pb.H * pb.W < (int64_t)nt || pb.C != ob.C || pb.per_sample != ob.per_sample)
+          return fail(c, "op %d: SE partial buffer [%d,%d,%d] too small for %d tiles", oi, pb.H, pb.W, pb.C, nt);
         a.se_partial = v.ptr(o.se_partial);
       }
       launch_dw(a, rows, o.k, o.stride, c->stream);
@@ -535,14 +534,12 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
     case UDA_OP_SE: {
       const uda_buf_desc_t& pb = c->bufs[o.in[0]];   // partial sums written by the DW op
       const uda_buf_desc_t& src = c->bufs[o.in[1]];  // the DW output (for H*W and geometry)
-      int tc, pxb, ncc, gx, xb;
-      dw_geometry(src.C, src.W, o.stride, &tc, &pxb, &ncc, &gx, &xb);
       SeArgs a{};
       a.partial = v.ptr(o.in[0]);
       a.scale = v.ptr(o.out);
       a.w1 = v.wt(o.se_w1_off); a.b1 = v.wt(o.se_b1_off);
       a.w2 = v.wt(o.se_w2_off); a.b2 = v.wt(o.se_b2_off);
-      a.C = src.C; a.mid = o.se_mid; a.n_tiles = src.H * gx;
+      a.C = src.C; a.mid = o.se_mid; a.n_tiles = dw_tiles(src.C, src.H, src.W, o.stride);
       a.inv_hw = 1.0f / (float)(src.H * src.W);
       if (pb.C != src.C || ob.C != src.C) return fail(c, "op %d: SE channel mismatch", oi);
       launch_se(a, rows, c->stream);

@@ -85,6 +85,7 @@ void launch_stem(const StemArgs& a, hipStream_t s);
 void launch_pw(const PwArgs& a, int rows, hipStream_t s);
 void launch_dw(DwArgs a, int rows, int k, int stride, hipStream_t s);
 void dw_geometry(int C, int Wo, int stride, int* tc, int* pxb, int* n_cchunk, int* grid_x, int* xb);
+int dw_tiles(int C, int Ho, int Wo, int stride);  // SE tile sums one depthwise launch leaves per sample row
 void launch_se(const SeArgs& a, int rows, hipStream_t s);
 void launch_fuse(const FuseArgs& a, hipStream_t s);
 void launch_philox_masks(float* masks, const int64_t* site_off_dev, const int32_t* site_ch_dev,

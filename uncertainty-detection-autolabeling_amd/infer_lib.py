@@ -158,6 +158,17 @@ class ServingDriver:
             out.append(logits)
         return tuple(out)
 
+    def empty_detections(self):
+        """A zero-image output tuple with the right trailing shapes (ragged multi-GPU shards)."""
+        bc, cc = C.c_int32(), C.c_int32()
+        self._ck(self._lib.uda_detection_cols(self._h, -1, C.byref(bc), C.byref(cc)), "uda_detection_cols")
+        cls_shape = (0, self.M) if cc.value == 1 else (0, self.M, cc.value)
+        out = [np.zeros((0, self.M, bc.value), np.float32), np.zeros((0, self.M), np.float32),
+               np.zeros(cls_shape, np.float32), np.zeros((0,), np.int32)]
+        if self.params["enable_softmax"]:
+            out.append(np.zeros((0, self.M, self.num_classes), np.float32))
+        return tuple(out)
+
     def serve(self, image_arrays):
         """uint8 [N,h,w,3] -> (boxes, scores, classes, valid_len[, logits])."""
         a = self._as_u8_batch(image_arrays)

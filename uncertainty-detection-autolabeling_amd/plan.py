@@ -34,6 +34,14 @@ def dw_tiles_x(C, Wo, stride):
     return (Wo + p * x - 1) // (p * x)
 
 
+DW_ROWS = 8  # mirror of DW_ROWS in csrc/kernels_conv.hip
+
+
+def dw_tiles(C, Ho, Wo, stride):
+    """SE tile sums one depthwise launch leaves per sample row (mirror of dw_tiles in csrc)."""
+    return -(-Ho // DW_ROWS) * dw_tiles_x(C, Wo, stride)
+
+
 def same_out(n, s):
     return -(-n // s)
 
@@ -145,7 +153,7 @@ class Plan:
         if bn is not None:
             kw["bn_scale_off"], kw["bn_shift_off"] = self._bn(bn)
         if with_se:
-            kw["se_partial"] = self._buf(Ho * dw_tiles_x(xb.C, Wo, stride), 1, xb.C, ps, name=name + "/se_partial")
+            kw["se_partial"] = self._buf(dw_tiles(xb.C, Ho, Wo, stride), 1, xb.C, ps, name=name + "/se_partial")
         self._op(capi.OP_DW, [x], out, **kw)
         return out, kw.get("se_partial", -1)
 
@@ -452,3 +460,49 @@ def nms_params(cfg):
     if method == "gaussian":
         return float(nc["sigma"] or 0.5) / 2, 0.5, float(nc["score_thresh"] or 0.001)
     raise ValueError("Inference has invalid nms method {}".format(method))
+
+
+def op_costs(plan, n_images):
+    """Layer-wise ALGORITHMIC cost of one pass of the op list over `n_images` images:
+    {op kind: dict(bytes, flops, launches)}.  Per op: every input tensor is read once, the
+    weights once, the output written once (BN / bias / activation / dropout folded into the
+    producing op) — the accounting SURVEY §8d uses for its MB/W figures."""
+    import math
+    T = plan.T
+    chunks = math.ceil(n_images / plan.chunk_images)
+    out = {}
+
+    def size(bi):
+        b = plan.bufs[bi]
+        return n_images * (T if b.per_sample else 1) * b.H * b.W * b.C
+
+    for o in plan.ops:
+        ob = plan.bufs[o["out"]]
+        rows = n_images * (T if ob.per_sample else 1)
+        by = size(o["out"])
+        fl = 0
+        for bi in (o["ins"][:1] if o["kind"] == capi.OP_SE else o["ins"]):
+            by += size(bi)          # SE reads only the tile sums the depthwise kernel left
+        for key in ("se_scale", "residual", "se_partial"):
+            if o[key] >= 0 and o["kind"] != capi.OP_SE:
+                by += size(o[key])
+        k = o["kind"]
+        if k == capi.OP_PW:
+            cin = plan.bufs[o["ins"][0]].C
+            by += cin * ob.C
+            fl = 2 * rows * ob.H * ob.W * cin * ob.C
+        elif k == capi.OP_DW:
+            by += o["k"] * o["k"] * ob.C
+            fl = 2 * rows * ob.H * ob.W * ob.C * o["k"] * o["k"]
+        elif k == capi.OP_STEM:
+            by += 27 * ob.C
+            fl = 2 * rows * ob.H * ob.W * 27 * ob.C
+        elif k == capi.OP_SE:
+            fl = 4 * rows * ob.C * o["se_mid"]
+        elif k in (capi.OP_FUSE, capi.OP_POOL):
+            fl = rows * ob.H * ob.W * ob.C * len(o["ins"]) * 2
+        d = out.setdefault(k, dict(bytes=0, flops=0, launches=0))
+        d["bytes"] += 4 * by
+        d["flops"] += fl
+        d["launches"] += chunks
+    return out
