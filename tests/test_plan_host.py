@@ -1,0 +1,195 @@
+"""Host logic on the CPU: config mirror, topology / structure KATs, the lowering to the op
+list (sample-axis propagation, arena liveness), anchors, cost accounting."""
+import os
+
+import numpy as np
+import pytest
+
+from common import FULL_MC, HEAD_MC, LOSS_ATT, PLAIN, BOX_ONLY_MC, make_params, make_weights
+from uda_amd import arch, capi, hparams_config as hp, plan as plan_mod, weights as W
+
+
+# ------------------------------------------------------------------ config mirror (hparams_config.py)
+def test_config_override_forms(tmp_path):
+    c = hp.get_efficientdet_config("efficientdet-d0")
+    assert (c.fpn_num_filters, c.fpn_cell_repeats, c.box_class_repeats, c.backbone_name) == (64, 3, 3, "efficientnet-b0")
+    c.override("mc_dropout=True,mc_dropoutrate=0.05,nms_configs.max_output_size=50,aspect_ratios=1.0*2.0*0.5")
+    assert c.mc_dropout is True and c.mc_dropoutrate == 0.05 and c.nms_configs.max_output_size == 50
+    assert c.aspect_ratios == [1.0, 2.0, 0.5] and c["nms_configs"]["method"] == "gaussian"
+    with pytest.raises(KeyError):
+        c.override(dict(no_such_key=1))
+    y = tmp_path / "cfg.yaml"
+    y.write_text("num_classes: 7\nimage_size: '1024x512'\nmc_dropout: True\nmc_boxheadrate: 0.05\nlabel_map: 'kitti'\n")
+    c.override(str(y))
+    assert c.num_classes == 7 and hp.parse_image_size(c.image_size) == (512, 1024) and c.label_map == "kitti"
+    with pytest.raises(ValueError):
+        c.override("nonsense")
+    d = hp.get_efficientdet_config("efficientdet-d2")
+    assert (d.backbone_name, d.fpn_num_filters, d.fpn_cell_repeats) == ("efficientnet-b2", 112, 5)
+    with pytest.raises(ValueError):
+        hp.get_detection_config("resnet")
+
+
+def test_reference_yaml_files_load_if_present():
+    ref = "/root/reference/configs/train"
+    if not os.path.isdir(ref):
+        pytest.skip("reference not mounted (GPU box)")
+    for f in sorted(os.listdir(ref)):
+        if f.endswith(".yaml"):
+            c = hp.get_efficientdet_config("efficientdet-d0")
+            c.override(os.path.join(ref, f))
+            assert c.num_classes in (7, 10)
+
+
+def test_image_and_feature_sizes():
+    assert hp.parse_image_size("1280x768") == (768, 1280) and hp.parse_image_size(512) == (512, 512)
+    assert hp.get_feat_sizes("1280x768", 7)[3:] == [(96, 160), (48, 80), (24, 40), (12, 20), (6, 10)]
+    assert hp.get_feat_sizes(1024, 7)[3:] == [(128, 128), (64, 64), (32, 32), (16, 16), (8, 8)]
+
+
+# ------------------------------------------------------------------ structure KATs (efficientnet_builder_test.py:46-86)
+@pytest.mark.parametrize("bb,full,feat", [("efficientnet-b0", 5288548, 3595388), ("efficientnet-b1", 7794184, None),
+                                           ("efficientnet-b2", 9109994, None), ("efficientnet-b3", 12233232, None),
+                                           ("efficientnet-b4", 19341616, None), ("efficientnet-b5", 30389784, None),
+                                           ("efficientnet-b6", 43040704, None), ("efficientnet-b7", 66347960, None)])
+def test_backbone_parameter_counts(bb, full, feat):
+    p = dict(make_params(), backbone_name=bb)
+    specs = [s for s in W.variable_specs(p) if s[0].startswith(bb)]
+    n = W.count_trainable(specs)
+    if feat is not None:
+        assert n == feat
+    last = arch.backbone_blocks(bb)[-1]["cout"]
+    head = arch.round_filters(1280, arch.EFFICIENTNET_PARAMS[bb][0])
+    assert n + last * head + 2 * head + head * 1000 + 1000 == full
+
+
+def test_block_table_and_reductions():
+    b0 = arch.backbone_blocks("efficientnet-b0")
+    assert len(b0) == 16 and [b0[i]["cout"] for i in arch.reduction_block_ids(b0)] == [16, 24, 40, 112, 320]
+    assert [b["se"] for b in b0[:4]] == [8, 4, 6, 6]
+    b2 = arch.backbone_blocks("efficientnet-b2")
+    assert sorted(set(b["cout"] for b in b2)) == [16, 24, 48, 88, 120, 208, 352]
+    assert [sum(1 for b in b2 if b["cout"] == c) for c in (16, 24, 48, 88, 120, 208, 352)] == [2, 3, 3, 4, 4, 5, 2]
+    nodes = arch.bifpn_nodes(3, 7)
+    assert [n["inputs_offsets"] for n in nodes] == [[3, 4], [2, 5], [1, 6], [0, 7], [1, 7, 8], [2, 6, 9], [3, 5, 10], [4, 11]]
+
+
+def test_weight_names_follow_the_reference():
+    p = make_params(**FULL_MC)
+    w = make_weights(p)
+    for k in ("efficientnet-b0/stem/conv2d/kernel", "efficientnet-b0/blocks_0/conv2d/kernel",
+              "efficientnet-b0/blocks_1/conv2d_1/kernel", "efficientnet-b0/blocks_1/tpu_batch_normalization_2/gamma",
+              "efficientnet-b0/blocks_3/se/conv2d_1/bias", "resample_p6/conv2d/kernel", "resample_p6/bn/moving_mean",
+              "fpn_cells/cell_0/fnode0/WSM_1", "fpn_cells/cell_0/fnode1/resample_0_2_6/conv2d/kernel",
+              "fpn_cells/cell_2/fnode7/op_after_combine12/conv/pointwise_kernel",
+              "class_net/class-2-bn-7/beta", "class_net/class-predict/bias", "box_net/box-predict/pointwise_kernel"):
+        assert k in w, k
+    assert "resample_p7/conv2d/kernel" not in w and "fpn_cells/cell_1/fnode1/resample_0_2_6/conv2d/kernel" not in w
+    assert w["box_net/box-predict/pointwise_kernel"].shape == (1, 1, 64, 72)
+    np.testing.assert_allclose(w["class_net/class-predict/bias"], -np.log(99.0), rtol=1e-6)
+
+
+# ------------------------------------------------------------------ lowering
+def _plan(over, **kw):
+    p = make_params(**over)
+    return plan_mod.Plan(p, make_weights(p), **kw), p
+
+
+def test_op_list_shape_d0():
+    pl, _ = _plan(FULL_MC, chunk_images=2, max_images=4)
+    kinds = [o["kind"] for o in pl.ops]
+    assert len(pl.ops) == 224
+    assert kinds.count(capi.OP_STEM) == 1 and kinds.count(capi.OP_SE) == 16 and kinds.count(capi.OP_FUSE) == 24
+    assert kinds.count(capi.OP_POOL) == 2 and kinds.count(capi.OP_DW) == 16 + 24 + 40
+    assert kinds.count(capi.OP_PW) == 31 + 1 + 5 + 24 + 40
+    assert len(pl.sites) == 61 and pl.T == 3
+
+
+def test_sample_axis_propagation():
+    full, _ = _plan(FULL_MC)
+    bn = full.buffer_names
+    assert not full.bufs[bn["image"]].per_sample and not full.bufs[bn["stem"]].per_sample
+    assert full.bufs[bn["blocks_0/dw"]].per_sample and full.bufs[bn["blocks_15/out"]].per_sample
+    assert full.cls_stacked_dev and full.box_stacked_dev
+    head, _ = _plan(HEAD_MC)
+    hb = head.buffer_names
+    assert not head.bufs[hb["blocks_15/out"]].per_sample and not head.bufs[hb["cell2/fnode7/out"]].per_sample
+    assert not head.bufs[hb["class-0-3/dw"]].per_sample          # depthwise before the first head dropout is shared
+    assert head.bufs[hb["class-0-3"]].per_sample and head.bufs[hb["box-predict-7"]].per_sample
+    assert all(o["drop_site"] == -1 for o in head.ops if head.bufs[o["out"]].name.startswith("blocks_"))
+    box_only, _ = _plan(BOX_ONLY_MC)
+    assert not box_only.cls_stacked_dev and box_only.box_stacked_dev and not box_only.cls_stacked
+    plain, _ = _plan(PLAIN)
+    assert plain.T == 1 and not any(b.per_sample for b in plain.bufs) and not plain.sites
+    la, _ = _plan(LOSS_ATT)
+    assert la.bufs[la.head_out["box"][0]].C == 72 and plain.bufs[plain.head_out["box"][0]].C == 36
+
+
+@pytest.mark.parametrize("over,chunk", [(FULL_MC, 1), (FULL_MC, 3), (HEAD_MC, 2), (PLAIN, 4)])
+def test_arena_liveness_has_no_overlap(over, chunk):
+    pl, _ = _plan(over, chunk_images=chunk, max_images=4)
+    live = []
+    for bi, b in enumerate(pl.bufs):
+        if b.kind != 0 or b.first is None:
+            continue
+        size = pl._rows(b) * b.H * b.W * b.C
+        assert b.offset % plan_mod.ALIGN == 0 and b.offset + size <= pl.arena_floats
+        live.append((b.first, b.last, b.offset, b.offset + size, bi))
+    for i, (f1, l1, o1, e1, b1) in enumerate(live):
+        for f2, l2, o2, e2, b2 in live[i + 1:]:
+            if f1 <= l2 and f2 <= l1:                      # lifetimes intersect -> memory must not
+                assert e1 <= o2 or e2 <= o1, (pl.bufs[b1].name, pl.bufs[b2].name)
+    # every op's inputs are written before they are read
+    written = {i for i, b in enumerate(pl.bufs) if b.kind == 1}
+    for o in pl.ops:
+        for i in o["ins"] + [o[k] for k in ("se_scale", "residual") if o[k] >= 0]:
+            assert i in written, pl.bufs[i].name
+        written.add(o["out"])
+        if o["se_partial"] >= 0:
+            written.add(o["se_partial"])
+
+
+def test_to_c_structures_roundtrip():
+    pl, p = _plan(FULL_MC, chunk_images=2, max_images=5)
+    m, bufs, ops, sites, blob, anchors = pl.to_c()
+    assert m.mc_samples == 3 and m.cls_stacked == 1 and m.has_uncert == 1 and m.decode_method == capi.DECODE_LNORM
+    assert abs(m.nms_soft_sigma - 0.25) < 1e-7 and abs(m.nms_score_thresh - 0.001) < 1e-9 and m.max_output_size == 100
+    assert m.num_levels == 5 and [m.level_h[i] for i in range(5)] == [16, 8, 4, 2, 1]
+    assert blob.dtype == np.float32 and blob.size == pl.blob_len and len(ops) == len(pl.ops)
+    assert anchors.shape == (sum(h * w for h, w in pl.level_hw) * 9, 4)
+    for o, c in zip(pl.ops, ops):
+        assert c.kind == o["kind"] and c.out == o["out"] and c.n_in == len(o["ins"]) and c.w_off == o["w_off"]
+    with pytest.raises(ValueError):
+        plan_mod.Plan(dict(p, uncert_adjust_method="sample"), pl.w).to_c()
+    hard = dict(p, nms_configs=dict(p["nms_configs"], method="hard"))
+    assert plan_mod.nms_params(hard) == (0.0, 0.5, float("-inf"))
+    with pytest.raises(ValueError):
+        plan_mod.nms_params(dict(p, nms_configs=dict(p["nms_configs"], method="linear")))
+
+
+def test_anchor_table_matches_oracle():
+    from oracle import post_ref
+    for size in ("192x128", 64, "1280x768"):
+        p = make_params(image_size=size)
+        pl = plan_mod.Plan(p, make_weights(p)) if size != "1280x768" else None
+        got = pl.anchors() if pl else plan_mod.Plan.anchors(type("X", (), {"cfg": p})())
+        np.testing.assert_array_equal(got, post_ref.anchor_boxes(p))
+
+
+def test_sites_match_oracle_convention():
+    from oracle import effdet_ref
+    for over in (FULL_MC, HEAD_MC, BOX_ONLY_MC):
+        pl, p = _plan(over)
+        want = effdet_ref.dropout_sites(p)
+        assert [(n, c) for n, c, _ in pl.sites] == [(n, c) for n, c, _ in want]
+        np.testing.assert_allclose([r for _, _, r in pl.sites], [r for _, _, r in want])
+
+
+def test_cost_accounting_close_to_survey_figures():
+    """D0 768x1280 C=7 loss-att = 8.487 GMAC/W; the plan shares the stem across T."""
+    p = make_params(image_size="1280x768", mc_dropout=True, mc_dropoutrate=0.05, mc_dropoutsamp=10, loss_attenuation=True)
+    pl = plan_mod.Plan(p, make_weights(p), chunk_images=2, max_images=32)
+    costs = plan_mod.op_costs(pl, 32)
+    gmac_per_w = sum(v["flops"] for v in costs.values()) / 2 / 320 / 1e9
+    assert 8.0 < gmac_per_w < 8.5
+    assert costs[capi.OP_PW]["launches"] == 101 * 16 and costs[capi.OP_DW]["launches"] == 80 * 16

@@ -222,7 +222,9 @@ class Plan:
             src = self.bufs[feats[-1]]
             th, tw = (src.H + 1) // 2, (src.W + 1) // 2
             xr, mode = self._resample(feats[-1], th, tw, "resample_p%d" % lvl, "resample_p%d" % lvl)
-            assert mode == capi.RS_MAXPOOL
+            if mode == capi.RS_NONE:        # a 1x1 map cannot shrink further: the level repeats (keras :339-342)
+                feats.append(xr)
+                continue
             out = self._buf(th, tw, F, self.bufs[xr].per_sample, name="p%d_in" % lvl)
             feats.append(self._op(capi.OP_POOL, [xr], out, resample=[capi.RS_MAXPOOL, 0, 0], fuse_w=[1.0, 0, 0]))
         # ---- BiFPN
