@@ -44,11 +44,11 @@ def parse():
     ap.add_argument("--classes", type=int, default=7)
     ap.add_argument("--variant", default="full", choices=["full", "head"],
                     help="full: mc_dropoutrate=0.05 everywhere; head: class/box head dropout only")
-    ap.add_argument("--chunk", type=int, default=2, help="images per pass of the op list")
+    ap.add_argument("--chunk", type=int, default=16, help="images per pass of the op list")
     ap.add_argument("--model", default="efficientdet-d0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-t", type=int, default=10)
-    ap.add_argument("--cpu-sample-images", type=int, default=1)
+    ap.add_argument("--cpu-sample-images", type=int, default=4)
     return ap.parse_args()
 
 

@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""Map a rocprofv3 --kernel-trace CSV of bench.py onto the op list: per-op duration,
+achieved algorithmic GB/s and TFLOP/s.   python tools/analyze_trace.py trace.csv [--chunk 16]"""
+import argparse
+import csv
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from uda_amd import capi, hparams_config, plan as plan_mod, weights as weights_mod  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("trace")
+ap.add_argument("--chunk", type=int, default=16)
+ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--samples", type=int, default=10)
+ap.add_argument("--variant", default="full")
+ap.add_argument("--top", type=int, default=40)
+a = ap.parse_args()
+
+cfg = hparams_config.get_efficientdet_config("efficientdet-d0")
+over = dict(image_size="1280x768", num_classes=7, mc_dropout=True, mc_dropoutsamp=a.samples, loss_attenuation=True,
+            enable_softmax=True)
+over.update(dict(mc_dropoutrate=0.05) if a.variant == "full" else dict(mc_classheadrate=0.05, mc_boxheadrate=0.05))
+cfg.override(over)
+p = cfg.as_dict()
+pl = plan_mod.Plan(p, weights_mod.init_weights(p, 0), chunk_images=a.chunk, max_images=a.batch)
+
+rows = list(csv.DictReader(open(a.trace)))
+names = ("stem_kernel", "pw_kernel", "dw_kernel", "se_kernel", "fuse_kernel")
+idx = [i for i, r in enumerate(rows) if "preprocess" in r["Kernel_Name"]]
+rows = rows[idx[-1]:]
+conv = [r for r in rows if any(n in r["Kernel_Name"] for n in names)]
+nops = len(pl.ops)
+assert len(conv) % nops == 0, (len(conv), nops)
+first = conv[:nops]                       # first chunk of the last step
+T = pl.T
+res = []
+for o, r in zip(pl.ops, first):
+    dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    ob = pl.bufs[o["out"]]
+    size = lambda bi: a.chunk * (T if pl.bufs[bi].per_sample else 1) * pl.bufs[bi].H * pl.bufs[bi].W * pl.bufs[bi].C
+    by = size(o["out"]) + sum(size(i) for i in (o["ins"][:1] if o["kind"] == capi.OP_SE else o["ins"]))
+    for k in ("se_scale", "residual", "se_partial"):
+        if o[k] >= 0 and o["kind"] != capi.OP_SE:
+            by += size(o[k])
+    fl = 0
+    rows_ = a.chunk * (T if ob.per_sample else 1)
+    if o["kind"] == capi.OP_PW:
+        cin = pl.bufs[o["ins"][0]].C
+        fl = 2 * rows_ * ob.H * ob.W * cin * ob.C
+        desc = "pw %4d->%-4d @%dx%d" % (cin, ob.C, ob.H, ob.W)
+    elif o["kind"] == capi.OP_DW:
+        fl = 2 * rows_ * ob.H * ob.W * ob.C * o["k"] ** 2
+        desc = "dw k%d s%d C=%-4d @%dx%d" % (o["k"], o["stride"], ob.C, ob.H, ob.W)
+    else:
+        desc = {1: "stem", 4: "se", 5: "fuse", 6: "pool"}[o["kind"]] + " C=%d @%dx%d" % (ob.C, ob.H, ob.W)
+    res.append((dur, desc, ob.name, by * 4, fl, r["Kernel_Name"].split("(")[0][-16:], r["VGPR_Count"]))
+tot = sum(r[0] for r in res)
+print("chunk of %d images: %d ops, %.2f ms kernel time" % (a.chunk, nops, tot / 1e3))
+for kind in ("pw", "dw", "se", "fuse", "stem", "pool"):
+    sel = [r for r in res if r[1].startswith(kind)]
+    if sel:
+        t = sum(r[0] for r in sel)
+        print("  %-5s %8.2f ms  %7.1f GB/s  %6.1f TFLOP/s" % (kind, t / 1e3, sum(r[3] for r in sel) / t / 1e3,
+                                                              sum(r[4] for r in sel) / t / 1e6))
+print("top ops:")
+for dur, desc, name, by, fl, kn, vg in sorted(res, reverse=True)[:a.top]:
+    print("  %8.1f us  %-28s %-22s %7.1f GB/s %6.1f TF/s  %s v%s" % (dur, desc, name, by / dur / 1e3, fl / dur / 1e6, kn, vg))

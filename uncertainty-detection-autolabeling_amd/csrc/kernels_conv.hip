@@ -13,14 +13,18 @@
 //
 // Wavefront = 64.  The pointwise GEMM uses v_mfma_f32_32x32x2_f32 (exact f32, runs at the
 // f32 vector rate); everything else is HBM-bound streaming with 16-byte accesses.
+#include <stdlib.h>
+
 #include "uda_internal.h"
 
 namespace uda {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float swishf(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with the hardware exp2 / rcp (1-ulp) instead of an IEEE divide: the activations
+// are compared with the oracle at 2e-4, and the divide sequence was a third of the pw epilogue.
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float swishf(float x) { return x * sigmoidf_(x); }
 
 // ------------------------------------------------------------------------------------ stem
 // One thread = one output pixel x 4 output channels; the 27 x Co weights sit in LDS.
@@ -77,22 +81,37 @@ void launch_stem(const StemArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------ pointwise
-// Block tile 128 pixels x (32*NT) output channels, K staged 32 at a time through LDS.
-// 4 waves; wave w owns pixel rows [32w, 32w+32) and all NT 32-wide column tiles.
-// A is staged transposed ([k][m], row stride 129 -> conflict-free writes and reads) so that
-// lane (i = lane&31, h = lane>>5) reads A[m = i][k = kk + h] with consecutive lanes on
-// consecutive banks; B is [k][n] straight from the TF kernel layout [Cin][Cout].
+// 1x1 conv as an f32 MFMA GEMM.  Block = 4 waves, tile = 128 pixels x (32*NT) output channels;
+// wave w owns pixel rows [32w, 32w+32) and all NT column tiles (NT accumulators of 16 VGPRs).
+//  * K is staged 32 deep through LDS; the next chunk's global loads are issued before the MFMAs
+//    of the current one (register prefetch), so HBM latency hides behind the matrix work.
+//  * A is staged transposed ([k][m], row stride 129: conflict-free writes and reads): lane
+//    (i = lane&31, h = lane>>5) feeds A[m = i][k = kk + h] to v_mfma_f32_32x32x2_f32;
+//    B is [k][n] straight from the TF kernel layout [Cin][Cout].
+//  * epilogue: accumulators go through a wave-private LDS tile so that every lane stores 16
+//    contiguous bytes (a 64-channel row segment = 256 contiguous bytes per 16 lanes), with
+//    bias / BN / swish / dropout keep-scale / residual applied on the float4.
+constexpr int PW_BM = 128, PW_BK = 32;
+constexpr int PW_STG = 68;  // staging row stride (floats): 64 columns + 4 pad
+
 template <int NT>
 __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
-  constexpr int BM = 128, BK = 32, BN = 32 * NT;
-  __shared__ float As[BK][BM + 1];
-  __shared__ float Bs[BK][BN];
+  constexpr int BM = PW_BM, BK = PW_BK, BN = 32 * NT;
+  constexpr int A_FLOATS = BK * (BM + 1);
+  constexpr int B_FLOATS = BK * BN;
+  constexpr int STG_FLOATS = 4 * 32 * PW_STG;
+  constexpr int LDS_FLOATS = (A_FLOATS + B_FLOATS) > STG_FLOATS ? (A_FLOATS + B_FLOATS) : STG_FLOATS;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  float(*As)[BM + 1] = (float(*)[BM + 1])lds;
+  float(*Bs)[BN] = (float(*)[BN])(lds + A_FLOATS);
+
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, b_in = b / a.in_div;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const float* A = a.in + (size_t)b_in * a.HW * a.Cin;
   const float* se = a.se ? a.se + (size_t)b_in * a.Cin : nullptr;
+  const bool vecB = (a.Cout & 3) == 0;
 
   f32x16 acc[NT];
 #pragma unroll
@@ -100,76 +119,198 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 
-  for (int k0 = 0; k0 < a.Cin; k0 += BK) {
+  constexpr int B_VEC_ITERS = (BK * BN / 4 + 255) / 256;
+  constexpr int B_SCL_ITERS = BK * BN / 256;
+  float4 ra[4];
+  float4 rb[B_VEC_ITERS];
+  float4 rg = make_float4(1.f, 1.f, 1.f, 1.f);   // SE gate of this thread's 4 k columns (same for its 4 rows)
+
+  auto load_chunk = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int f = tid + 256 * i;
       const int m = f >> 3, kq = f & 7;
       const int k = k0 + 4 * kq;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m0 + m < a.HW && k < a.Cin) {
-        v = *(const float4*)(A + (size_t)(m0 + m) * a.Cin + k);
-        if (se) {
-          const float4 g = *(const float4*)(se + k);
-          v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
+      if (m0 + m < a.HW && k < a.Cin) v = *(const float4*)(A + (size_t)(m0 + m) * a.Cin + k);
+      ra[i] = v;
+    }
+    if (se) {   // applied when the chunk is written to LDS, so the loads stay in flight over the MFMAs
+      const int k = k0 + 4 * (tid & 7);
+      rg = (k < a.Cin) ? *(const float4*)(se + k) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+    if (vecB) {
+#pragma unroll
+      for (int i = 0; i < B_VEC_ITERS; ++i) {
+        const int f = tid + 256 * i;
+        const int kk = f / (BN / 4), nq = f % (BN / 4);
+        const int k = k0 + kk, col = n0 + 4 * nq;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < BK * BN / 4 && k < a.Cin && col < a.Cout) v = *(const float4*)(a.w + (size_t)k * a.Cout + col);
+        rb[i] = v;
+      }
+    }
+  };
+  auto store_chunk = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = tid + 256 * i;
+      const int m = f >> 3, kq = f & 7;
+      As[4 * kq + 0][m] = ra[i].x * rg.x;
+      As[4 * kq + 1][m] = ra[i].y * rg.y;
+      As[4 * kq + 2][m] = ra[i].z * rg.z;
+      As[4 * kq + 3][m] = ra[i].w * rg.w;
+    }
+    if (vecB) {
+#pragma unroll
+      for (int i = 0; i < B_VEC_ITERS; ++i) {
+        const int f = tid + 256 * i;
+        if (f < BK * BN / 4) {
+          const int kk = f / (BN / 4), nq = f % (BN / 4);
+          *(float4*)&Bs[kk][4 * nq] = rb[i];
         }
       }
-      As[4 * kq + 0][m] = v.x;
-      As[4 * kq + 1][m] = v.y;
-      As[4 * kq + 2][m] = v.z;
-      As[4 * kq + 3][m] = v.w;
-    }
+    } else {  // Cout not a multiple of 4 (class head: 9*7 = 63): scalar weight loads
 #pragma unroll
-    for (int i = 0; i < (BK * BN) / 256; ++i) {
-      const int f = tid + 256 * i;
-      const int kk = f / BN, n = f % BN;
-      const int k = k0 + kk, col = n0 + n;
-      Bs[kk][n] = (k < a.Cin && col < a.Cout) ? a.w[(size_t)k * a.Cout + col] : 0.f;
+      for (int i = 0; i < B_SCL_ITERS; ++i) {
+        const int f = tid + 256 * i;
+        const int kk = f / BN, n = f % BN;
+        const int k = k0 + kk, col = n0 + n;
+        Bs[kk][n] = (k < a.Cin && col < a.Cout) ? a.w[(size_t)k * a.Cout + col] : 0.f;
+      }
     }
+  };
+
+  load_chunk(0);
+  for (int k0 = 0; k0 < a.Cin; k0 += BK) {
+    store_chunk(k0);
     __syncthreads();
+    if (k0 + BK < a.Cin) load_chunk(k0 + BK);   // in flight during the MFMAs below
     const int kend = min(BK, a.Cin - k0);
-    for (int kk = 0; kk < kend; kk += 2) {
-      const float av = As[kk + lh][wave * 32 + li];
+    if (kend == BK) {
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const float bv = Bs[kk + lh][n * 32 + li];
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[n], 0, 0, 0);
+      for (int kk = 0; kk < BK; kk += 2) {
+        const float av = As[kk + lh][wave * 32 + li];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const float bv = Bs[kk + lh][n * 32 + li];
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[n], 0, 0, 0);
+        }
+      }
+    } else {
+      for (int kk = 0; kk < kend; kk += 2) {
+        const float av = As[kk + lh][wave * 32 + li];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const float bv = Bs[kk + lh][n * 32 + li];
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[n], 0, 0, 0);
+        }
       }
     }
     __syncthreads();
   }
 
-  // epilogue: lane holds column (li) of 16 rows: row = (r&3) + 8*(r>>2) + 4*lh
   const size_t out_base = (size_t)b * a.HW;
   const size_t res_base = a.res ? (size_t)(b / a.res_div) * a.HW : 0;
+
+  if (!vecB) {
+    // scalar epilogue: lane holds column li of 16 rows: row = (r&3) + 8*(r>>2) + 4*lh
 #pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int col = n0 + n * 32 + li;
-    if (col >= a.Cout) continue;
-    const float bias = a.bias ? a.bias[col] : 0.f;
-    const float sc = a.bn_scale ? a.bn_scale[col] : 1.f;
-    const float sh = a.bn_scale ? a.bn_shift[col] : 0.f;
-    const float mk = a.mask ? a.mask[(size_t)b * a.Cout + col] : 1.f;
+    for (int n = 0; n < NT; ++n) {
+      const int col = n0 + n * 32 + li;
+      if (col >= a.Cout) continue;
+      const float bias = a.bias ? a.bias[col] : 0.f;
+      const float sc = a.bn_scale ? a.bn_scale[col] : 1.f;
+      const float sh = a.bn_scale ? a.bn_shift[col] : 0.f;
+      const float mk = a.mask ? a.mask[(size_t)b * a.Cout + col] : 1.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (m >= a.HW) continue;
-      float v = acc[n][r] + bias;
-      v = fmaf(v, sc, sh);
-      if (a.act == UDA_ACT_SWISH) v = swishf(v);
-      v *= mk;
-      if (a.res) v += a.res[(res_base + m) * a.Cout + col];
-      a.out[(out_base + m) * a.Cout + col] = v;
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= a.HW) continue;
+        float v = acc[n][r] + bias;
+        v = fmaf(v, sc, sh);
+        if (a.act == UDA_ACT_SWISH) v = swishf(v);
+        v *= mk;
+        if (a.res) v += a.res[(res_base + m) * a.Cout + col];
+        a.out[(out_base + m) * a.Cout + col] = v;
+      }
     }
+    return;
+  }
+
+  // vector epilogue through a wave-private staging tile [32 rows][64 cols (+4 pad)]
+  float* stg = lds + wave * 32 * PW_STG;
+  const int rrow = lane >> 4, c4 = lane & 15;   // read-back: 16 lanes per row, 4 rows per pass
+#pragma unroll
+  for (int p = 0; p < (NT + 1) / 2; ++p) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int n = 2 * p + q;
+      if (n < NT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * PW_STG + q * 32 + li] = acc[n][r];
+      }
+    }
+    __syncthreads();
+    const int col = n0 + p * 64 + 4 * c4;
+    const bool colok = (col < a.Cout) && (p * 64 + 4 * c4 < BN);
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 sh = make_float4(0.f, 0.f, 0.f, 0.f), mk = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (colok) {
+      if (a.bias) bias = *(const float4*)(a.bias + col);
+      if (a.bn_scale) {
+        sc = *(const float4*)(a.bn_scale + col);
+        sh = *(const float4*)(a.bn_shift + col);
+      }
+      if (a.mask) mk = *(const float4*)(a.mask + (size_t)b * a.Cout + col);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 4 + rrow;
+      const int m = m0 + wave * 32 + row;
+      if (colok && m < a.HW) {
+        float4 v = *(const float4*)(stg + row * PW_STG + 4 * c4);
+        v.x = fmaf(v.x + bias.x, sc.x, sh.x);
+        v.y = fmaf(v.y + bias.y, sc.y, sh.y);
+        v.z = fmaf(v.z + bias.z, sc.z, sh.z);
+        v.w = fmaf(v.w + bias.w, sc.w, sh.w);
+        if (a.act == UDA_ACT_SWISH) {
+          v.x = swishf(v.x); v.y = swishf(v.y); v.z = swishf(v.z); v.w = swishf(v.w);
+        }
+        v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
+        if (a.res) {
+          const float4 rr = *(const float4*)(a.res + (res_base + m) * a.Cout + col);
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        *(float4*)(a.out + (out_base + m) * a.Cout + col) = v;
+      }
+    }
+    __syncthreads();
   }
 }
 
 void launch_pw(const PwArgs& a, int rows, hipStream_t s) {
-  const int gx = (a.HW + 127) / 128;
-  if (a.Cout <= 32) {
-    hipLaunchKernelGGL(pw_kernel<1>, dim3(gx, 1, rows), dim3(256), 0, s, a);
-  } else {
-    hipLaunchKernelGGL(pw_kernel<2>, dim3(gx, (a.Cout + 63) / 64, rows), dim3(256), 0, s, a);
+  const int gx = (a.HW + PW_BM - 1) / PW_BM;
+  // one pass over the columns when Cout <= 192, else the fewest passes of <= 6 column tiles
+  static int maxnt = -1, maxnt_small = -1;
+  if (maxnt < 0) {
+    const char* e = getenv("UDA_PW_MAXNT");
+    maxnt = e ? atoi(e) : 4;
+    const char* e2 = getenv("UDA_PW_MAXNT_SMALLK");
+    maxnt_small = e2 ? atoi(e2) : maxnt;
+  }
+  const int cap = 32 * (a.Cin <= 48 ? maxnt_small : maxnt);
+  const int passes = (a.Cout + cap - 1) / cap;
+  const int per = (a.Cout + passes - 1) / passes;
+  const int nt = (per + 31) / 32;
+  const dim3 grid(gx, (a.Cout + 32 * nt - 1) / (32 * nt), rows), block(256);
+  switch (nt) {
+    case 1: hipLaunchKernelGGL(pw_kernel<1>, grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL(pw_kernel<2>, grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL(pw_kernel<3>, grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL(pw_kernel<4>, grid, block, 0, s, a); break;
+    case 5: hipLaunchKernelGGL(pw_kernel<5>, grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL(pw_kernel<6>, grid, block, 0, s, a); break;
   }
 }
 
@@ -178,25 +319,35 @@ void launch_pw(const PwArgs& a, int rows, hipStream_t s) {
 // threads walk the channel quads of a pixel first (16-byte loads, fully coalesced NHWC),
 // then the x-groups.  The per-tile channel sums for squeeze-excite are reduced in a fixed
 // order (deterministic; no float atomics).
-constexpr int DW_ROWS = 8;  // output rows per block: 8x fewer SE tile sums, weights stay hot in L1
+constexpr int DW_ROWS = 8;  // output rows per block
 
+// Each thread keeps a K-row x NCOL-column window of its 4 channels in registers and slides it
+// down the DW_ROWS output rows: every input element is loaded once per block column strip
+// (instead of K times), the K*K weight quads of the block's channels sit in LDS.
 template <int K, int S, int XB>
-__global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
-  __shared__ float4 red[256];
+__global__ __launch_bounds__(256, 3) void dw_kernel(DwArgs a) {
+  extern __shared__ float4 dsm[];          // wts[K*K][tc] | red[blockDim]
+  float4* wts = dsm;
+  float4* red = dsm + K * K * a.tc;
   const int tid = threadIdx.x;
   const int c4l = tid % a.tc, pg = tid / a.tc;
   const int b = blockIdx.z / a.n_cchunk, cc = blockIdx.z % a.n_cchunk;
   const int c4 = cc * a.tc + c4l;
   const int C4 = a.C >> 2;
+  for (int i = tid; i < K * K * a.tc; i += blockDim.x) {
+    const int tap = i / a.tc, q = cc * a.tc + i % a.tc;
+    wts[i] = (q < C4) ? *(const float4*)(a.w + (size_t)tap * a.C + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
   const int x0 = (blockIdx.x * a.pxb + pg) * XB;
   const bool active = (pg < a.pxb) && (c4 < C4) && (x0 < a.Wo);
   constexpr int NCOL = (XB - 1) * S + K;
+  constexpr int IN_ROWS = (DW_ROWS - 1) * S + K;
   float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f);
 
   if (active) {
     const int b_in = b / a.in_div;
     const float* inb = a.in + (size_t)b_in * a.H * a.W * a.C + c4 * 4;
-    const float* wb = a.w + c4 * 4;
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.bn_scale) {
       sc = *(const float4*)(a.bn_scale + c4 * 4);
@@ -204,55 +355,61 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
     }
     float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
     if (a.mask) mk = *(const float4*)(a.mask + (size_t)b * a.C + c4 * 4);
-    const int ix0 = x0 * S - a.pad_l;
-    for (int r = 0; r < DW_ROWS; ++r) {
-      const int y = blockIdx.y * DW_ROWS + r;
-      if (y >= a.Ho) break;
-      float4 acc[XB];
+    const int y0 = blockIdx.y * DW_ROWS;
+    const int iy_base = y0 * S - a.pad_t, ix0 = x0 * S - a.pad_l;
+    float4 win[K][NCOL];
 #pragma unroll
-      for (int o = 0; o < XB; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int iy0 = y * S - a.pad_t;
+    for (int r = 0; r < IN_ROWS; ++r) {
+      const int iy = iy_base + r;
+      const bool rowok = (iy >= 0) && (iy < a.H);
+      const float* rowp = inb + (size_t)(rowok ? iy : 0) * a.W * a.C;
 #pragma unroll
-      for (int ky = 0; ky < K; ++ky) {
-        const int iy = iy0 + ky;
-        if (iy < 0 || iy >= a.H) continue;
-        const float* rowp = inb + (size_t)iy * a.W * a.C;
-        float4 col[NCOL];
+      for (int j = 0; j < NCOL; ++j) {
+        const int ix = ix0 + j;
+        win[r % K][j] = (rowok && ix >= 0 && ix < a.W) ? *(const float4*)(rowp + (size_t)ix * a.C)
+                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (r >= K - 1 && (r - (K - 1)) % S == 0) {
+        const int o_row = (r - (K - 1)) / S;
+        const int y = y0 + o_row;
+        if (y < a.Ho) {
+          float4 acc[XB];
 #pragma unroll
-        for (int j = 0; j < NCOL; ++j) {
-          const int ix = ix0 + j;
-          col[j] = (ix >= 0 && ix < a.W) ? *(const float4*)(rowp + (size_t)ix * a.C)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+          for (int o = 0; o < XB; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-          const float4 w = *(const float4*)(wb + (size_t)(ky * K + kx) * a.C);
+          for (int ky = 0; ky < K; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+              const float4 w = wts[(ky * K + kx) * a.tc + c4l];
+#pragma unroll
+              for (int o = 0; o < XB; ++o) {
+                const float4 v = win[(o_row * S + ky) % K][o * S + kx];
+                acc[o].x = fmaf(v.x, w.x, acc[o].x);
+                acc[o].y = fmaf(v.y, w.y, acc[o].y);
+                acc[o].z = fmaf(v.z, w.z, acc[o].z);
+                acc[o].w = fmaf(v.w, w.w, acc[o].w);
+              }
+            }
+          }
+          float* outp = a.out + (((size_t)b * a.Ho + y) * a.Wo) * a.C + c4 * 4;
 #pragma unroll
           for (int o = 0; o < XB; ++o) {
-            const float4 v = col[o * S + kx];
-            acc[o].x = fmaf(v.x, w.x, acc[o].x);
-            acc[o].y = fmaf(v.y, w.y, acc[o].y);
-            acc[o].z = fmaf(v.z, w.z, acc[o].z);
-            acc[o].w = fmaf(v.w, w.w, acc[o].w);
+            const int x = x0 + o;
+            if (x < a.Wo) {
+              float4 v;
+              v.x = fmaf(acc[o].x, sc.x, sh.x);
+              v.y = fmaf(acc[o].y, sc.y, sh.y);
+              v.z = fmaf(acc[o].z, sc.z, sh.z);
+              v.w = fmaf(acc[o].w, sc.w, sh.w);
+              if (a.act == UDA_ACT_SWISH) {
+                v.x = swishf(v.x); v.y = swishf(v.y); v.z = swishf(v.z); v.w = swishf(v.w);
+              }
+              v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
+              *(float4*)(outp + (size_t)x * a.C) = v;
+              ssum.x += v.x; ssum.y += v.y; ssum.z += v.z; ssum.w += v.w;
+            }
           }
         }
-      }
-      float* outp = a.out + (((size_t)b * a.Ho + y) * a.Wo) * a.C + c4 * 4;
-#pragma unroll
-      for (int o = 0; o < XB; ++o) {
-        const int x = x0 + o;
-        if (x >= a.Wo) break;
-        float4 v;
-        v.x = fmaf(acc[o].x, sc.x, sh.x);
-        v.y = fmaf(acc[o].y, sc.y, sh.y);
-        v.z = fmaf(acc[o].z, sc.z, sh.z);
-        v.w = fmaf(acc[o].w, sc.w, sh.w);
-        if (a.act == UDA_ACT_SWISH) {
-          v.x = swishf(v.x); v.y = swishf(v.y); v.z = swishf(v.z); v.w = swishf(v.w);
-        }
-        v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
-        *(float4*)(outp + (size_t)x * a.C) = v;
-        ssum.x += v.x; ssum.y += v.y; ssum.z += v.z; ssum.w += v.w;
       }
     }
   }
@@ -271,13 +428,15 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
   }
 }
 
-void dw_geometry(int C, int Wo, int stride, int* tc, int* pxb, int* n_cchunk, int* grid_x, int* xb) {
+static inline int dw_xb(int k, int stride) { return k == 5 ? 1 : (stride == 1 ? 4 : 2); }
+
+void dw_geometry(int C, int Wo, int k, int stride, int* tc, int* pxb, int* n_cchunk, int* grid_x, int* xb) {
   const int C4 = C / 4;
-  const int ncc = (C4 + 255) / 256;
+  const int ncc = (C4 + 63) / 64;   // <= 64 channel quads per block: the K*K weight quads in LDS stay <= 25.6 KB
   const int t = (C4 + ncc - 1) / ncc;
   int p = 256 / t;
   if (p < 1) p = 1;
-  const int x = (stride == 1) ? 4 : 2;
+  const int x = dw_xb(k, stride);
   // do not spread one block over more columns than the row has
   const int need = (Wo + x - 1) / x;
   if (p > need) p = need;
@@ -288,24 +447,25 @@ void dw_geometry(int C, int Wo, int stride, int* tc, int* pxb, int* n_cchunk, in
   *grid_x = (Wo + p * x - 1) / (p * x);
 }
 
-int dw_tiles(int C, int Ho, int Wo, int stride) {
+int dw_tiles(int C, int Ho, int Wo, int k, int stride) {
   int tc, pxb, ncc, gx, xb;
-  dw_geometry(C, Wo, stride, &tc, &pxb, &ncc, &gx, &xb);
+  dw_geometry(C, Wo, k, stride, &tc, &pxb, &ncc, &gx, &xb);
   return ((Ho + DW_ROWS - 1) / DW_ROWS) * gx;
 }
 
 void launch_dw(DwArgs a, int rows, int k, int stride, hipStream_t s) {
   int gx, xb;
-  dw_geometry(a.C, a.Wo, stride, &a.tc, &a.pxb, &a.n_cchunk, &gx, &xb);
+  dw_geometry(a.C, a.Wo, k, stride, &a.tc, &a.pxb, &a.n_cchunk, &gx, &xb);
   const int gy = (a.Ho + DW_ROWS - 1) / DW_ROWS;
   a.n_tiles = gy * gx;
   int threads = a.tc * a.pxb;
   threads = (threads + 63) / 64 * 64;
   const dim3 grid(gx, gy, rows * a.n_cchunk), block(threads);
-  if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_kernel<3, 1, 4>), grid, block, 0, s, a);
-  else if (k == 3 && stride == 2) hipLaunchKernelGGL((dw_kernel<3, 2, 2>), grid, block, 0, s, a);
-  else if (k == 5 && stride == 1) hipLaunchKernelGGL((dw_kernel<5, 1, 4>), grid, block, 0, s, a);
-  else if (k == 5 && stride == 2) hipLaunchKernelGGL((dw_kernel<5, 2, 2>), grid, block, 0, s, a);
+  const size_t lds = ((size_t)k * k * a.tc + threads) * sizeof(float4);
+  if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_kernel<3, 1, 4>), grid, block, lds, s, a);
+  else if (k == 3 && stride == 2) hipLaunchKernelGGL((dw_kernel<3, 2, 2>), grid, block, lds, s, a);
+  else if (k == 5 && stride == 1) hipLaunchKernelGGL((dw_kernel<5, 1, 1>), grid, block, lds, s, a);
+  else if (k == 5 && stride == 2) hipLaunchKernelGGL((dw_kernel<5, 2, 1>), grid, block, lds, s, a);
 }
 
 // ------------------------------------------------------------------------------------ squeeze-excite

@@ -272,11 +272,28 @@ __device__ __forceinline__ float nms_iou(const float* a, const float* b) {
   return inter / (area_i + area_j - inter);
 }
 
-// pending suppression chain of one candidate; returns false when the candidate is dropped
-__device__ __forceinline__ bool nms_chain(const NmsArgs& a, const float* box, const float* sel_box,
-                                          int begin, int k, float& score) {
+// LDS of the epoch kernels: the image's selected boxes + the block's compacted work list
+struct NmsLds {
+  float sel[4 * 128];        // up to 128 selected boxes (max_output_size <= 128 on this path)
+  int list[NMS_CHUNK];       // candidates of this chunk whose pending chain must be evaluated
+  int count;
+};
+
+__device__ __forceinline__ void nms_load_sel(const NmsArgs& a, NmsLds& L, int n, int k) {
+  for (int t = threadIdx.x; t < 4 * k; t += blockDim.x) L.sel[t] = a.sel_box[(size_t)n * a.M * 4 + t];
+  if (threadIdx.x == 0) L.count = 0;
+  __syncthreads();
+}
+
+// exact updated score of candidate i in epoch k: the reference's pending chain as written
+// (j = k-1 .. begin, newest selected box first, with its early exits); -inf when dropped.
+__device__ __forceinline__ float nms_chain_eval(const NmsArgs& a, const NmsLds& L, size_t base, int i, int k) {
+  float score = a.stale[base + i];
+  const int begin = a.begin[base + i];
+  const float4 b4 = *(const float4*)(a.boxes + (base + i) * 4);
+  const float bx[4] = {b4.x, b4.y, b4.z, b4.w};
   for (int j = k - 1; j >= begin; --j) {
-    const float sim = nms_iou(box, sel_box + 4 * j);
+    const float sim = nms_iou(bx, L.sel + 4 * j);
     float w;
     if (a.soft || sim <= a.iou_thr) {
       const float e = a.scale * sim * sim;
@@ -285,10 +302,32 @@ __device__ __forceinline__ bool nms_chain(const NmsArgs& a, const float* box, co
       w = 0.0f;
     }
     score *= w;
-    if (!a.soft && sim > a.iou_thr) return false;
-    if (score <= a.score_thr) return false;
+    if (!a.soft && sim > a.iou_thr) return -INFINITY;
+    if (score <= a.score_thr) return -INFINITY;
   }
-  return true;
+  return score;
+}
+
+// Evaluate the block's work list, one candidate per thread round-robin (the flagged candidates
+// of a chunk are spatial neighbours, so without the compaction a few waves would carry all the
+// chains).  Records tent / ub / ev; returns the best key among the entries this thread evaluated.
+__device__ __forceinline__ unsigned long long nms_run_list(const NmsArgs& a, NmsLds& L, size_t base, int k) {
+  __syncthreads();
+  unsigned long long best = 0ull;
+  const int cnt = L.count;
+  for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+    const int i = L.list[e];
+    const float s = nms_chain_eval(a, L, base, i, k);
+    a.tent[base + i] = s;
+    a.ub[base + i] = s;       // weights are <= 1: no later epoch can score this candidate higher
+    a.ev[base + i] = k;
+    if (s != -INFINITY) {
+      const unsigned long long key = nms_key(s, i);
+      best = key > best ? key : best;
+    }
+  }
+  __syncthreads();
+  return best;
 }
 
 __device__ __forceinline__ unsigned long long block_max_key(unsigned long long v) {
@@ -312,7 +351,10 @@ __global__ __launch_bounds__(256) void nms_init_kernel(NmsArgs a, const float* s
   const int64_t total = (int64_t)a.n_img * a.K;
   if (gid < total) {
     const float s = scores[gid];
-    a.stale[gid] = (s > a.score_thr) ? s : -INFINITY;
+    const float v = (s > a.score_thr) ? s : -INFINITY;
+    a.stale[gid] = v;
+    a.ub[gid] = v;
+    a.ev[gid] = -1;
     a.begin[gid] = 0;
   }
   if (gid < (int64_t)a.n_img * a.M) {
@@ -327,9 +369,12 @@ __global__ __launch_bounds__(256) void nms_init_kernel(NmsArgs a, const float* s
   }
 }
 
+// A bound: every chunk evaluates its best candidate by cached upper bound -> lower bound on the winner
 __global__ __launch_bounds__(256) void nms_bound_kernel(NmsArgs a, int k) {
+  __shared__ NmsLds L;
   const int n = blockIdx.y;
   if (a.done[n]) return;
+  nms_load_sel(a, L, n, k);
   const size_t base = (size_t)n * a.K;
   const int i0 = blockIdx.x * NMS_CHUNK;
   unsigned long long best = 0ull;
@@ -337,9 +382,9 @@ __global__ __launch_bounds__(256) void nms_bound_kernel(NmsArgs a, int k) {
   for (int it = 0; it < NMS_ITEMS; ++it) {
     const int i = i0 + it * 256 + threadIdx.x;
     if (i < a.K) {
-      const float s = a.stale[base + i];
-      if (s != -INFINITY) {
-        const unsigned long long key = nms_key(s, i);
+      const float u = a.ub[base + i];
+      if (u != -INFINITY && a.stale[base + i] != -INFINITY) {
+        const unsigned long long key = nms_key(u, i);
         best = key > best ? key : best;
       }
     }
@@ -347,17 +392,20 @@ __global__ __launch_bounds__(256) void nms_bound_kernel(NmsArgs a, int k) {
   best = block_max_key(best);
   if (threadIdx.x == 0 && best != 0ull) {
     const int idx = (int)(0xFFFFFFFFu - (uint32_t)best);
-    float score = a.stale[base + idx];
-    const int bg = a.begin[base + idx];
-    bool alive = true;
-    if (bg < k) alive = nms_chain(a, a.boxes + (base + idx) * 4, a.sel_box + (size_t)n * a.M * 4, bg, k, score);
-    if (alive) atomicMax(&a.bound_key[(size_t)n * a.M + k], nms_key(score, idx));
+    const float s = nms_chain_eval(a, L, base, idx, k);
+    a.tent[base + idx] = s;
+    a.ub[base + idx] = s;
+    a.ev[base + idx] = k;
+    if (s != -INFINITY) atomicMax(&a.bound_key[(size_t)n * a.M + k], nms_key(s, idx));
   }
 }
 
+// B eval: exact scores for every candidate whose upper bound can still reach the bound -> winner
 __global__ __launch_bounds__(256) void nms_eval_kernel(NmsArgs a, int k) {
+  __shared__ NmsLds L;
   const int n = blockIdx.y;
   if (a.done[n]) return;
+  nms_load_sel(a, L, n, k);
   const size_t base = (size_t)n * a.K;
   const unsigned long long bound = a.bound_key[(size_t)n * a.M + k];
   const int i0 = blockIdx.x * NMS_CHUNK;
@@ -366,57 +414,70 @@ __global__ __launch_bounds__(256) void nms_eval_kernel(NmsArgs a, int k) {
   for (int it = 0; it < NMS_ITEMS; ++it) {
     const int i = i0 + it * 256 + threadIdx.x;
     if (i < a.K) {
-      float s = a.stale[base + i];
-      if (s != -INFINITY && nms_key(s, i) >= bound) {
-        const int bg = a.begin[base + i];
-        bool alive = true;
-        if (bg < k) alive = nms_chain(a, a.boxes + (base + i) * 4, a.sel_box + (size_t)n * a.M * 4, bg, k, s);
-        a.tent[base + i] = alive ? s : -INFINITY;
-        if (alive) {
-          const unsigned long long key = nms_key(s, i);
+      const float u = a.ub[base + i];
+      if (u != -INFINITY && a.stale[base + i] != -INFINITY && nms_key(u, i) >= bound) {
+        if (a.ev[base + i] == k) {                 // already exact (the chunk's bound candidate)
+          const unsigned long long key = nms_key(a.tent[base + i], i);
           best = key > best ? key : best;
+        } else {
+          L.list[atomicAdd(&L.count, 1)] = i;
         }
       }
     }
   }
+  const unsigned long long b2 = nms_run_list(a, L, base, k);
+  best = b2 > best ? b2 : best;
   best = block_max_key(best);
   if (threadIdx.x == 0 && best != 0ull) atomicMax(&a.win_key[(size_t)n * a.M + k], best);
 }
 
+// C commit: the winner is selected; every candidate whose STALE priority outranks it is popped
+// once in this epoch (score <- updated score, begin <- k), exactly the reference's heap traffic.
 __global__ __launch_bounds__(256) void nms_commit_kernel(NmsArgs a, int k) {
+  __shared__ NmsLds L;
   const int n = blockIdx.y;
   if (a.done[n]) return;
   const size_t base = (size_t)n * a.K;
   const unsigned long long wk = a.win_key[(size_t)n * a.M + k];
   if (wk == 0ull) {
-    // no live candidate left: finished (every block sees the same wk; only one writes the flag,
-    // and no block of THIS launch reads it after its entry check)
     if (blockIdx.x == 0 && threadIdx.x == 0) a.done[n] = 1;
     return;
   }
+  nms_load_sel(a, L, n, k);
   const int widx = (int)(0xFFFFFFFFu - (uint32_t)wk);
   const int i0 = blockIdx.x * NMS_CHUNK;
+  bool pop[NMS_ITEMS];
 #pragma unroll
   for (int it = 0; it < NMS_ITEMS; ++it) {
     const int i = i0 + it * 256 + threadIdx.x;
-    if (i < a.K) {
+    pop[it] = false;
+    if (i < a.K && i != widx) {
       const float s = a.stale[base + i];
-      if (s == -INFINITY) continue;
-      if (i == widx) {
-        const size_t o = (size_t)n * a.M + k;
-        a.sel_idx[o] = i;
-        a.sel_score[o] = a.tent[base + i];
-        const float* bx = a.boxes + (base + i) * 4;
-        a.sel_box[o * 4 + 0] = bx[0];
-        a.sel_box[o * 4 + 1] = bx[1];
-        a.sel_box[o * 4 + 2] = bx[2];
-        a.sel_box[o * 4 + 3] = bx[3];
-        a.stale[base + i] = -INFINITY;
-        a.nsel[n] = k + 1;
-      } else if (nms_key(s, i) > wk) {
-        a.stale[base + i] = a.tent[base + i];
-        a.begin[base + i] = k;
+      if (s != -INFINITY && nms_key(s, i) > wk) {
+        pop[it] = true;
+        if (a.ev[base + i] != k) L.list[atomicAdd(&L.count, 1)] = i;   // popped without having been scored this epoch
       }
+    }
+  }
+  nms_run_list(a, L, base, k);      // (ends with a barrier: tent[] of this chunk is visible below)
+#pragma unroll
+  for (int it = 0; it < NMS_ITEMS; ++it) {
+    const int i = i0 + it * 256 + threadIdx.x;
+    if (pop[it]) {
+      a.stale[base + i] = a.tent[base + i];
+      a.begin[base + i] = k;
+    }
+    if (i == widx) {
+      const size_t o = (size_t)n * a.M + k;
+      a.sel_idx[o] = i;
+      a.sel_score[o] = a.tent[base + i];
+      const float* bx = a.boxes + (base + i) * 4;
+      a.sel_box[o * 4 + 0] = bx[0];
+      a.sel_box[o * 4 + 1] = bx[1];
+      a.sel_box[o * 4 + 2] = bx[2];
+      a.sel_box[o * 4 + 3] = bx[3];
+      a.stale[base + i] = -INFINITY;
+      a.nsel[n] = k + 1;
     }
   }
 }

@@ -70,8 +70,8 @@ struct uda_ctx {
   int32_t* d_cclasses = nullptr;
   float *d_ucls = nullptr, *d_ual = nullptr, *d_uep = nullptr;
   // nms workspace
-  float *d_stale = nullptr, *d_tent = nullptr, *d_sel_score = nullptr, *d_sel_box = nullptr;
-  int32_t *d_begin = nullptr, *d_sel_idx = nullptr, *d_nsel = nullptr, *d_done = nullptr;
+  float *d_stale = nullptr, *d_tent = nullptr, *d_ub = nullptr, *d_sel_score = nullptr, *d_sel_box = nullptr;
+  int32_t *d_ev = nullptr, *d_begin = nullptr, *d_sel_idx = nullptr, *d_nsel = nullptr, *d_done = nullptr;
   unsigned long long *d_bound = nullptr, *d_win = nullptr;
   // outputs
   float *d_oboxes = nullptr, *d_oscores = nullptr, *d_oclasses = nullptr, *d_ologits = nullptr;
@@ -161,7 +161,7 @@ extern "C" void uda_destroy(uda_ctx_t* c) {
   for (int k = 0; k < 32; ++k) prof_collect(c, k);
   void* ptrs[] = {c->d_weights, c->d_arena, c->d_anchors, c->d_u8, c->d_images, c->d_scales, c->d_masks,
                   c->d_site_off, c->d_site_ch, c->d_site_rate, c->d_cboxes, c->d_cscores, c->d_clogits,
-                  c->d_cclasses, c->d_ucls, c->d_ual, c->d_uep, c->d_stale, c->d_tent, c->d_sel_score,
+                  c->d_cclasses, c->d_ucls, c->d_ual, c->d_uep, c->d_stale, c->d_tent, c->d_ub, c->d_ev, c->d_sel_score,
                   c->d_sel_box, c->d_begin, c->d_sel_idx, c->d_nsel, c->d_done, c->d_bound, c->d_win,
                   c->d_oboxes, c->d_oscores, c->d_oclasses, c->d_ologits, c->d_ovalid};
   for (void* p : ptrs)
@@ -205,6 +205,8 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
     return fail(nullptr, "uda_create: ABI version %d, library has %d", model->abi_version, UDA_ABI_VERSION);
   if (model->num_levels < 1 || model->num_levels > UDA_MAX_LEVELS)
     return fail(nullptr, "uda_create: num_levels %d out of range", model->num_levels);
+  if (model->max_output_size < 1 || model->max_output_size > 128)
+    return fail(nullptr, "uda_create: max_output_size %d outside [1, 128]", model->max_output_size);
   if (model->chunk_images < 1 || model->max_images < 1 || model->mc_samples < 1)
     return fail(nullptr, "uda_create: chunk_images/max_images/mc_samples must be >= 1");
   int ndev = 0;
@@ -328,6 +330,8 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
   if (m.has_uncert && m.box_stacked) CK(dalloc(&c->d_uep, N * K * 4));
   CK(dalloc(&c->d_stale, N * K));
   CK(dalloc(&c->d_tent, N * K));
+  CK(dalloc(&c->d_ub, N * K));
+  CK(dalloc(&c->d_ev, N * K));
   CK(dalloc(&c->d_begin, N * K));
   CK(dalloc(&c->d_sel_idx, N * M));
   CK(dalloc(&c->d_sel_score, N * M));
@@ -522,7 +526,7 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       a.in_div = v.div(ib, ob);
       a.act = o.act;
       if (o.se_partial >= 0) {
-        const int nt = dw_tiles(ob.C, ob.H, ob.W, o.stride);
+        const int nt = dw_tiles(ob.C, ob.H, ob.W, o.k, o.stride);
         const uda_buf_desc_t& pb = c->bufs[o.se_partial];
         if ((int64_t)pb.H * pb.W < (int64_t)nt || pb.C != ob.C || pb.per_sample != ob.per_sample)
           return fail(c, "op %d: SE partial buffer [%d,%d,%d] too small for %d tiles", oi, pb.H, pb.W, pb.C, nt);
@@ -539,7 +543,7 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       a.scale = v.ptr(o.out);
       a.w1 = v.wt(o.se_w1_off); a.b1 = v.wt(o.se_b1_off);
       a.w2 = v.wt(o.se_w2_off); a.b2 = v.wt(o.se_b2_off);
-      a.C = src.C; a.mid = o.se_mid; a.n_tiles = dw_tiles(src.C, src.H, src.W, o.stride);
+      a.C = src.C; a.mid = o.se_mid; a.n_tiles = dw_tiles(src.C, src.H, src.W, o.k, o.stride);
       a.inv_hw = 1.0f / (float)(src.H * src.W);
       if (pb.C != src.C || ob.C != src.C) return fail(c, "op %d: SE channel mismatch", oi);
       launch_se(a, rows, c->stream);
@@ -635,7 +639,7 @@ static int run_network(uda_ctx* c) {
 static NmsArgs nms_args_of(uda_ctx* c, int n, int K, int M, const float* boxes) {
   NmsArgs a{};
   a.boxes = boxes;
-  a.stale = c->d_stale; a.begin = c->d_begin; a.tent = c->d_tent;
+  a.stale = c->d_stale; a.begin = c->d_begin; a.tent = c->d_tent; a.ub = c->d_ub; a.ev = c->d_ev;
   a.sel_idx = c->d_sel_idx; a.sel_score = c->d_sel_score; a.sel_box = c->d_sel_box;
   a.bound_key = c->d_bound; a.win_key = c->d_win; a.nsel = c->d_nsel; a.done = c->d_done;
   a.n_img = n; a.K = K; a.M = M;
@@ -856,14 +860,14 @@ extern "C" int uda_nms(uda_ctx_t* c, const float* boxes, const float* scores, in
                        int32_t max_out, float iou_thresh, float score_thresh, float soft_sigma, int32_t pad,
                        int32_t* idx, float* out_scores, int32_t* valid) {
   if (!c || !boxes || !scores || !idx || !out_scores || !valid) return c ? fail(c, "uda_nms: NULL argument") : 1;
-  if (n_img < 1 || k < 0 || max_out < 1) return fail(c, "uda_nms: bad sizes");
+  if (n_img < 1 || k < 0 || max_out < 1 || max_out > 128) return fail(c, "uda_nms: bad sizes (max_out must be in [1, 128])");
   HIPC(c, hipSetDevice(c->device));
   const size_t NK = (size_t)n_img * (k ? k : 1), NM = (size_t)n_img * max_out;
-  float *d_boxes, *d_scores, *d_stale, *d_tent, *d_ss, *d_sb;
-  int32_t *d_begin, *d_si, *d_nsel, *d_done;
+  float *d_boxes, *d_scores, *d_stale, *d_tent, *d_ub, *d_ss, *d_sb;
+  int32_t *d_begin, *d_ev, *d_si, *d_nsel, *d_done;
   unsigned long long *d_bound, *d_win;
   HIPC(c, dalloc(&d_boxes, NK * 4)); HIPC(c, dalloc(&d_scores, NK)); HIPC(c, dalloc(&d_stale, NK));
-  HIPC(c, dalloc(&d_tent, NK)); HIPC(c, dalloc(&d_begin, NK)); HIPC(c, dalloc(&d_si, NM));
+  HIPC(c, dalloc(&d_tent, NK)); HIPC(c, dalloc(&d_ub, NK)); HIPC(c, dalloc(&d_ev, NK)); HIPC(c, dalloc(&d_begin, NK)); HIPC(c, dalloc(&d_si, NM));
   HIPC(c, dalloc(&d_ss, NM)); HIPC(c, dalloc(&d_sb, NM * 4)); HIPC(c, dalloc(&d_bound, NM));
   HIPC(c, dalloc(&d_win, NM)); HIPC(c, dalloc(&d_nsel, (size_t)n_img)); HIPC(c, dalloc(&d_done, (size_t)n_img));
   if (k) {
@@ -871,7 +875,7 @@ extern "C" int uda_nms(uda_ctx_t* c, const float* boxes, const float* scores, in
     HIPC(c, hipMemcpyAsync(d_scores, scores, NK * sizeof(float), hipMemcpyHostToDevice, c->stream));
   }
   NmsArgs a{};
-  a.boxes = d_boxes; a.stale = d_stale; a.begin = d_begin; a.tent = d_tent;
+  a.boxes = d_boxes; a.stale = d_stale; a.begin = d_begin; a.tent = d_tent; a.ub = d_ub; a.ev = d_ev;
   a.sel_idx = d_si; a.sel_score = d_ss; a.sel_box = d_sb; a.bound_key = d_bound; a.win_key = d_win;
   a.nsel = d_nsel; a.done = d_done; a.n_img = n_img; a.K = k; a.M = max_out;
   nms_params(a, iou_thresh, score_thresh, soft_sigma);
@@ -884,7 +888,7 @@ extern "C" int uda_nms(uda_ctx_t* c, const float* boxes, const float* scores, in
   HIPC(c, hipMemcpy(idx, d_si, NM * sizeof(int32_t), hipMemcpyDeviceToHost));
   HIPC(c, hipMemcpy(out_scores, d_ss, NM * sizeof(float), hipMemcpyDeviceToHost));
   (void)pad;  // slots >= valid already hold index 0 / score 0.0 (the padded form); callers slice when pad == 0
-  void* frees[] = {d_boxes, d_scores, d_stale, d_tent, d_begin, d_si, d_ss, d_sb, d_bound, d_win, d_nsel, d_done};
+  void* frees[] = {d_boxes, d_scores, d_stale, d_tent, d_ub, d_ev, d_begin, d_si, d_ss, d_sb, d_bound, d_win, d_nsel, d_done};
   for (void* p : frees) hipFree(p);
   return 0;
 }

@@ -84,8 +84,8 @@ struct FuseArgs {
 void launch_stem(const StemArgs& a, hipStream_t s);
 void launch_pw(const PwArgs& a, int rows, hipStream_t s);
 void launch_dw(DwArgs a, int rows, int k, int stride, hipStream_t s);
-void dw_geometry(int C, int Wo, int stride, int* tc, int* pxb, int* n_cchunk, int* grid_x, int* xb);
-int dw_tiles(int C, int Ho, int Wo, int stride);  // SE tile sums one depthwise launch leaves per sample row
+void dw_geometry(int C, int Wo, int k, int stride, int* tc, int* pxb, int* n_cchunk, int* grid_x, int* xb);
+int dw_tiles(int C, int Ho, int Wo, int k, int stride);  // SE tile sums one depthwise launch leaves per sample row
 void launch_se(const SeArgs& a, int rows, hipStream_t s);
 void launch_fuse(const FuseArgs& a, hipStream_t s);
 void launch_philox_masks(float* masks, const int64_t* site_off_dev, const int32_t* site_ch_dev,
@@ -131,7 +131,9 @@ struct NmsArgs {
   const float* boxes;    // [n, K, 4]
   float* stale;          // [n, K]  working scores (dead = -inf)
   int32_t* begin;        // [n, K]
-  float* tent;           // [n, K]
+  float* tent;           // [n, K]  updated score computed in epoch ev[i]
+  float* ub;             // [n, K]  upper bound of the candidate's updated score in every later epoch
+  int32_t* ev;           // [n, K]  epoch of the last evaluation (-1 = never)
   int32_t* sel_idx;      // [n, M]
   float* sel_score;      // [n, M]
   float* sel_box;        // [n, M, 4]

@@ -67,7 +67,7 @@ class ServingDriver:
                 weights = weights_mod.init_weights(self.params, seed=int(self.params.get("uda_seed", 0)))
         self.weights = weights
         if chunk_images is None:
-            chunk_images = min(self.batch_size, int(self.params.get("uda_chunk_images", 2)))
+            chunk_images = min(self.batch_size, int(self.params.get("uda_chunk_images", 16)))
         self.plan = plan_mod.Plan(self.params, weights, chunk_images=chunk_images, max_images=self.batch_size)
         self._post_mode = capi.POST_PER_CLASS if post_mode == "per_class" else capi.POST_GLOBAL
         self._lib = capi.load()

@@ -23,13 +23,13 @@ from .hparams_config import get_feat_sizes, parse_image_size
 ALIGN = 256  # floats
 
 
-def dw_tiles_x(C, Wo, stride):
+def dw_tiles_x(C, Wo, k, stride):
     """gridDim.x of the depthwise kernel (mirror of dw_geometry in csrc/kernels_conv.hip)."""
     C4 = C // 4
-    ncc = (C4 + 255) // 256
+    ncc = (C4 + 63) // 64
     t = (C4 + ncc - 1) // ncc
     p = max(1, 256 // t)
-    x = 4 if stride == 1 else 2
+    x = 1 if k == 5 else (4 if stride == 1 else 2)
     p = min(p, (Wo + x - 1) // x)
     return (Wo + p * x - 1) // (p * x)
 
@@ -37,9 +37,9 @@ def dw_tiles_x(C, Wo, stride):
 DW_ROWS = 8  # mirror of DW_ROWS in csrc/kernels_conv.hip
 
 
-def dw_tiles(C, Ho, Wo, stride):
+def dw_tiles(C, Ho, Wo, k, stride):
     """SE tile sums one depthwise launch leaves per sample row (mirror of dw_tiles in csrc)."""
-    return -(-Ho // DW_ROWS) * dw_tiles_x(C, Wo, stride)
+    return -(-Ho // DW_ROWS) * dw_tiles_x(C, Wo, k, stride)
 
 
 def same_out(n, s):
@@ -153,7 +153,7 @@ class Plan:
         if bn is not None:
             kw["bn_scale_off"], kw["bn_shift_off"] = self._bn(bn)
         if with_se:
-            kw["se_partial"] = self._buf(dw_tiles(xb.C, Ho, Wo, stride), 1, xb.C, ps, name=name + "/se_partial")
+            kw["se_partial"] = self._buf(dw_tiles(xb.C, Ho, Wo, k, stride), 1, xb.C, ps, name=name + "/se_partial")
         self._op(capi.OP_DW, [x], out, **kw)
         return out, kw.get("se_partial", -1)
 
@@ -205,7 +205,7 @@ class Plan:
             if b["se"]:
                 xb = self.bufs[x]
                 gate = self._op(capi.OP_SE, [part, x], self._buf(1, 1, xb.C, xb.per_sample, name="blocks_%d/se" % i),
-                                stride=b["stride"], se_mid=b["se"],
+                                k=b["kernel"], stride=b["stride"], se_mid=b["se"],
                                 se_w1_off=self._pack(w[p + "se/conv2d/kernel"]),
                                 se_b1_off=self._pack(w[p + "se/conv2d/bias"]),
                                 se_w2_off=self._pack(w[p + "se/conv2d_1/kernel"]),
