@@ -203,3 +203,89 @@ def test_serve_end_to_end_close_to_oracle():
         np.testing.assert_allclose(got[0][n, :k, :4], want[0][n, :k, :4], rtol=1e-3, atol=0.2)
         np.testing.assert_array_equal(got[2][n, :k, 0], want[2][n, :k, 0])
     d.close()
+
+
+TOPK = dict(nms_configs=dict(method="gaussian", iou_thresh=None, score_thresh=0.0, sigma=None, pyfunc=False,
+                             max_nms_inputs=500, max_output_size=100))
+HARD = dict(nms_configs=dict(method="hard", iou_thresh=None, score_thresh=0.0, sigma=None, pyfunc=False,
+                             max_nms_inputs=0, max_output_size=100))
+
+
+@pytest.mark.parametrize("name,over,spread", [("full_mc", FULL_MC, 20.0), ("lossatt", LOSS_ATT, 1.0), ("plain", PLAIN, 20.0),
+                                              ("topk_mc", dict(FULL_MC, **TOPK), 20.0), ("topk_plain", dict(PLAIN, **TOPK), 1.0),
+                                              ("hard", dict(HEAD_MC, **HARD), 20.0)])
+def test_per_class_postprocess_bit_exact(name, over, spread):
+    """a17 (+a10 top-k): per-class NMS, concat, pad, top-100 on the oracle's head outputs."""
+    from oracle import post_ref as P, preprocess_ref as PP
+    p = make_params(**over)
+    w = make_weights(p, seed=17, cls_spread=spread)
+    x, scales = PP.preprocess(make_images(2, 100, 180, seed=18), (128, 192), p["mean_rgb"], p["stddev_rgb"])
+    (rcls, rbox), _ = _oracle_net(p, w, x, 31)
+    want = P.postprocess_per_class(p, rcls, rbox, scales)
+    d = _driver(p, w, 2)
+    got = d.postprocess(rcls, rbox, scales, post_mode="per_class")
+    assert len(got) == 4
+    for k, (g, r) in enumerate(zip(got, want)):
+        assert g.shape == r.shape, (k, g.shape, r.shape)
+        np.testing.assert_array_equal(g, r, err_msg="output %d" % k)
+    d.close()
+
+
+@pytest.mark.parametrize("name,over", [("topk_mc", dict(FULL_MC, **TOPK)), ("topk_lossatt", dict(LOSS_ATT, **TOPK)),
+                                       ("topk_headmc", dict(HEAD_MC, **TOPK))])
+def test_topk_global_postprocess_bit_exact(name, over):
+    """a10: max_nms_inputs > 0 (the eval-time setting, eval.py:75) in global mode."""
+    from oracle import post_ref as P, preprocess_ref as PP
+    p = make_params(**over)
+    w = make_weights(p, seed=19, cls_spread=20.0)
+    x, scales = PP.preprocess(make_images(2, 100, 180, seed=20), (128, 192), p["mean_rgb"], p["stddev_rgb"])
+    (rcls, rbox), _ = _oracle_net(p, w, x, 41)
+    want = P.postprocess_global(p, rcls, rbox, scales)
+    d = _driver(p, w, 2)
+    got = d.postprocess(rcls, rbox, scales)
+    assert len(got) == len(want)
+    for k, (g, r) in enumerate(zip(got, want)):
+        assert g.shape == r.shape, (k, g.shape, r.shape)
+        np.testing.assert_array_equal(g, r, err_msg="output %d" % k)
+    d.close()
+
+
+def test_topk_kernel_orders_ties_by_index():
+    """top-k pre-selection on logits with many exact ties (random-init regime)."""
+    from oracle import post_ref as P, preprocess_ref as PP
+    p = make_params(**dict(PLAIN, **TOPK))
+    w = make_weights(p, seed=23)
+    x, scales = PP.preprocess(make_images(1, 128, 192, seed=24), (128, 192), p["mean_rgb"], p["stddev_rgb"])
+    (rcls, rbox), _ = _oracle_net(p, w, x, 0)
+    rcls = [np.round(c * 4) / 4 for c in rcls]            # quantise: thousands of exact ties
+    want = P.pre_nms(p, rcls, rbox)
+    d = _driver(p, w, 1)
+    d.postprocess(rcls, rbox, scales)
+    got = d.candidates(1)
+    np.testing.assert_array_equal(got["classes"], want["classes"])
+    np.testing.assert_array_equal(got["scores"], want["scores"])
+    np.testing.assert_array_equal(got["boxes"], want["boxes"])
+    d.close()
+
+
+def test_legacy_detection_rows():
+    """a19: generate_detections / transform_detections row formats."""
+    from oracle import post_ref as P, preprocess_ref as PP
+    from uda_amd import postprocess as legacy
+    p = make_params(**LOSS_ATT)
+    w = make_weights(p, seed=29, cls_spread=20.0)
+    x, scales = PP.preprocess(make_images(2, 100, 180, seed=30), (128, 192), p["mean_rgb"], p["stddev_rgb"])
+    (rcls, rbox), _ = _oracle_net(p, w, x, 0)
+    d = _driver(p, w, 2)
+    rows = legacy.generate_detections(d, p, rcls, rbox, scales, np.array([7, 9]), per_class_nms=True)
+    b, s, c, v = P.postprocess_per_class(p, rcls, rbox, scales)
+    assert rows.shape == (2, 100, 7)
+    np.testing.assert_array_equal(rows[..., 0], np.array([[7.0], [9.0]], np.float32) * np.ones((2, 100), np.float32))
+    np.testing.assert_array_equal(rows[..., 1:5], b[..., [1, 0, 3, 2]])
+    np.testing.assert_array_equal(rows[..., 5], s)
+    np.testing.assert_array_equal(rows[..., 6], c)
+    xywh = legacy.transform_detections(rows)
+    np.testing.assert_array_equal(xywh[..., 3], rows[..., 3] - rows[..., 1])
+    rows_g = legacy.generate_detections(d, p, rcls, rbox, scales, np.array([7, 9]), per_class_nms=False)
+    assert rows_g.shape == (2, 100, 7 + 7)
+    d.close()

@@ -325,7 +325,7 @@ constexpr int DW_ROWS = 8;  // output rows per block
 // down the DW_ROWS output rows: every input element is loaded once per block column strip
 // (instead of K times), the K*K weight quads of the block's channels sit in LDS.
 template <int K, int S, int XB>
-__global__ __launch_bounds__(256, 3) void dw_kernel(DwArgs a) {
+__global__ __launch_bounds__(256, (K == 5 && XB == 2) ? 2 : 3) void dw_kernel(DwArgs a) {
   extern __shared__ float4 dsm[];          // wts[K*K][tc] | red[blockDim]
   float4* wts = dsm;
   float4* red = dsm + K * K * a.tc;
@@ -428,7 +428,12 @@ __global__ __launch_bounds__(256, 3) void dw_kernel(DwArgs a) {
   }
 }
 
-static inline int dw_xb(int k, int stride) { return k == 5 ? 1 : (stride == 1 ? 4 : 2); }
+static inline int dw_xb5() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("UDA_DW5_XB"); v = e ? atoi(e) : 1; }
+  return v;
+}
+static inline int dw_xb(int k, int stride) { return k == 5 ? dw_xb5() : (stride == 1 ? 4 : 2); }
 
 void dw_geometry(int C, int Wo, int k, int stride, int* tc, int* pxb, int* n_cchunk, int* grid_x, int* xb) {
   const int C4 = C / 4;
@@ -464,8 +469,10 @@ void launch_dw(DwArgs a, int rows, int k, int stride, hipStream_t s) {
   const size_t lds = ((size_t)k * k * a.tc + threads) * sizeof(float4);
   if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_kernel<3, 1, 4>), grid, block, lds, s, a);
   else if (k == 3 && stride == 2) hipLaunchKernelGGL((dw_kernel<3, 2, 2>), grid, block, lds, s, a);
-  else if (k == 5 && stride == 1) hipLaunchKernelGGL((dw_kernel<5, 1, 1>), grid, block, lds, s, a);
-  else if (k == 5 && stride == 2) hipLaunchKernelGGL((dw_kernel<5, 2, 1>), grid, block, lds, s, a);
+  else if (k == 5 && stride == 1 && xb == 1) hipLaunchKernelGGL((dw_kernel<5, 1, 1>), grid, block, lds, s, a);
+  else if (k == 5 && stride == 2 && xb == 1) hipLaunchKernelGGL((dw_kernel<5, 2, 1>), grid, block, lds, s, a);
+  else if (k == 5 && stride == 1) hipLaunchKernelGGL((dw_kernel<5, 1, 2>), grid, block, lds, s, a);
+  else if (k == 5 && stride == 2) hipLaunchKernelGGL((dw_kernel<5, 2, 2>), grid, block, lds, s, a);
 }
 
 // ------------------------------------------------------------------------------------ squeeze-excite

@@ -150,17 +150,22 @@ __device__ __forceinline__ void decode_one(const AggArgs& a, const float* bp, in
 
 __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (int64_t)a.n_img * a.A_tot) return;
-  const int n = (int)(gid / a.A_tot);
-  const int ai = (int)(gid % a.A_tot);
+  if (gid >= (int64_t)a.n_img * a.K) return;
+  const int n = (int)(gid / a.K);
+  const int C = a.C;
+  int ai = (int)(gid % a.K), fixed_c = -1;
+  if (a.cand_flat) {            // top-k path: this candidate is one (anchor, class) pair
+    const int flat = a.cand_flat[gid];
+    ai = flat / C;
+    fixed_c = flat % C;
+  }
   int lvl = 0;
   while (lvl + 1 < a.lv.num_levels && ai >= a.lv.a_off[lvl + 1]) ++lvl;
   const int loc = ai - a.lv.a_off[lvl];
   const int p = loc / a.A, al = loc % a.A;
   const int hw = a.lv.hw[lvl];
-  const int C = a.C;
 
-  // ---- class logits: mean / population std over the T axis, first-max argmax
+  // ---- class logits: mean / population std over the T axis; first-max argmax or the given class
   const int cch = a.A * C;
   const float* cbase = a.lv.cls[lvl] + ((size_t)n * a.Tc * hw + p) * cch + al * C;
   const size_t cstride = (size_t)hw * cch;
@@ -169,20 +174,28 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a) {
   int best_c = 0;
   for (int c = 0; c < C; ++c) {
     float m = cbase[c];
+    float sd = 0.f;
     if (a.Tc > 1) {
       for (int t = 1; t < a.Tc; ++t) m = m + cbase[t * cstride + c];
       m = m / fT;
-      float v = 0.f;
-      for (int t = 0; t < a.Tc; ++t) {
-        const float dlt = cbase[t * cstride + c] - m;
-        v = v + dlt * dlt;
+      if (a.u_cls && (fixed_c < 0 || fixed_c == c)) {
+        float v = 0.f;
+        for (int t = 0; t < a.Tc; ++t) {
+          const float dlt = cbase[t * cstride + c] - m;
+          v = v + dlt * dlt;
+        }
+        sd = sqrtf(v / fT);
       }
-      if (a.u_cls) a.u_cls[(size_t)gid * C + c] = sqrtf(v / fT);
-    } else if (a.u_cls) {
-      a.u_cls[(size_t)gid * C + c] = 0.f;
     }
     a.logits[(size_t)gid * C + c] = m;
-    if (m > best) {
+    if (fixed_c < 0) {
+      if (a.u_cls) a.u_cls[(size_t)gid * C + c] = sd;
+      if (m > best) {
+        best = m;
+        best_c = c;
+      }
+    } else if (c == fixed_c) {
+      if (a.u_cls) a.u_cls[gid] = sd;
       best = m;
       best_c = c;
     }
@@ -234,8 +247,159 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a) {
 }
 
 void launch_aggregate(const AggArgs& a, hipStream_t s) {
-  const int64_t total = (int64_t)a.n_img * a.A_tot;
+  const int64_t total = (int64_t)a.n_img * a.K;
   hipLaunchKernelGGL(aggregate_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------ top-k pre-selection
+// postprocess.topk_class_boxes with max_nms_inputs > 0 (postprocess.py:96-121): the k largest mean
+// logits over anchors*classes.  TF leaves the order of sorted=False open; the build fixes it to
+// value descending, ties -> lower flat index, identically in oracle and kernel.
+__global__ __launch_bounds__(256) void class_mean_kernel(AggArgs a, float* out) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (n, anchor, class)
+  const int64_t per = (int64_t)a.A_tot * a.C;
+  if (gid >= (int64_t)a.n_img * per) return;
+  const int n = (int)(gid / per);
+  const int r = (int)(gid % per);
+  const int ai = r / a.C, c = r % a.C;
+  int lvl = 0;
+  while (lvl + 1 < a.lv.num_levels && ai >= a.lv.a_off[lvl + 1]) ++lvl;
+  const int loc = ai - a.lv.a_off[lvl];
+  const int p = loc / a.A, al = loc % a.A;
+  const int hw = a.lv.hw[lvl], cch = a.A * a.C;
+  const float* cbase = a.lv.cls[lvl] + ((size_t)n * a.Tc * hw + p) * cch + al * a.C + c;
+  const size_t cstride = (size_t)hw * cch;
+  float m = cbase[0];
+  if (a.Tc > 1) {
+    for (int t = 1; t < a.Tc; ++t) m = m + cbase[t * cstride];
+    m = m / (float)a.Tc;
+  }
+  out[gid] = m;
+}
+
+void launch_class_mean(const AggArgs& a, float* out, hipStream_t s) {
+  const int64_t total = (int64_t)a.n_img * a.A_tot * a.C;
+  hipLaunchKernelGGL(class_mean_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, out);
+}
+
+__device__ __forceinline__ uint32_t ord32(float v) {
+  const uint32_t b = __float_as_uint(v);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+constexpr int TOPK_THREADS = 1024;
+constexpr int TOPK_MAX = 8192;
+
+// block-wide exclusive scan of one int per thread (1024 threads); *total gets the sum
+__device__ __forceinline__ int block_excl_scan(int v, int* wsum /*[17]*/, int* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += o;
+  }
+  __syncthreads();
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int w = 0; w < TOPK_THREADS / 64; ++w) {
+      const int t = wsum[w];
+      wsum[w] = run;
+      run += t;
+    }
+    wsum[16] = run;
+  }
+  __syncthreads();
+  *total = wsum[16];
+  return wsum[wave] + incl - v;
+}
+
+// radix-select step: among elements whose key matches `prefix` on the bits above `shift+bits`,
+// histogram the next `bits` bits; pick the bin (from the top) where the running count reaches `need`.
+__device__ __forceinline__ void topk_select_digit(const float* v, int L, uint32_t prefix, int hi_shift, int shift,
+                                                  int bits, unsigned* hist, int* need, uint32_t* out_prefix) {
+  const int nb = 1 << bits;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < L; i += blockDim.x) {
+    const uint32_t key = ord32(v[i]);
+    if (hi_shift >= 32 || (key >> hi_shift) == prefix) atomicAdd(&hist[(key >> shift) & (nb - 1)], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int rem = *need;
+    int b = nb - 1;
+    for (; b > 0; --b) {
+      if ((int)hist[b] >= rem) break;
+      rem -= (int)hist[b];
+    }
+    *need = rem;                                   // still to take inside bin b
+    *out_prefix = (hi_shift >= 32 ? 0u : (prefix << bits)) | (uint32_t)b;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* vals, int L, int k, int32_t* out_idx) {
+  __shared__ unsigned long long keys[TOPK_MAX];
+  __shared__ unsigned hist[2048];
+  __shared__ int wsum[17];
+  __shared__ int need;
+  __shared__ uint32_t prefix;
+  __shared__ int n_gt, n_eq_taken;
+  const float* v = vals + (size_t)blockIdx.x * L;
+  int32_t* out = out_idx + (size_t)blockIdx.x * k;
+  if (threadIdx.x == 0) { need = k; prefix = 0; n_gt = 0; n_eq_taken = 0; }
+  __syncthreads();
+  topk_select_digit(v, L, 0u, 32, 21, 11, hist, &need, &prefix);
+  topk_select_digit(v, L, prefix, 21, 10, 11, hist, &need, &prefix);
+  topk_select_digit(v, L, prefix, 10, 0, 10, hist, &need, &prefix);
+  const uint32_t T = prefix;            // key of the k-th largest value; `need` of the elements equal to it are taken
+  const int take_eq = need;
+  int P = 1;
+  while (P < k) P <<= 1;
+  for (int i = threadIdx.x; i < P; i += blockDim.x) keys[i] = 0ull;
+  __syncthreads();
+  // collect in index order: everything above T, and the first `take_eq` elements equal to T
+  for (int base = 0; base < L; base += TOPK_THREADS) {
+    const int i = base + threadIdx.x;
+    uint32_t key = 0;
+    int gt = 0, eq = 0;
+    if (i < L) {
+      key = ord32(v[i]);
+      gt = key > T;
+      eq = key == T;
+    }
+    int tot_gt, tot_eq;
+    const int pg = block_excl_scan(gt, wsum, &tot_gt);
+    const int pe = block_excl_scan(eq, wsum, &tot_eq);
+    const int base_gt = n_gt, base_eq = n_eq_taken;
+    const unsigned long long full = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+    if (gt) keys[base_gt + pg] = full;
+    if (eq && base_eq + pe < take_eq) keys[(k - take_eq) + base_eq + pe] = full;
+    __syncthreads();
+    if (threadIdx.x == 0) { n_gt = base_gt + tot_gt; n_eq_taken = min(take_eq, base_eq + tot_eq); }
+    __syncthreads();
+  }
+  // bitonic sort, descending (padding keys are 0 = smallest)
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < P / 2; t += blockDim.x) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long x = keys[lo], y = keys[hi];
+        if ((x < y) == desc) { keys[lo] = y; keys[hi] = x; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int j = threadIdx.x; j < k; j += blockDim.x) out[j] = (int32_t)(0xFFFFFFFFu - (uint32_t)keys[j]);
+}
+
+void launch_topk(const float* vals, int n_img, int L, int k, int32_t* out_idx, hipStream_t s) {
+  hipLaunchKernelGGL(topk_kernel, dim3(n_img), dim3(TOPK_THREADS), 0, s, vals, L, k, out_idx);
 }
 
 // ------------------------------------------------------------------------------------ NMS (NonMaxSuppressionV5)
@@ -290,7 +454,8 @@ __device__ __forceinline__ void nms_load_sel(const NmsArgs& a, NmsLds& L, int n,
 __device__ __forceinline__ float nms_chain_eval(const NmsArgs& a, const NmsLds& L, size_t base, int i, int k) {
   float score = a.stale[base + i];
   const int begin = a.begin[base + i];
-  const float4 b4 = *(const float4*)(a.boxes + (base + i) * 4);
+  const size_t bbase = (size_t)(blockIdx.y / a.segs) * a.K;   // boxes are per image, state per problem
+  const float4 b4 = *(const float4*)(a.boxes + (bbase + i) * 4);
   const float bx[4] = {b4.x, b4.y, b4.z, b4.w};
   for (int j = k - 1; j >= begin; --j) {
     const float sim = nms_iou(bx, L.sel + 4 * j);
@@ -350,8 +515,11 @@ __global__ __launch_bounds__(256) void nms_init_kernel(NmsArgs a, const float* s
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)a.n_img * a.K;
   if (gid < total) {
-    const float s = scores[gid];
-    const float v = (s > a.score_thr) ? s : -INFINITY;
+    const int seg = (int)(gid / a.K), i = (int)(gid % a.K);
+    const size_t src = (size_t)(seg / a.segs) * a.K + i;
+    const float s = scores[src];
+    const bool member = (a.segs == 1) || (a.classes[src] == seg % a.segs);
+    const float v = (member && s > a.score_thr) ? s : -INFINITY;
     a.stale[gid] = v;
     a.ub[gid] = v;
     a.ev[gid] = -1;
@@ -471,7 +639,7 @@ __global__ __launch_bounds__(256) void nms_commit_kernel(NmsArgs a, int k) {
       const size_t o = (size_t)n * a.M + k;
       a.sel_idx[o] = i;
       a.sel_score[o] = a.tent[base + i];
-      const float* bx = a.boxes + (base + i) * 4;
+      const float* bx = a.boxes + ((size_t)(n / a.segs) * a.K + i) * 4;
       a.sel_box[o * 4 + 0] = bx[0];
       a.sel_box[o * 4 + 1] = bx[1];
       a.sel_box[o * 4 + 2] = bx[2];
@@ -528,9 +696,86 @@ __global__ __launch_bounds__(128) void gather_kernel(GatherArgs a) {
   float* oc = a.out_classes + (size_t)gid * a.cls_cols;
   oc[0] = (float)(a.classes[src] + 1);
   if (a.u_cls)
-    for (int c = 0; c < a.C; ++c) oc[1 + c] = a.u_cls[src * a.C + c];
+    for (int c = 0; c < a.ucls_cols; ++c) oc[1 + c] = a.u_cls[src * a.ucls_cols + c];
   if (a.out_logits)
     for (int c = 0; c < a.C; ++c) a.out_logits[(size_t)gid * a.C + c] = a.logits[src * a.C + c];
+}
+
+// per-class mode (postprocess.per_class_nms, :676-698): concatenate the per-class selections in
+// class order, append M zero rows, take the top M by score (ties -> lower position), scale; no clip.
+__global__ __launch_bounds__(256) void merge_per_class_kernel(MergeArgs a) {
+  __shared__ unsigned long long wbest[4];
+  __shared__ int offs[130];
+  const int n = blockIdx.x;
+  const int E_max = a.C * a.M + a.M;
+  unsigned long long* keys = a.keys + (size_t)n * E_max;
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int c = 0; c < a.C; ++c) {
+      if (c < 128) offs[c] = run;
+      run += a.nsel[(size_t)n * a.C + c];
+    }
+    offs[128] = run;                         // number of real detections
+  }
+  __syncthreads();
+  const int total_valid = offs[128];
+  const int E = total_valid + a.M;
+  // position e of entry (class c, rank j) in the concatenation; key = (score, earlier position first)
+  for (int c = 0; c < a.C; ++c) {
+    const size_t seg = (size_t)n * a.C + c;
+    int start = 0;
+    for (int cc = 0; cc < c; ++cc) start += a.nsel[(size_t)n * a.C + cc];
+    for (int j = threadIdx.x; j < a.nsel[seg]; j += blockDim.x) {
+      const int e = start + j;
+      keys[e] = ((unsigned long long)ord32(a.sel_score[seg * a.M + j]) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)e);
+    }
+  }
+  for (int j = threadIdx.x; j < a.M; j += blockDim.x) {
+    const int e = total_valid + j;
+    keys[e] = ((unsigned long long)ord32(0.0f) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)e);
+  }
+  __syncthreads();
+  const float sc = a.scales ? a.scales[n] : 1.0f;
+  for (int r = 0; r < a.M; ++r) {
+    unsigned long long best = 0ull;
+    for (int e = threadIdx.x; e < E; e += blockDim.x) best = keys[e] > best ? keys[e] : best;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned long long o = __shfl_xor(best, off, 64);
+      best = o > best ? o : best;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = best;
+    __syncthreads();
+    best = wbest[0];
+    for (int w = 1; w < 4; ++w) best = wbest[w] > best ? wbest[w] : best;
+    const int e = (int)(0xFFFFFFFFu - (uint32_t)best);
+    if (threadIdx.x == 0) {
+      keys[e] = 0ull;                                   // taken
+      const size_t o = (size_t)n * a.M + r;
+      if (e < total_valid) {
+        int c = 0, start = 0;
+        while (c + 1 < a.C && e >= start + a.nsel[(size_t)n * a.C + c]) { start += a.nsel[(size_t)n * a.C + c]; ++c; }
+        const size_t seg = (size_t)n * a.C + c;
+        const int j = e - start;
+        const int idx = a.sel_idx[seg * a.M + j];
+        const float* bx = a.boxes + ((size_t)n * a.K + idx) * 4;
+        for (int q = 0; q < 4; ++q) a.out_boxes[o * 4 + q] = a.scales ? bx[q] * sc : bx[q];
+        a.out_scores[o] = a.sel_score[seg * a.M + j];
+        a.out_classes[o] = (float)(c + 1);
+      } else {
+        for (int q = 0; q < 4; ++q) a.out_boxes[o * 4 + q] = a.scales ? 0.0f * sc : 0.0f;
+        a.out_scores[o] = 0.0f;
+        a.out_classes[o] = 0.0f;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) a.out_valid[n] = total_valid < a.M ? total_valid : a.M;
+}
+
+void launch_merge_per_class(const MergeArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(merge_per_class_kernel, dim3(a.n_img), dim3(256), 0, s, a);
 }
 
 void launch_gather(const GatherArgs& a, hipStream_t s) {

@@ -69,10 +69,17 @@ struct uda_ctx {
   float *d_cboxes = nullptr, *d_cscores = nullptr, *d_clogits = nullptr;
   int32_t* d_cclasses = nullptr;
   float *d_ucls = nullptr, *d_ual = nullptr, *d_uep = nullptr;
-  // nms workspace
-  float *d_stale = nullptr, *d_tent = nullptr, *d_ub = nullptr, *d_sel_score = nullptr, *d_sel_box = nullptr;
-  int32_t *d_ev = nullptr, *d_begin = nullptr, *d_sel_idx = nullptr, *d_nsel = nullptr, *d_done = nullptr;
-  unsigned long long *d_bound = nullptr, *d_win = nullptr;
+  int Kc = 0;                  // candidates per image: A_tot, or max_nms_inputs on the top-k path
+  float* d_clsmean = nullptr;  // [max_images, A_tot*C]  (top-k path)
+  int32_t* d_cand_flat = nullptr;  // [max_images, Kc]   (top-k path)
+  // nms workspaces: [0] global mode (one problem per image), [1] per-class mode (images*classes problems)
+  struct NmsWs {
+    float *stale = nullptr, *tent = nullptr, *ub = nullptr, *sel_score = nullptr, *sel_box = nullptr;
+    int32_t *ev = nullptr, *begin = nullptr, *sel_idx = nullptr, *nsel = nullptr, *done = nullptr;
+    unsigned long long *bound = nullptr, *win = nullptr;
+    bool ready = false;
+  } ws[2];
+  unsigned long long* d_merge_keys = nullptr;
   // outputs
   float *d_oboxes = nullptr, *d_oscores = nullptr, *d_oclasses = nullptr, *d_ologits = nullptr;
   int32_t* d_ovalid = nullptr;
@@ -161,11 +168,15 @@ extern "C" void uda_destroy(uda_ctx_t* c) {
   for (int k = 0; k < 32; ++k) prof_collect(c, k);
   void* ptrs[] = {c->d_weights, c->d_arena, c->d_anchors, c->d_u8, c->d_images, c->d_scales, c->d_masks,
                   c->d_site_off, c->d_site_ch, c->d_site_rate, c->d_cboxes, c->d_cscores, c->d_clogits,
-                  c->d_cclasses, c->d_ucls, c->d_ual, c->d_uep, c->d_stale, c->d_tent, c->d_ub, c->d_ev, c->d_sel_score,
-                  c->d_sel_box, c->d_begin, c->d_sel_idx, c->d_nsel, c->d_done, c->d_bound, c->d_win,
+                  c->d_cclasses, c->d_ucls, c->d_ual, c->d_uep, c->d_clsmean, c->d_cand_flat, c->d_merge_keys,
                   c->d_oboxes, c->d_oscores, c->d_oclasses, c->d_ologits, c->d_ovalid};
   for (void* p : ptrs)
     if (p) hipFree(p);
+  for (auto& w : c->ws) {
+    void* wp[] = {w.stale, w.tent, w.ub, w.sel_score, w.sel_box, w.ev, w.begin, w.sel_idx, w.nsel, w.done, w.bound, w.win};
+    for (void* p : wp)
+      if (p) hipFree(p);
+  }
   for (int l = 0; l < UDA_MAX_LEVELS; ++l) {
     if (c->d_cls[l]) hipFree(c->d_cls[l]);
     if (c->d_box[l]) hipFree(c->d_box[l]);
@@ -183,7 +194,21 @@ static int box_cols_of(const uda_model_t& m, int post_mode) {
 }
 static int cls_cols_of(const uda_model_t& m, int post_mode) {
   if (post_mode == UDA_POST_PER_CLASS) return 1;
-  return 1 + ((m.has_uncert && m.cls_stacked) ? m.num_classes : 0);
+  // top-k path gathers ONE class-std value per (anchor, class) candidate (postprocess.py:117-121)
+  return 1 + ((m.has_uncert && m.cls_stacked) ? (m.max_nms_inputs > 0 ? 1 : m.num_classes) : 0);
+}
+
+static hipError_t alloc_nms_ws(uda_ctx::NmsWs& w, size_t problems, size_t K, size_t M) {
+  if (w.ready) return hipSuccess;
+  hipError_t e;
+#define WS(ptr, n) if ((e = dalloc(&ptr, (n))) != hipSuccess) return e
+  WS(w.stale, problems * K); WS(w.tent, problems * K); WS(w.ub, problems * K); WS(w.ev, problems * K);
+  WS(w.begin, problems * K); WS(w.sel_idx, problems * M); WS(w.sel_score, problems * M);
+  WS(w.sel_box, problems * M * 4); WS(w.bound, problems * M); WS(w.win, problems * M);
+  WS(w.nsel, problems); WS(w.done, problems);
+#undef WS
+  w.ready = true;
+  return hipSuccess;
 }
 
 extern "C" int uda_detection_cols(const uda_ctx_t* c, int32_t post_mode, int32_t* box_cols, int32_t* cls_cols) {
@@ -320,7 +345,20 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
   }
 
   // candidates + nms + outputs
-  const size_t K = (size_t)c->A_tot, M = (size_t)m.max_output_size, C = (size_t)m.num_classes;
+  if (m.max_nms_inputs > 0) {
+    if (m.max_nms_inputs > 8192 || (int64_t)m.max_nms_inputs > (int64_t)c->A_tot * m.num_classes) {
+      fail(nullptr, "uda_create: max_nms_inputs %d must be <= min(8192, anchors*classes = %lld)", m.max_nms_inputs,
+           (long long)c->A_tot * m.num_classes);
+      uda_destroy(c);
+      return 1;
+    }
+    c->Kc = m.max_nms_inputs;
+    CK(dalloc(&c->d_clsmean, N * (size_t)c->A_tot * m.num_classes));
+    CK(dalloc(&c->d_cand_flat, N * (size_t)c->Kc));
+  } else {
+    c->Kc = c->A_tot;
+  }
+  const size_t K = (size_t)c->Kc, M = (size_t)m.max_output_size, C = (size_t)m.num_classes;
   CK(dalloc(&c->d_cboxes, N * K * 4));
   CK(dalloc(&c->d_cscores, N * K));
   CK(dalloc(&c->d_cclasses, N * K));
@@ -328,18 +366,7 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
   if (m.has_uncert && m.cls_stacked) CK(dalloc(&c->d_ucls, N * K * C));
   if (m.has_uncert && m.loss_attenuation) CK(dalloc(&c->d_ual, N * K * 4));
   if (m.has_uncert && m.box_stacked) CK(dalloc(&c->d_uep, N * K * 4));
-  CK(dalloc(&c->d_stale, N * K));
-  CK(dalloc(&c->d_tent, N * K));
-  CK(dalloc(&c->d_ub, N * K));
-  CK(dalloc(&c->d_ev, N * K));
-  CK(dalloc(&c->d_begin, N * K));
-  CK(dalloc(&c->d_sel_idx, N * M));
-  CK(dalloc(&c->d_sel_score, N * M));
-  CK(dalloc(&c->d_sel_box, N * M * 4));
-  CK(dalloc(&c->d_bound, N * M));
-  CK(dalloc(&c->d_win, N * M));
-  CK(dalloc(&c->d_nsel, N));
-  CK(dalloc(&c->d_done, N));
+  CK(alloc_nms_ws(c->ws[0], N, K, M));
   CK(dalloc(&c->d_oboxes, N * M * 12));
   CK(dalloc(&c->d_oscores, N * M));
   CK(dalloc(&c->d_oclasses, N * M * (1 + C)));
@@ -636,13 +663,14 @@ static int run_network(uda_ctx* c) {
 }
 
 // ------------------------------------------------------------------------------------ post-process
-static NmsArgs nms_args_of(uda_ctx* c, int n, int K, int M, const float* boxes) {
+static NmsArgs nms_args_of(uda_ctx::NmsWs& w, int problems, int K, int M, const float* boxes) {
   NmsArgs a{};
   a.boxes = boxes;
-  a.stale = c->d_stale; a.begin = c->d_begin; a.tent = c->d_tent; a.ub = c->d_ub; a.ev = c->d_ev;
-  a.sel_idx = c->d_sel_idx; a.sel_score = c->d_sel_score; a.sel_box = c->d_sel_box;
-  a.bound_key = c->d_bound; a.win_key = c->d_win; a.nsel = c->d_nsel; a.done = c->d_done;
-  a.n_img = n; a.K = K; a.M = M;
+  a.stale = w.stale; a.begin = w.begin; a.tent = w.tent; a.ub = w.ub; a.ev = w.ev;
+  a.sel_idx = w.sel_idx; a.sel_score = w.sel_score; a.sel_box = w.sel_box;
+  a.bound_key = w.bound; a.win_key = w.win; a.nsel = w.nsel; a.done = w.done;
+  a.n_img = problems; a.K = K; a.M = M;
+  a.segs = 1; a.classes = nullptr;
   return a;
 }
 
@@ -653,40 +681,52 @@ static void nms_params(NmsArgs& a, float iou_thr, float score_thr, float soft_si
   a.scale = a.soft ? -0.5f / soft_sigma : 0.0f;
 }
 
+// a8-a14: class statistics, (top-k pre-selection), per-sample decode and MC aggregation -> candidates
+static int run_candidates(uda_ctx* c, int n) {
+  const uda_model_t& m = c->model;
+  ProfScope ps(c, 16);
+  AggArgs a{};
+  a.lv.num_levels = m.num_levels;
+  for (int l = 0; l < m.num_levels; ++l) {
+    a.lv.hw[l] = m.level_h[l] * m.level_w[l];
+    a.lv.a_off[l] = c->a_off[l];
+    a.lv.cls[l] = c->d_cls[l];
+    a.lv.box[l] = c->d_box[l];
+  }
+  a.lv.a_off[m.num_levels] = c->A_tot;
+  a.anchors = c->d_anchors;
+  a.n_img = n; a.A_tot = c->A_tot; a.A = m.anchors_per_loc; a.C = m.num_classes;
+  a.K = c->Kc;
+  a.Tc = m.cls_stacked ? m.mc_samples : 1;
+  a.Tb = m.box_stacked ? m.mc_samples : 1;
+  a.loss_att = m.loss_attenuation;
+  a.decode = m.decode_method;
+  a.boxes = c->d_cboxes; a.scores = c->d_cscores; a.classes = c->d_cclasses; a.logits = c->d_clogits;
+  a.u_cls = c->d_ucls; a.u_al = c->d_ual; a.u_ep = c->d_uep;
+  a.cand_flat = nullptr;
+  if (m.max_nms_inputs > 0) {
+    launch_class_mean(a, c->d_clsmean, c->stream);
+    launch_topk(c->d_clsmean, n, c->A_tot * m.num_classes, c->Kc, c->d_cand_flat, c->stream);
+    a.cand_flat = c->d_cand_flat;
+  }
+  launch_aggregate(a, c->stream);
+  return 0;
+}
+
 static int run_post_global(uda_ctx* c, int n) {
   const uda_model_t& m = c->model;
-  if (m.max_nms_inputs > 0) return fail(c, "max_nms_inputs > 0 (top-k pre-selection) is not built yet");
-  {
-    ProfScope ps(c, 16);
-    AggArgs a{};
-    a.lv.num_levels = m.num_levels;
-    for (int l = 0; l < m.num_levels; ++l) {
-      a.lv.hw[l] = m.level_h[l] * m.level_w[l];
-      a.lv.a_off[l] = c->a_off[l];
-      a.lv.cls[l] = c->d_cls[l];
-      a.lv.box[l] = c->d_box[l];
-    }
-    a.lv.a_off[m.num_levels] = c->A_tot;
-    a.anchors = c->d_anchors;
-    a.n_img = n; a.A_tot = c->A_tot; a.A = m.anchors_per_loc; a.C = m.num_classes;
-    a.Tc = m.cls_stacked ? m.mc_samples : 1;
-    a.Tb = m.box_stacked ? m.mc_samples : 1;
-    a.loss_att = m.loss_attenuation;
-    a.decode = m.decode_method;
-    a.boxes = c->d_cboxes; a.scores = c->d_cscores; a.classes = c->d_cclasses; a.logits = c->d_clogits;
-    a.u_cls = c->d_ucls; a.u_al = c->d_ual; a.u_ep = c->d_uep;
-    launch_aggregate(a, c->stream);
-  }
-  const int K = c->A_tot, M = m.max_output_size;
+  int rc = run_candidates(c, n);
+  if (rc) return rc;
+  const int K = c->Kc, M = m.max_output_size;
   {
     ProfScope ps(c, 17);
-    NmsArgs na = nms_args_of(c, n, K, M, c->d_cboxes);
+    NmsArgs na = nms_args_of(c->ws[0], n, K, M, c->d_cboxes);
     nms_params(na, m.nms_iou_thresh, m.nms_score_thresh, m.nms_soft_sigma);
     launch_nms_init(na, c->d_cscores, c->stream);
     for (int k = 0; k < M; ++k) launch_nms_epoch(na, k, c->stream);
   }
   GatherArgs g{};
-  g.sel_idx = c->d_sel_idx; g.sel_score = c->d_sel_score; g.nsel = c->d_nsel;
+  g.sel_idx = c->ws[0].sel_idx; g.sel_score = c->ws[0].sel_score; g.nsel = c->ws[0].nsel;
   g.boxes = c->d_cboxes; g.classes = c->d_cclasses; g.logits = c->d_clogits;
   g.u_cls = c->d_ucls; g.u_al = c->d_ual; g.u_ep = c->d_uep;
   g.scales = c->d_scales;
@@ -695,6 +735,7 @@ static int run_post_global(uda_ctx* c, int n) {
   g.n_img = n; g.K = K; g.M = M; g.C = m.num_classes;
   g.box_cols = box_cols_of(m, UDA_POST_GLOBAL);
   g.cls_cols = cls_cols_of(m, UDA_POST_GLOBAL);
+  g.ucls_cols = g.cls_cols - 1;
   g.clip_h = (float)m.image_h; g.clip_w = (float)m.image_w; g.clip = 1;
   launch_gather(g, c->stream);
   HIPC(c, hipGetLastError());
@@ -703,10 +744,41 @@ static int run_post_global(uda_ctx* c, int n) {
   return 0;
 }
 
+// a17: one NMS problem per (image, class), then concat / pad / top-M (postprocess.py:624-740)
+static int run_post_per_class(uda_ctx* c, int n) {
+  const uda_model_t& m = c->model;
+  int rc = run_candidates(c, n);
+  if (rc) return rc;
+  const int K = c->Kc, M = m.max_output_size, C = m.num_classes;
+  const size_t N = (size_t)m.max_images;
+  HIPC(c, alloc_nms_ws(c->ws[1], N * C, (size_t)K, (size_t)M));
+  if (!c->d_merge_keys) HIPC(c, dalloc(&c->d_merge_keys, N * ((size_t)C * M + M)));
+  {
+    ProfScope ps(c, 17);
+    NmsArgs na = nms_args_of(c->ws[1], n * C, K, M, c->d_cboxes);
+    na.segs = C;
+    na.classes = c->d_cclasses;
+    nms_params(na, m.nms_iou_thresh, m.nms_score_thresh, m.nms_soft_sigma);
+    launch_nms_init(na, c->d_cscores, c->stream);
+    for (int k = 0; k < M; ++k) launch_nms_epoch(na, k, c->stream);
+  }
+  MergeArgs g{};
+  g.sel_idx = c->ws[1].sel_idx; g.sel_score = c->ws[1].sel_score; g.nsel = c->ws[1].nsel;
+  g.boxes = c->d_cboxes; g.scales = c->d_scales; g.keys = c->d_merge_keys;
+  g.out_boxes = c->d_oboxes; g.out_scores = c->d_oscores; g.out_classes = c->d_oclasses; g.out_valid = c->d_ovalid;
+  g.n_img = n; g.K = K; g.M = M; g.C = C;
+  launch_merge_per_class(g, c->stream);
+  HIPC(c, hipGetLastError());
+  c->last_post_mode = UDA_POST_PER_CLASS;
+  c->last_n = n;
+  return 0;
+}
+
 static int run_post(uda_ctx* c, int n, int post_mode) {
   const int pm = post_mode < 0 ? c->model.post_mode : post_mode;
   if (pm == UDA_POST_GLOBAL) return run_post_global(c, n);
-  return fail(c, "post mode %d (per-class NMS) is not built yet", pm);
+  if (pm == UDA_POST_PER_CLASS) return run_post_per_class(c, n);
+  return fail(c, "unknown post mode %d", pm);
 }
 
 extern "C" int uda_run(uda_ctx_t* c, int32_t post_mode, int32_t do_post) {
@@ -737,7 +809,8 @@ extern "C" int uda_get_detections(uda_ctx_t* c, float* boxes, float* scores, flo
   if (scores) HIPC(c, hipMemcpy(scores, c->d_oscores, n * M * sizeof(float), hipMemcpyDeviceToHost));
   if (classes) HIPC(c, hipMemcpy(classes, c->d_oclasses, n * M * cc * sizeof(float), hipMemcpyDeviceToHost));
   if (valid) HIPC(c, hipMemcpy(valid, c->d_ovalid, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (logits) HIPC(c, hipMemcpy(logits, c->d_ologits, n * M * C * sizeof(float), hipMemcpyDeviceToHost));
+  if (logits && c->last_post_mode == UDA_POST_GLOBAL)
+    HIPC(c, hipMemcpy(logits, c->d_ologits, n * M * C * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -814,14 +887,14 @@ extern "C" int uda_predict(uda_ctx_t* c, const float* images, int32_t n) {
   return uda_synchronize(c);
 }
 
-extern "C" int32_t uda_num_candidates(const uda_ctx_t* c) { return c ? c->A_tot : 0; }
+extern "C" int32_t uda_num_candidates(const uda_ctx_t* c) { return c ? c->Kc : 0; }
 
 extern "C" int uda_get_candidates(uda_ctx_t* c, float* boxes, float* scores, int32_t* classes,
                                   float* u_cls, float* u_al, float* u_ep) {
   if (!c) return 1;
   HIPC(c, hipSetDevice(c->device));
   HIPC(c, hipStreamSynchronize(c->stream));
-  const size_t n = c->last_n, K = c->A_tot, C = c->model.num_classes;
+  const size_t n = c->last_n, K = c->Kc, C = c->model.max_nms_inputs > 0 ? 1 : c->model.num_classes;
   if (boxes) HIPC(c, hipMemcpy(boxes, c->d_cboxes, n * K * 4 * sizeof(float), hipMemcpyDeviceToHost));
   if (scores) HIPC(c, hipMemcpy(scores, c->d_cscores, n * K * sizeof(float), hipMemcpyDeviceToHost));
   if (classes) HIPC(c, hipMemcpy(classes, c->d_cclasses, n * K * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -878,6 +951,7 @@ extern "C" int uda_nms(uda_ctx_t* c, const float* boxes, const float* scores, in
   a.boxes = d_boxes; a.stale = d_stale; a.begin = d_begin; a.tent = d_tent; a.ub = d_ub; a.ev = d_ev;
   a.sel_idx = d_si; a.sel_score = d_ss; a.sel_box = d_sb; a.bound_key = d_bound; a.win_key = d_win;
   a.nsel = d_nsel; a.done = d_done; a.n_img = n_img; a.K = k; a.M = max_out;
+  a.segs = 1; a.classes = nullptr;
   nms_params(a, iou_thresh, score_thresh, soft_sigma);
   launch_nms_init(a, d_scores, c->stream);
   if (k > 0)

@@ -105,6 +105,8 @@ struct AggArgs {
   LevelTable lv;
   const float* anchors;  // [A_tot, 4]
   int n_img, A_tot, A, C;
+  int K;                 // candidates per image: A_tot (argmax path) or max_nms_inputs (top-k path)
+  const int32_t* cand_flat;  // [n, K] flat (anchor*C + class) indices of the top-k path, or null
   int Tc, Tb;            // samples carried by the class / box head outputs (1 = not stacked)
   int loss_att;
   int decode;            // uda_decode
@@ -112,11 +114,15 @@ struct AggArgs {
   float* scores;         // [n, A_tot]
   int32_t* classes;      // [n, A_tot]
   float* logits;         // [n, A_tot, C]  mean logits
-  float* u_cls;          // [n, A_tot, C] or null
+  float* u_cls;          // [n, K, C] (argmax path) / [n, K, 1] (top-k path) or null
   float* u_al;           // [n, A_tot, 4] or null
   float* u_ep;           // [n, A_tot, 4] or null
 };
 void launch_aggregate(const AggArgs& a, hipStream_t s);
+// mean logits of every (anchor, class): out [n, A_tot*C]   (input of the top-k pre-selection)
+void launch_class_mean(const AggArgs& a, float* out, hipStream_t s);
+// per image: the k largest of vals[n][0..L) -> flat indices, value descending, ties -> lower index
+void launch_topk(const float* vals, int n_img, int L, int k, int32_t* out_idx, hipStream_t s);
 
 struct PreprocArgs {
   const uint8_t* in;   // [n, h, w, 3]
@@ -141,9 +147,11 @@ struct NmsArgs {
   unsigned long long* win_key;    // [n, M]
   int32_t* nsel;         // [n]
   int32_t* done;         // [n]
-  int n_img, K, M;
+  int n_img, K, M;       // n_img = number of NMS problems (images, or images*classes in per-class mode)
   float iou_thr, score_thr, scale;  // scale = soft ? -0.5/sigma : 0
   int soft;
+  int segs;              // problems per image: 1 (global) or num_classes (per-class mode)
+  const int32_t* classes;  // [images, K] candidate classes (per-class mode) or null
 };
 void launch_nms_init(const NmsArgs& a, const float* scores, hipStream_t s);
 void launch_nms_epoch(const NmsArgs& a, int epoch, hipStream_t s);
@@ -166,9 +174,25 @@ struct GatherArgs {
   int32_t* out_valid;       // [n]
   float* out_logits;        // [n, M, C] or null
   int n_img, K, M, C, box_cols, cls_cols;
+  int ucls_cols;            // class-std values per candidate: C (argmax path) or 1 (top-k path)
   float clip_h, clip_w;
   int clip;
 };
 void launch_gather(const GatherArgs& a, hipStream_t s);
+
+struct MergeArgs {         // per-class mode: concat per-class selections, pad, top-M by score
+  const int32_t* sel_idx;  // [images*C, M]
+  const float* sel_score;  // [images*C, M]
+  const int32_t* nsel;     // [images*C]
+  const float* boxes;      // [images, K, 4]
+  const float* scales;     // [images] or null
+  unsigned long long* keys;  // workspace [images, C*M + M]
+  float* out_boxes;        // [images, M, 4]
+  float* out_scores;       // [images, M]
+  float* out_classes;      // [images, M]
+  int32_t* out_valid;      // [images]
+  int n_img, K, M, C;
+};
+void launch_merge_per_class(const MergeArgs& a, hipStream_t s);
 
 }  // namespace uda

@@ -141,14 +141,25 @@ class ServingDriver:
             raise ValueError("batch of %d images exceeds batch_size=%d" % (a.shape[0], self.batch_size))
         return np.ascontiguousarray(a)
 
-    def _collect(self, n):
+    def _mode(self, post_mode):
+        if post_mode is None:
+            return self._post_mode
+        if post_mode in ("global", capi.POST_GLOBAL):
+            return capi.POST_GLOBAL
+        if post_mode in ("per_class", capi.POST_PER_CLASS):
+            return capi.POST_PER_CLASS
+        raise ValueError("Unsupported postprocess mode {}".format(post_mode))
+
+    def _collect(self, n, mode=None):
+        mode = self._post_mode if mode is None else mode
         bc, cc = C.c_int32(), C.c_int32()
-        self._ck(self._lib.uda_detection_cols(self._h, -1, C.byref(bc), C.byref(cc)), "uda_detection_cols")
+        self._ck(self._lib.uda_detection_cols(self._h, mode, C.byref(bc), C.byref(cc)), "uda_detection_cols")
         boxes = np.empty((n, self.M, bc.value), np.float32)
         scores = np.empty((n, self.M), np.float32)
         classes = np.empty((n, self.M, cc.value), np.float32)
         valid = np.empty((n,), np.int32)
-        logits = np.empty((n, self.M, self.num_classes), np.float32) if self.params["enable_softmax"] else None
+        with_logits = self.params["enable_softmax"] and mode == capi.POST_GLOBAL
+        logits = np.empty((n, self.M, self.num_classes), np.float32) if with_logits else None
         self._ck(self._lib.uda_get_detections(self._h, _ptr(boxes), _ptr(scores), _ptr(classes), _ptr(valid),
                                               _ptr(logits)), "uda_get_detections")
         if cc.value == 1:
@@ -169,14 +180,20 @@ class ServingDriver:
             out.append(np.zeros((0, self.M, self.num_classes), np.float32))
         return tuple(out)
 
-    def serve(self, image_arrays):
-        """uint8 [N,h,w,3] -> (boxes, scores, classes, valid_len[, logits])."""
+    def serve(self, image_arrays, post_mode=None):
+        """uint8 [N,h,w,3] -> (boxes, scores, classes, valid_len[, logits]).
+
+        post_mode None = the driver's default ("global", as `EfficientDetModel.call`); "per_class"
+        gives `postprocess_per_class` (boxes [N,M,4], scores, classes [N,M], valid_len): the
+        uncertainty columns are dropped there by the reference (postprocess.py:737) and its logits
+        output in that mode is corrupted by a variable overwrite (:659-666), so none is returned."""
+        mode = self._mode(post_mode)
         a = self._as_u8_batch(image_arrays)
         n, h, w = a.shape[:3]
         self._next_seed()
         self._ck(self._lib.uda_set_images_u8(self._h, _ptr(a), n, h, w), "uda_set_images_u8")
-        self._ck(self._lib.uda_run(self._h, -1, 1), "uda_run")
-        return self._collect(n)
+        self._ck(self._lib.uda_run(self._h, mode, 1), "uda_run")
+        return self._collect(n, mode)
 
     def predict(self, image_arrays):
         """only_network: float32 [N,H,W,3] -> (cls_outputs[levels], box_outputs[levels]) with the
@@ -212,8 +229,10 @@ class ServingDriver:
             box_out.append(b if p.box_stacked else b[0])
         return cls_out, box_out
 
-    def postprocess(self, cls_outputs, box_outputs, image_scales=None):
-        """`ServingDriver._postprocess` = postprocess_global on given head outputs (infer_lib.py:263-267)."""
+    def postprocess(self, cls_outputs, box_outputs, image_scales=None, post_mode=None):
+        """`ServingDriver._postprocess` = postprocess_global on given head outputs (infer_lib.py:263-267);
+        post_mode="per_class" = postprocess_per_class (eval.py:117-123 via generate_detections)."""
+        mode = self._mode(post_mode)
         p = self.plan
         n = cls_outputs[0].shape[-4]
         for lvl in range(len(p.level_hw)):
@@ -225,8 +244,8 @@ class ServingDriver:
                 b = b[None]
             self._ck(self._lib.uda_set_head_outputs(self._h, lvl, n, _ptr(c), _ptr(b)), "uda_set_head_outputs")
         s = None if image_scales is None else np.ascontiguousarray(image_scales, dtype=np.float32)
-        self._ck(self._lib.uda_postprocess_heads(self._h, n, _ptr(s), -1), "uda_postprocess_heads")
-        return self._collect(n)
+        self._ck(self._lib.uda_postprocess_heads(self._h, n, _ptr(s), mode), "uda_postprocess_heads")
+        return self._collect(n, mode)
 
     # ------------------------------------------------------------------ debug / parity accessors
     def preprocessed(self):
@@ -254,7 +273,7 @@ class ServingDriver:
         boxes = np.empty((n, K, 4), np.float32)
         scores = np.empty((n, K), np.float32)
         classes = np.empty((n, K), np.int32)
-        ucls = np.zeros((n, K, self.num_classes), np.float32)
+        ucls = np.zeros((n, K, 1 if self.params["nms_configs"].get("max_nms_inputs", 0) else self.num_classes), np.float32)
         ual = np.zeros((n, K, 4), np.float32)
         uep = np.zeros((n, K, 4), np.float32)
         self._ck(self._lib.uda_get_candidates(self._h, _ptr(boxes), _ptr(scores), _ptr(classes), _ptr(ucls),
