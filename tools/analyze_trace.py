@@ -27,7 +27,7 @@ p = cfg.as_dict()
 pl = plan_mod.Plan(p, weights_mod.init_weights(p, 0), chunk_images=a.chunk, max_images=a.batch)
 
 rows = list(csv.DictReader(open(a.trace)))
-names = ("stem_kernel", "pw_kernel", "dw_kernel", "se_kernel", "fuse_kernel")
+names = ("stem_kernel", "pw_kernel", "dw_kernel", "se_kernel", "fuse_kernel", "mbx_kernel")
 idx = [i for i, r in enumerate(rows) if "preprocess" in r["Kernel_Name"]]
 rows = rows[idx[-1]:]
 conv = [r for r in rows if any(n in r["Kernel_Name"] for n in names)]
@@ -53,12 +53,16 @@ for o, r in zip(pl.ops, first):
     elif o["kind"] == capi.OP_DW:
         fl = 2 * rows_ * ob.H * ob.W * ob.C * o["k"] ** 2
         desc = "dw k%d s%d C=%-4d @%dx%d" % (o["k"], o["stride"], ob.C, ob.H, ob.W)
+    elif o["kind"] == capi.OP_MBX:
+        ib = pl.bufs[o["ins"][0]]
+        fl = 2 * rows_ * (ib.H * ib.W * ib.C * ob.C + ob.H * ob.W * ob.C * o["k"] ** 2)
+        desc = "mbx %d->%d k%d s%d @%dx%d" % (ib.C, ob.C, o["k"], o["stride"], ob.H, ob.W)
     else:
         desc = {1: "stem", 4: "se", 5: "fuse", 6: "pool"}[o["kind"]] + " C=%d @%dx%d" % (ob.C, ob.H, ob.W)
     res.append((dur, desc, ob.name, by * 4, fl, r["Kernel_Name"].split("(")[0][-16:], r["VGPR_Count"]))
 tot = sum(r[0] for r in res)
 print("chunk of %d images: %d ops, %.2f ms kernel time" % (a.chunk, nops, tot / 1e3))
-for kind in ("pw", "dw", "se", "fuse", "stem", "pool"):
+for kind in ("pw", "dw", "mbx", "se", "fuse", "stem", "pool"):
     sel = [r for r in res if r[1].startswith(kind)]
     if sel:
         t = sum(r[0] for r in sel)

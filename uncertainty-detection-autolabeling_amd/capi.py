@@ -18,7 +18,7 @@ UDA_ABI_VERSION = 1
 MAX_LEVELS = 8
 MAX_FUSE = 3
 
-OP_STEM, OP_PW, OP_DW, OP_SE, OP_FUSE, OP_POOL = 1, 2, 3, 4, 5, 6
+OP_STEM, OP_PW, OP_DW, OP_SE, OP_FUSE, OP_POOL, OP_MBX = 1, 2, 3, 4, 5, 6, 7
 ACT_NONE, ACT_SWISH = 0, 1
 RS_NONE, RS_NEAREST_UP, RS_MAXPOOL = 0, 1, 2
 DECODE_PLAIN, DECODE_LNORM, DECODE_FALSEDEC = 0, 1, 2
@@ -39,7 +39,8 @@ class Op(C.Structure):
                 ("bn_shift_off", C.c_int64), ("se_w1_off", C.c_int64), ("se_b1_off", C.c_int64),
                 ("se_w2_off", C.c_int64), ("se_b2_off", C.c_int64), ("se_mid", C.c_int32),
                 ("drop_site", C.c_int32), ("resample", C.c_int32 * MAX_FUSE),
-                ("fuse_w", C.c_float * MAX_FUSE), ("n_in", C.c_int32), ("reserved", C.c_int32)]
+                ("fuse_w", C.c_float * MAX_FUSE), ("n_in", C.c_int32), ("drop_site2", C.c_int32),
+                ("w2_off", C.c_int64), ("bn2_scale_off", C.c_int64), ("bn2_shift_off", C.c_int64)]
 
 
 class DropSite(C.Structure):

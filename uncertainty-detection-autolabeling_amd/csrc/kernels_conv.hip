@@ -645,4 +645,241 @@ void launch_philox_masks(float* masks, const int64_t* site_off_dev, const int32_
                      masks, site_off_dev, site_ch_dev, site_rate_dev, rows, max_c4, seed);
 }
 
+// ------------------------------------------------------------------------------------ fused MBConv front half
+// expand 1x1 (f32 MFMA) + BN + swish + dropout -> depthwise kxk / stride s (TF SAME) + BN + swish +
+// dropout + SE tile sums, one output tile per block, 32 expanded channels at a time:
+//   X  : the input tile with halo, all Cin channels, transposed [k][pixel] in LDS (MFMA A operand)
+//   E  : the expanded + activated tile of the current 32 channels [pixel][33] in LDS; positions
+//        outside the image are ZERO (TF pads the depthwise INPUT, i.e. the expanded activation)
+//   the depthwise stage reads E with a sliding window along x, writes the output tile (128-byte
+//   channel segments) and the per-tile channel sums for squeeze-excite.
+// The 6x-expanded tensor (94 MB per image-sample at block 1) never goes to HBM; the price is the
+// halo recompute of the expand GEMM (1.4x for 3x3, 1.9x for 5x5 at an 8x16 tile).
+namespace {
+struct MbxCfg { int th, tw; };
+__host__ __device__ constexpr MbxCfg mbx_cfg(int k, int s) {
+  return s == 1 ? MbxCfg{8, 16} : (k == 3 ? MbxCfg{4, 16} : MbxCfg{4, 8});
+}
+}  // namespace
+
+template <int K, int S, int KS>   // KS = Cin / 2 MFMA k-steps (compile-time: the operand registers are indexed statically)
+__global__ __launch_bounds__(256) void mbx_kernel(MbxArgs a) {
+  constexpr int TH = mbx_cfg(K, S).th, TW = mbx_cfg(K, S).tw;
+  constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
+  constexpr int NP = IH * IW;
+  constexpr int NPP = (NP + 31) / 32 * 32;
+  constexpr int NMT = NPP / 32;               // MFMA row tiles of the input tile
+  constexpr int MT_PER_WAVE = (NMT + 3) / 4;
+  constexpr int XS = NPP + 1;                 // X row stride (floats)
+  constexpr int ES = 33;                      // E row stride
+  constexpr int GPR = 8 / TH;                 // thread groups per output row (8 groups of 32 channels)
+  constexpr int XW = TW / GPR;                // outputs per thread along x
+  constexpr int NCOL = (XW - 1) * S + K;
+  extern __shared__ float mlds[];
+  float* X = mlds;                            // [Cin][XS]
+  float* E = mlds + (size_t)a.Cin * XS;       // [NPP][ES]
+  float* red = E + (size_t)NPP * ES;          // [8][32]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, b_in = b / a.in_div;
+  const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+  const int iy0 = oy0 * S - a.pad_t, ix0 = ox0 * S - a.pad_l;
+  const float* xin = a.in + (size_t)b_in * a.H * a.W * a.Cin;
+
+  // ---- stage the input tile (zero outside the image / beyond NP); loads are issued 4 deep
+  const int cq = a.Cin >> 2;
+  const int nf = NPP * cq;
+  for (int f0 = tid; f0 < nf; f0 += 4 * 256) {
+    float4 v[4];
+    int pp[4], qq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int f = f0 + u * 256;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      pp[u] = f / cq;
+      qq[u] = f - pp[u] * cq;
+      if (f < nf && pp[u] < NP) {
+        const int iy = iy0 + pp[u] / IW, ix = ix0 + pp[u] % IW;
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+          v[u] = *(const float4*)(xin + ((size_t)iy * a.W + ix) * a.Cin + 4 * qq[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (f0 + u * 256 < nf) {
+        float* xp = X + (size_t)(4 * qq[u]) * XS + pp[u];
+        xp[0] = v[u].x; xp[XS] = v[u].y; xp[2 * XS] = v[u].z; xp[3 * XS] = v[u].w;
+      }
+    }
+  }
+  // which of this lane's 16 accumulator rows of each of its row tiles lie inside the image
+  unsigned inmask[MT_PER_WAVE];
+#pragma unroll
+  for (int t = 0; t < MT_PER_WAVE; ++t) {
+    const int mt = wave + 4 * t;
+    unsigned m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int p = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int iy = iy0 + p / IW, ix = ix0 + p % IW;
+      if (mt < NMT && p < NP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) m |= 1u << r;
+    }
+    inmask[t] = m;
+  }
+  __syncthreads();
+
+  const int c = tid & 31, g = tid >> 5;       // depthwise stage: channel within the chunk, thread group
+  const int orow = g / GPR, oxs = (g % GPR) * XW;
+  const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  const int oy = oy0 + orow;
+
+  // All per-chunk operands (expand column of We, BN/mask scalars, the K*K depthwise taps) are
+  // requested one chunk ahead, right after the expand phase and BEFORE the depthwise phase issues
+  // its output stores: the next expand phase then waits with a counted vmcnt on loads that are
+  // older than those stores instead of draining them (vmcnt retires loads and stores in order).
+  struct ChunkParams {
+    float bf[KS];
+    float sc0, sh0, mk0;
+    float wk[K * K];
+    float sc1, sh1, mk1;
+  };
+  auto load_params = [&](int c0, ChunkParams& q) {
+    const int ecol = c0 + li;
+    const bool eok = ecol < a.Cmid;
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) q.bf[s2] = eok ? a.we[(size_t)(2 * s2 + lh) * a.Cmid + ecol] : 0.f;
+    q.sc0 = eok ? a.sc0[ecol] : 0.f;
+    q.sh0 = eok ? a.sh0[ecol] : 0.f;
+    q.mk0 = (eok && a.mask0) ? a.mask0[(size_t)b * a.Cmid + ecol] : 1.f;
+    const int dcol_ = c0 + c;
+    const bool dok = dcol_ < a.Cmid;
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) q.wk[t] = dok ? a.wd[(size_t)t * a.Cmid + dcol_] : 0.f;
+    q.sc1 = dok ? a.sc1[dcol_] : 0.f;
+    q.sh1 = dok ? a.sh1[dcol_] : 0.f;
+    q.mk1 = (dok && a.mask1) ? a.mask1[(size_t)b * a.Cmid + dcol_] : 1.f;
+  };
+  ChunkParams cur, nxt;
+  load_params(0, cur);
+
+  for (int c0 = 0; c0 < a.Cmid; c0 += 32) {
+    const int col = c0 + c;
+    const bool dcol = col < a.Cmid;
+    float (&bfr)[KS] = cur.bf;
+    float (&wk)[K * K] = cur.wk;
+    const float sc0 = cur.sc0, sh0 = cur.sh0, mk0 = cur.mk0;
+    const float sc1 = cur.sc1, sh1 = cur.sh1, mk1 = cur.mk1;
+
+    // ---- expand: E[p][j] = swish(bn0(sum_k X[k][p] * We[k][c0 + j])) * mask0, zero outside the image
+#pragma unroll
+    for (int t = 0; t < MT_PER_WAVE; ++t) {
+      const int mt = wave + 4 * t;
+      if (mt < NMT) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* xa = X + (size_t)lh * XS + mt * 32 + li;
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[(size_t)2 * s2 * XS], bfr[s2], acc, 0, 0, 0);
+        float* ep = E + (size_t)(mt * 32 + 4 * lh) * ES + li;
+        const unsigned im = inmask[t];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = swishf(fmaf(acc[r], sc0, sh0)) * mk0;
+          ep[((r & 3) + 8 * (r >> 2)) * ES] = ((im >> r) & 1u) ? v : 0.f;
+        }
+      }
+    }
+    // operands of the NEXT chunk: in flight during the depthwise phase, older than its stores
+    if (c0 + 32 < a.Cmid) load_params(c0 + 32, nxt);
+    __syncthreads();
+    // ---- depthwise on E for channel c0 + c
+    float ssum = 0.f;
+    if (dcol && oy < a.Ho) {
+      float acc[XW];
+#pragma unroll
+      for (int o = 0; o < XW; ++o) acc[o] = 0.f;
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        float rowv[NCOL];
+        const float* er = E + ((size_t)(orow * S + ky) * IW + oxs * S) * ES + c;
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) rowv[j] = er[j * ES];
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+#pragma unroll
+          for (int o = 0; o < XW; ++o) acc[o] = fmaf(rowv[o * S + kx], wk[ky * K + kx], acc[o]);
+        }
+      }
+      float* op = a.out + (((size_t)b * a.Ho + oy) * a.Wo + ox0 + oxs) * a.Cmid + col;
+#pragma unroll
+      for (int o = 0; o < XW; ++o) {
+        if (ox0 + oxs + o < a.Wo) {
+          const float v = swishf(fmaf(acc[o], sc1, sh1)) * mk1;
+          op[(size_t)o * a.Cmid] = v;
+          ssum += v;
+        }
+      }
+    }
+    if (a.se_partial) {
+      red[g * 32 + c] = ssum;
+      __syncthreads();
+      if (g == 0 && dcol) {
+        float t = red[c];
+#pragma unroll
+        for (int gg = 1; gg < 8; ++gg) t += red[gg * 32 + c];
+        a.se_partial[((size_t)b * a.n_tiles + tile) * a.Cmid + col] = t;
+      }
+    }
+    __syncthreads();   // E (and red) are rewritten by the next channel chunk
+    cur = nxt;
+  }
+}
+
+bool mbx_supported(int Cin, int Cmid, int k, int stride) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("UDA_FUSE_MBX"); on = e ? atoi(e) : 1; }
+  return on && Cin % 8 == 0 && Cin >= 16 && Cin <= 48 && Cmid % 4 == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2);
+}
+
+int mbx_tiles(int Ho, int Wo, int k, int stride) {
+  const MbxCfg c = mbx_cfg(k, stride);
+  return ((Ho + c.th - 1) / c.th) * ((Wo + c.tw - 1) / c.tw);
+}
+
+template <int K, int S, int KS>
+static void launch_mbx_t(const MbxArgs& a, int rows, hipStream_t s) {
+  constexpr int TH = mbx_cfg(K, S).th, TW = mbx_cfg(K, S).tw;
+  constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
+  constexpr int NPP = (IH * IW + 31) / 32 * 32;
+  const size_t lds = ((size_t)a.Cin * (NPP + 1) + (size_t)NPP * 33 + 256) * sizeof(float);
+  static size_t attr_lds = 64 * 1024;      // above the default limit the kernel needs an explicit opt-in
+  if (lds > attr_lds) {
+    hipFuncSetAttribute((const void*)mbx_kernel<K, S, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_lds = lds;
+  }
+  const dim3 grid((a.Wo + TW - 1) / TW, (a.Ho + TH - 1) / TH, rows);
+  hipLaunchKernelGGL((mbx_kernel<K, S, KS>), grid, dim3(256), lds, s, a);
+}
+
+template <int K, int S>
+static void launch_mbx_ks(const MbxArgs& a, int rows, hipStream_t s) {
+  switch (a.Cin) {
+    case 16: launch_mbx_t<K, S, 8>(a, rows, s); break;
+    case 24: launch_mbx_t<K, S, 12>(a, rows, s); break;
+    case 32: launch_mbx_t<K, S, 16>(a, rows, s); break;
+    case 40: launch_mbx_t<K, S, 20>(a, rows, s); break;
+    default: launch_mbx_t<K, S, 24>(a, rows, s); break;   // 48
+  }
+}
+
+void launch_mbx(const MbxArgs& a, int rows, int k, int stride, hipStream_t s) {
+  if (k == 3 && stride == 1) launch_mbx_ks<3, 1>(a, rows, s);
+  else if (k == 3 && stride == 2) launch_mbx_ks<3, 2>(a, rows, s);
+  else if (k == 5 && stride == 1) launch_mbx_ks<5, 1>(a, rows, s);
+  else launch_mbx_ks<5, 2>(a, rows, s);
+}
+
 }  // namespace uda

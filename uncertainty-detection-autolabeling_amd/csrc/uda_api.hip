@@ -267,17 +267,23 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
     if (!okbuf(o.out)) { fail(nullptr, "op %d: bad out buffer %d", i, o.out); uda_destroy(c); return 1; }
     for (int j = 0; j < o.n_in; ++j)
       if (!okbuf(o.in[j])) { fail(nullptr, "op %d: bad in[%d] buffer %d", i, j, o.in[j]); uda_destroy(c); return 1; }
-    if (o.drop_site >= m.n_drop_sites) { fail(nullptr, "op %d: bad drop site %d", i, o.drop_site); uda_destroy(c); return 1; }
+    if (o.drop_site >= m.n_drop_sites || (o.kind == UDA_OP_MBX && o.drop_site2 >= m.n_drop_sites)) {
+      fail(nullptr, "op %d: bad drop site %d", i, o.drop_site);
+      uda_destroy(c);
+      return 1;
+    }
     if (o.drop_site >= 0 && c->sites[o.drop_site].channels != bufs[o.out].C) {
       fail(nullptr, "op %d: drop site %d has %d channels, output has %d", i, o.drop_site,
            c->sites[o.drop_site].channels, bufs[o.out].C);
       uda_destroy(c);
       return 1;
     }
-    const int64_t offs[] = {o.w_off, o.bias_off, o.bn_scale_off, o.bn_shift_off, o.se_w1_off, o.se_b1_off, o.se_w2_off, o.se_b2_off};
+    const int64_t offs[] = {o.w_off, o.bias_off, o.bn_scale_off, o.bn_shift_off, o.se_w1_off, o.se_b1_off, o.se_w2_off, o.se_b2_off,
+                            o.kind == UDA_OP_MBX ? o.w2_off : -1, o.kind == UDA_OP_MBX ? o.bn2_scale_off : -1,
+                            o.kind == UDA_OP_MBX ? o.bn2_shift_off : -1};
     for (int64_t off : offs)
       if (off >= n_weights) { fail(nullptr, "op %d: weight offset %lld beyond blob (%lld)", i, (long long)off, (long long)n_weights); uda_destroy(c); return 1; }
-    if ((o.kind == UDA_OP_PW || o.kind == UDA_OP_DW) && (bufs[o.in[0]].C % 4 || bufs[o.out].C % 1)) {
+    if ((o.kind == UDA_OP_PW || o.kind == UDA_OP_DW || o.kind == UDA_OP_MBX) && (bufs[o.in[0]].C % 4 || bufs[o.out].C % 1)) {
       fail(nullptr, "op %d: channel count %d not a multiple of 4", i, bufs[o.in[0]].C);
       uda_destroy(c);
       return 1;
@@ -555,11 +561,38 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       if (o.se_partial >= 0) {
         const int nt = dw_tiles(ob.C, ob.H, ob.W, o.k, o.stride);
         const uda_buf_desc_t& pb = c->bufs[o.se_partial];
-        if ((int64_t)pb.H * pb.W < (int64_t)nt || pb.C != ob.C || pb.per_sample != ob.per_sample)
-          return fail(c, "op %d: SE partial buffer [%d,%d,%d] too small for %d tiles", oi, pb.H, pb.W, pb.C, nt);
+        if ((int64_t)pb.H * pb.W != (int64_t)nt || pb.C != ob.C || pb.per_sample != ob.per_sample)
+          return fail(c, "op %d: SE partial buffer [%d,%d,%d] does not match %d tiles", oi, pb.H, pb.W, pb.C, nt);
         a.se_partial = v.ptr(o.se_partial);
       }
       launch_dw(a, rows, o.k, o.stride, c->stream);
+      break;
+    }
+    case UDA_OP_MBX: {
+      const uda_buf_desc_t& ib = c->bufs[o.in[0]];
+      if (!mbx_supported(ib.C, ob.C, o.k, o.stride)) return fail(c, "op %d: fused MBConv %d->%d k%d s%d unsupported", oi, ib.C, ob.C, o.k, o.stride);
+      if (o.drop_site2 >= c->model.n_drop_sites || (o.drop_site2 >= 0 && c->sites[o.drop_site2].channels != ob.C))
+        return fail(c, "op %d: bad second dropout site", oi);
+      MbxArgs a{};
+      a.in = v.ptr(o.in[0]);
+      a.out = v.ptr(o.out);
+      a.we = v.wt(o.w_off); a.sc0 = v.wt(o.bn_scale_off); a.sh0 = v.wt(o.bn_shift_off);
+      a.wd = v.wt(o.w2_off); a.sc1 = v.wt(o.bn2_scale_off); a.sh1 = v.wt(o.bn2_shift_off);
+      if (!a.we || !a.sc0 || !a.wd || !a.sc1) return fail(c, "op %d: fused MBConv needs both kernels and both BNs", oi);
+      a.mask0 = v.mask(o.drop_site);
+      a.mask1 = v.mask(o.drop_site2);
+      a.H = ib.H; a.W = ib.W; a.Ho = ob.H; a.Wo = ob.W; a.Cin = ib.C; a.Cmid = ob.C;
+      a.pad_t = same_pad_before(ib.H, ob.H, o.k, o.stride);
+      a.pad_l = same_pad_before(ib.W, ob.W, o.k, o.stride);
+      a.in_div = v.div(ib, ob);
+      a.n_tiles = mbx_tiles(ob.H, ob.W, o.k, o.stride);
+      if (o.se_partial >= 0) {
+        const uda_buf_desc_t& pb = c->bufs[o.se_partial];
+        if ((int64_t)pb.H * pb.W != (int64_t)a.n_tiles || pb.C != ob.C || pb.per_sample != ob.per_sample)
+          return fail(c, "op %d: SE partial buffer [%d,%d,%d] does not match %d tiles", oi, pb.H, pb.W, pb.C, a.n_tiles);
+        a.se_partial = v.ptr(o.se_partial);
+      }
+      launch_mbx(a, rows, o.k, o.stride, c->stream);
       break;
     }
     case UDA_OP_SE: {
@@ -570,7 +603,7 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       a.scale = v.ptr(o.out);
       a.w1 = v.wt(o.se_w1_off); a.b1 = v.wt(o.se_b1_off);
       a.w2 = v.wt(o.se_w2_off); a.b2 = v.wt(o.se_b2_off);
-      a.C = src.C; a.mid = o.se_mid; a.n_tiles = dw_tiles(src.C, src.H, src.W, o.k, o.stride);
+      a.C = src.C; a.mid = o.se_mid; a.n_tiles = pb.H * pb.W;   // the producer (DW / MBX) validated this count
       a.inv_hw = 1.0f / (float)(src.H * src.W);
       if (pb.C != src.C || ob.C != src.C) return fail(c, "op %d: SE channel mismatch", oi);
       launch_se(a, rows, c->stream);

@@ -53,6 +53,28 @@ struct DwArgs {
   int n_tiles;           // Ho * gridDim.x
 };
 
+struct MbxArgs {
+  const float* in;        // [rows_in, H, W, Cin]
+  float* out;             // [rows, Ho, Wo, Cmid]
+  const float* we;        // expand kernel [Cin, Cmid]
+  const float* sc0;       // BN after expand
+  const float* sh0;
+  const float* mask0;     // [rows, Cmid] or null
+  const float* wd;        // depthwise kernel [k*k, Cmid]
+  const float* sc1;       // BN after depthwise
+  const float* sh1;
+  const float* mask1;     // [rows, Cmid] or null
+  float* se_partial;      // [rows, n_tiles, Cmid] or null
+  int H, W, Ho, Wo, Cin, Cmid;
+  int pad_t, pad_l;
+  int in_div;
+  int n_tiles;
+  int debug;              // ablation switches (UDA_MBX_DEBUG), 0 in production
+};
+void launch_mbx(const MbxArgs& a, int rows, int k, int stride, hipStream_t s);
+int mbx_tiles(int Ho, int Wo, int k, int stride);
+bool mbx_supported(int Cin, int Cmid, int k, int stride);
+
 struct SeArgs {
   const float* partial;  // [rows, n_tiles, C]
   float* scale;          // [rows, C]

@@ -43,6 +43,22 @@ def dw_tiles(C, Ho, Wo, k, stride):
     return -(-Ho // DW_ROWS) * dw_tiles_x(C, Wo, k, stride)
 
 
+def mbx_tile(k, stride):
+    """(TH, TW) output tile of the fused expand+depthwise kernel (mirror of mbx_cfg in csrc)."""
+    return (8, 16) if stride == 1 else ((4, 16) if k == 3 else (4, 8))
+
+
+def mbx_tiles(Ho, Wo, k, stride):
+    th, tw = mbx_tile(k, stride)
+    return -(-Ho // th) * -(-Wo // tw)
+
+
+def mbx_supported(cin, cmid, k, stride):
+    import os
+    return (int(os.environ.get("UDA_FUSE_MBX", "1")) and cin % 8 == 0 and 16 <= cin <= 48 and cmid % 4 == 0
+            and k in (3, 5) and stride in (1, 2))
+
+
 def same_out(n, s):
     return -(-n // s)
 
@@ -128,7 +144,8 @@ class Plan:
         o = dict(kind=kind, ins=list(ins), out=out, se_scale=-1, se_partial=-1, residual=-1, k=0,
                  stride=1, act=capi.ACT_NONE, w_off=-1, bias_off=-1, bn_scale_off=-1, bn_shift_off=-1,
                  se_w1_off=-1, se_b1_off=-1, se_w2_off=-1, se_b2_off=-1, se_mid=0, drop_site=-1,
-                 resample=[0, 0, 0], fuse_w=[0.0, 0.0, 0.0])
+                 resample=[0, 0, 0], fuse_w=[0.0, 0.0, 0.0], drop_site2=-1, w2_off=-1, bn2_scale_off=-1,
+                 bn2_shift_off=-1)
         o.update(kw)
         self.ops.append(o)
         return out
@@ -191,17 +208,39 @@ class Plan:
             p = "%s/blocks_%d/" % (bb, i)
             bn_names = [p + "tpu_batch_normalization" + ("" if j == 0 else "_%d" % j) for j in range(3)]
             inp, nb = x, 0
-            if b["expand"] != 1:
-                x = self._pw(x, b["cin"] * b["expand"], p + "conv2d/kernel", "blocks_%d/expand" % i,
-                             bn=bn_names[nb], act=capi.ACT_SWISH, site=self._site("blocks_%d/expand" % i))
-                nb += 1
+            mid = b["cin"] * b["expand"]
+            if b["expand"] != 1 and mbx_supported(b["cin"], mid, b["kernel"], b["stride"]):
+                # fused expand + depthwise: the expanded tensor stays on-chip
+                xb = self.bufs[x]
+                Ho, Wo = same_out(xb.H, b["stride"]), same_out(xb.W, b["stride"])
+                s0, s1 = self._site("blocks_%d/expand" % i), self._site("blocks_%d/dw" % i)
+                ps = xb.per_sample or s0 >= 0 or s1 >= 0
+                out = self._buf(Ho, Wo, mid, ps, name="blocks_%d/dw" % i)
+                part = -1
+                kw = dict(k=b["kernel"], stride=b["stride"], w_off=self._pack(w[p + "conv2d/kernel"]),
+                          drop_site=s0, drop_site2=s1, act=capi.ACT_SWISH,
+                          w2_off=self._pack(w[p + "depthwise_conv2d/depthwise_kernel"]))
+                kw["bn_scale_off"], kw["bn_shift_off"] = self._bn(bn_names[0])
+                kw["bn2_scale_off"], kw["bn2_shift_off"] = self._bn(bn_names[1])
+                if b["se"]:
+                    part = self._buf(mbx_tiles(Ho, Wo, b["kernel"], b["stride"]), 1, mid, ps,
+                                     name="blocks_%d/dw/se_partial" % i)
+                    kw["se_partial"] = part
+                x = self._op(capi.OP_MBX, [x], out, **kw)
+                nb = 2
                 proj = p + "conv2d_1/kernel"
             else:
-                proj = p + "conv2d/kernel"
-            x, part = self._dw(x, b["kernel"], b["stride"], p + "depthwise_conv2d/depthwise_kernel",
-                               "blocks_%d/dw" % i, bn=bn_names[nb], act=capi.ACT_SWISH,
-                               site=self._site("blocks_%d/dw" % i), with_se=bool(b["se"]))
-            nb += 1
+                if b["expand"] != 1:
+                    x = self._pw(x, mid, p + "conv2d/kernel", "blocks_%d/expand" % i,
+                                 bn=bn_names[nb], act=capi.ACT_SWISH, site=self._site("blocks_%d/expand" % i))
+                    nb += 1
+                    proj = p + "conv2d_1/kernel"
+                else:
+                    proj = p + "conv2d/kernel"
+                x, part = self._dw(x, b["kernel"], b["stride"], p + "depthwise_conv2d/depthwise_kernel",
+                                   "blocks_%d/dw" % i, bn=bn_names[nb], act=capi.ACT_SWISH,
+                                   site=self._site("blocks_%d/dw" % i), with_se=bool(b["se"]))
+                nb += 1
             gate = -1
             if b["se"]:
                 xb = self.bufs[x]
@@ -441,7 +480,7 @@ class Plan:
             c.n_in = len(o["ins"])
             for k in ("out", "se_scale", "se_partial", "residual", "k", "stride", "act", "w_off", "bias_off",
                       "bn_scale_off", "bn_shift_off", "se_w1_off", "se_b1_off", "se_w2_off", "se_b2_off",
-                      "se_mid", "drop_site"):
+                      "se_mid", "drop_site", "drop_site2", "w2_off", "bn2_scale_off", "bn2_shift_off"):
                 setattr(c, k, int(o[k]))
         sites = (capi.DropSite * max(1, len(self.sites)))()
         for i, (_, ch, r) in enumerate(self.sites):
@@ -500,6 +539,10 @@ def op_costs(plan, n_images):
         elif k == capi.OP_STEM:
             by += 27 * ob.C
             fl = 2 * rows * ob.H * ob.W * 27 * ob.C
+        elif k == capi.OP_MBX:
+            ib = plan.bufs[o["ins"][0]]
+            by += ib.C * ob.C + o["k"] * o["k"] * ob.C
+            fl = 2 * rows * (ib.H * ib.W * ib.C * ob.C + ob.H * ob.W * ob.C * o["k"] * o["k"])
         elif k == capi.OP_SE:
             fl = 4 * rows * ob.C * o["se_mid"]
         elif k in (capi.OP_FUSE, capi.OP_POOL):
