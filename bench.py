@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--chunk", type=int, default=16, help="images per pass of the op list")
     ap.add_argument("--model", default="efficientdet-d0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="use the process group (RCCL) path even at world size 1")
     ap.add_argument("--cpu-sample-t", type=int, default=10)
     ap.add_argument("--cpu-sample-images", type=int, default=4)
     return ap.parse_args()
@@ -94,13 +95,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1 or a.gpus > 1:
+    if world > 1 or a.gpus > 1 or a.force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch                    # torch first: the HIP library then binds to the same runtime
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         tdev = torch.device("cuda", local_rank)
+        # RCCL prints a version banner on stdout at communicator creation; stdout carries exactly one
+        # JSON line (the driver's contract), so the banner is sent to stderr.
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=tdev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
 
     from uda_amd import capi, plan as plan_mod, weights as weights_mod
     from uda_amd.infer_lib import ServingDriver
@@ -113,6 +125,7 @@ def main():
     images = np.random.default_rng(2 + rank).integers(0, 256, (a.batch, H_, W_, 3), dtype=np.uint8)
 
     log("driver ready: %s" % (drv.plan.summary(),))
+    drv.set_image_offset(rank * a.batch)           # Philox rows of the global (weak-scaled) batch
     t_up = time.perf_counter()
     drv.stage_images(images)                       # PCIe leg, outside the timed region
     upload_s = time.perf_counter() - t_up

@@ -145,6 +145,9 @@ int uda_set_images_f32(uda_ctx_t* ctx, const float* images, int32_t n, const flo
 /* Dropout masks: either generated on the device from `seed` (Philox4x32-10)
  * or injected: `masks` = concatenation over sites of float32 [n*T, channels] keep-scales. */
 int uda_set_dropout_seed(uda_ctx_t* ctx, uint64_t seed);
+/* Index of the handle's first image inside the global batch (multi-GPU image shards): the Philox row
+ * of image n, sample t is (offset + n) * T + t, so a sharded batch draws the masks of the unsharded one. */
+int uda_set_dropout_image_offset(uda_ctx_t* ctx, int64_t first_image);
 int uda_set_dropout_masks(uda_ctx_t* ctx, const float* masks, int64_t n_floats);
 int uda_get_dropout_masks(uda_ctx_t* ctx, float* masks, int64_t n_floats);
 

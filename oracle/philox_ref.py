@@ -37,9 +37,9 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     return c0, c1, c2, c3
 
 
-def site_mask(seed, site, rate, n_rows, channels):
-    """float32 [n_rows, channels] keep-scales of one dropout site."""
-    b = np.arange(n_rows, dtype=np.uint32)[:, None]
+def site_mask(seed, site, rate, n_rows, channels, row_base=0):
+    """float32 [n_rows, channels] keep-scales of one dropout site (rows row_base .. row_base+n_rows)."""
+    b = (np.arange(n_rows, dtype=np.uint32) + np.uint32(row_base))[:, None]
     c = np.arange(channels, dtype=np.uint32)[None, :]
     out = philox4x32_10(c >> np.uint32(2), b, np.uint32(site), np.uint32(0),
                         seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
@@ -51,7 +51,8 @@ def site_mask(seed, site, rate, n_rows, channels):
     return np.where(keep, scale, np.float32(0.0)).astype(np.float32)
 
 
-def make_masks(sites, seed, N, T):
-    """{site name: float32 [N, T, C]} for `effdet_ref.forward`."""
-    return {name: site_mask(seed, s, rate, N * T, ch).reshape(N, T, ch)
+def make_masks(sites, seed, N, T, first_image=0):
+    """{site name: float32 [N, T, C]} for `effdet_ref.forward`; `first_image` = index of image 0
+    in the global batch (image shards)."""
+    return {name: site_mask(seed, s, rate, N * T, ch, first_image * T).reshape(N, T, ch)
             for s, (name, ch, rate) in enumerate(sites)}

@@ -289,3 +289,54 @@ def test_legacy_detection_rows():
     rows_g = legacy.generate_detections(d, p, rcls, rbox, scales, np.array([7, 9]), per_class_nms=False)
     assert rows_g.shape == (2, 100, 7 + 7)
     d.close()
+
+
+SHARD_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import torch.distributed as dist
+from common import FULL_MC, make_images, make_params, make_weights
+from uda_amd import dist as udist
+from uda_amd.infer_lib import ServingDriver
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+p = make_params(**FULL_MC); w = make_weights(p, seed=33, cls_spread=20.0)
+imgs = make_images(3, 100, 180, seed=34)
+drv = ServingDriver("_", False, p["name"], batch_size=3, model_params=p, weights=w)
+drv.set_dropout_seed(11)
+got = udist.serve_sharded(drv, imgs, rank, world)
+np.savez(sys.argv[1] + ".rank%%d.npz" %% rank, *got)
+dist.barrier(); dist.destroy_process_group(); drv.close()
+'''
+
+
+def test_image_sharded_serve_equals_unsharded(tmp_path):
+    """e: two ranks (gloo, both on GPU 0) each serve their contiguous image shard and all-gather the
+    detections; with the global image offset fed to the Philox stream the result is bit-identical
+    to one process serving the whole batch."""
+    import os, socket, subprocess, sys
+    from common import ROOT
+    p = make_params(**FULL_MC)
+    w = make_weights(p, seed=33, cls_spread=20.0)
+    imgs = make_images(3, 100, 180, seed=34)
+    d = _driver(p, w, 3)
+    d.set_dropout_seed(11)
+    want = d.serve(imgs)
+    d.close()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "det")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, "-c", SHARD_WORKER % {"root": ROOT}, out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for pr in procs:
+        o = pr.communicate(timeout=300)[0]
+        assert pr.returncode == 0, o
+    for rank in range(2):
+        z = np.load(out + ".rank%d.npz" % rank)
+        got = [z["arr_%d" % i] for i in range(len(want))]
+        for g, r in zip(got, want):
+            np.testing.assert_array_equal(g, r)

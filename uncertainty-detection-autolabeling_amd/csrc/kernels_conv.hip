@@ -612,7 +612,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 __global__ __launch_bounds__(256) void philox_kernel(float* masks, const int64_t* site_off,
                                                      const int32_t* site_ch, const float* site_rate,
-                                                     int rows, int max_c4, uint64_t seed) {
+                                                     int rows, uint32_t row_base, int max_c4, uint64_t seed) {
   const int site = blockIdx.y;
   const int C = site_ch[site];
   const int C4 = (C + 3) >> 2;
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256) void philox_kernel(float* masks, const int64_t
   const int row = (int)(gid / max_c4);
   if (c4 >= C4) return;
   uint32_t w[4];
-  philox4x32_10((uint32_t)c4, (uint32_t)row, (uint32_t)site, 0u, (uint32_t)seed,
+  philox4x32_10((uint32_t)c4, row_base + (uint32_t)row, (uint32_t)site, 0u, (uint32_t)seed,
                 (uint32_t)(seed >> 32), w);
   const float rate = site_rate[site];
   const float scale = 1.0f / (1.0f - rate);
@@ -637,12 +637,12 @@ __global__ __launch_bounds__(256) void philox_kernel(float* masks, const int64_t
 }
 
 void launch_philox_masks(float* masks, const int64_t* site_off_dev, const int32_t* site_ch_dev,
-                         const float* site_rate_dev, int n_sites, int rows, int max_c4,
+                         const float* site_rate_dev, int n_sites, int rows, uint32_t row_base, int max_c4,
                          uint64_t seed, hipStream_t s) {
   if (n_sites == 0 || rows == 0) return;
   const int64_t per_site = (int64_t)rows * max_c4;
   hipLaunchKernelGGL(philox_kernel, dim3((unsigned)((per_site + 255) / 256), n_sites), dim3(256), 0, s,
-                     masks, site_off_dev, site_ch_dev, site_rate_dev, rows, max_c4, seed);
+                     masks, site_off_dev, site_ch_dev, site_rate_dev, rows, row_base, max_c4, seed);
 }
 
 // ------------------------------------------------------------------------------------ fused MBConv front half

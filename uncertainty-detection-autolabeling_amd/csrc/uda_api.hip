@@ -59,6 +59,7 @@ struct uda_ctx {
   bool masks_injected = false;
   int masks_rows = 0;
   uint64_t seed = 0;
+  int64_t image_offset = 0;
 
   // head outputs [max_images * Tx, hw, ch] per level
   float* d_cls[UDA_MAX_LEVELS] = {};
@@ -449,6 +450,13 @@ extern "C" int uda_set_dropout_seed(uda_ctx_t* c, uint64_t seed) {
   return 0;
 }
 
+extern "C" int uda_set_dropout_image_offset(uda_ctx_t* c, int64_t first_image) {
+  if (!c) return 1;
+  if (first_image < 0) return fail(c, "set_dropout_image_offset: negative offset");
+  c->image_offset = first_image;
+  return 0;
+}
+
 extern "C" int uda_set_dropout_masks(uda_ctx_t* c, const float* masks, int64_t n_floats) {
   if (!c || !masks) return c ? fail(c, "set_dropout_masks: NULL") : 1;
   if (n_floats > c->mask_cap || (c->sum_site_ch && n_floats % c->sum_site_ch))
@@ -679,7 +687,7 @@ static int run_network(uda_ctx* c) {
       HIPC(c, hipMemcpyAsync(c->d_site_off, c->site_off.data(), c->sites.size() * sizeof(int64_t),
                              hipMemcpyHostToDevice, c->stream));
       launch_philox_masks(c->d_masks, c->d_site_off, c->d_site_ch, c->d_site_rate, (int)c->sites.size(), rows,
-                          c->max_c4, c->seed, c->stream);
+                          (uint32_t)(c->image_offset * T), c->max_c4, c->seed, c->stream);
     }
   }
   for (int i0 = 0; i0 < n; i0 += m.chunk_images) {

@@ -111,7 +111,7 @@ int dw_tiles(int C, int Ho, int Wo, int k, int stride);  // SE tile sums one dep
 void launch_se(const SeArgs& a, int rows, hipStream_t s);
 void launch_fuse(const FuseArgs& a, hipStream_t s);
 void launch_philox_masks(float* masks, const int64_t* site_off_dev, const int32_t* site_ch_dev,
-                         const float* site_rate_dev, int n_sites, int rows, int max_c4,
+                         const float* site_rate_dev, int n_sites, int rows, uint32_t row_base, int max_c4,
                          uint64_t seed, hipStream_t s);
 
 // ---------------------------------------------------------------- post-process (kernels_post.hip)

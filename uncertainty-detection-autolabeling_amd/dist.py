@@ -73,6 +73,7 @@ def serve_sharded(driver, images, rank, world, device=None, group=None):
     """Image-sharded serve: each rank runs the path on its contiguous shard, then one
     all-gather returns the full batch's detections on every rank."""
     start, stop = shard_range(len(images), rank, world)
+    driver.set_image_offset(start)      # same dropout masks as the unsharded batch
     if stop > start:
         det = driver.serve(images[start:stop])
     else:  # more ranks than images: this rank contributes an empty shard

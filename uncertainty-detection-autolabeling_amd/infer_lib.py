@@ -180,6 +180,11 @@ class ServingDriver:
             out.append(np.zeros((0, self.M, self.num_classes), np.float32))
         return tuple(out)
 
+    def set_image_offset(self, first_image):
+        """Position of this driver's first image in the global batch (multi-GPU shards): makes the
+        Philox dropout rows those of the unsharded batch."""
+        self._ck(self._lib.uda_set_dropout_image_offset(self._h, int(first_image)), "uda_set_dropout_image_offset")
+
     def serve(self, image_arrays, post_mode=None):
         """uint8 [N,h,w,3] -> (boxes, scores, classes, valid_len[, logits]).
 
