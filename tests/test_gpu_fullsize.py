@@ -1,0 +1,123 @@
+"""GPU tests at BASELINE.json's full sizes (D0, 1280x768, T=10, batch 32): the oracle is too slow
+for the whole batch, so the checks are size-independent properties plus an oracle spot check on
+one image."""
+import numpy as np
+import pytest
+
+from common import make_images, make_params, make_weights
+
+pytestmark = pytest.mark.gpu
+
+FULL = dict(image_size="1280x768", mc_dropout=True, mc_dropoutrate=0.05, mc_dropoutsamp=10, loss_attenuation=True)
+
+
+def _driver(params, w, batch, **kw):
+    from uda_amd.infer_lib import ServingDriver
+    return ServingDriver("_", False, params["name"], batch_size=batch, model_params=params, weights=w, **kw)
+
+
+@pytest.fixture(scope="module")
+def full_run():
+    p = make_params(**FULL)
+    w = make_weights(p, seed=0)
+    imgs = make_images(32, 768, 1280, seed=2)
+    d = _driver(p, w, 32, chunk_images=16)
+    d.set_dropout_seed(5)
+    det = d.serve(imgs)
+    yield p, w, imgs, d, det
+    d.close()
+
+
+def test_output_layout_and_invariants(full_run):
+    p, w, imgs, d, (boxes, scores, classes, valid, logits) = full_run
+    assert boxes.shape == (32, 100, 12) and scores.shape == (32, 100) and classes.shape == (32, 100, 8)
+    assert valid.dtype == np.int32 and logits.shape == (32, 100, 7)
+    assert np.all(valid == 100)                              # random-init regime: every anchor is a candidate
+    assert np.all(np.isfinite(boxes)) and np.all(np.isfinite(scores))
+    assert np.all(np.diff(scores, axis=1) <= 0)              # soft-NMS emits non-increasing scores
+    assert np.all(scores > 0.001) and np.all(scores < 1)
+    b = boxes[..., :4]
+    assert b.min() >= 0 and b[..., [0, 2]].max() <= 768 and b[..., [1, 3]].max() <= 1280   # clipped, scale 1
+    assert np.all(b[..., 2] >= b[..., 0]) and np.all(b[..., 3] >= b[..., 1])
+    assert np.all(boxes[..., 4:] >= 0)                       # aleatoric / epistemic std
+    assert np.all(classes[..., 0] >= 1) and np.all(classes[..., 0] <= 7) and np.all(classes[..., 1:] >= 0)
+    # MC dropout really varies the samples: epistemic std is non-zero almost everywhere
+    assert (boxes[..., 8:] > 0).mean() > 0.99
+
+
+def test_rerun_is_deterministic_and_seed_matters(full_run):
+    p, w, imgs, d, det = full_run
+    d.set_dropout_seed(5)
+    again = d.serve(imgs)
+    for a, b in zip(again, det):
+        np.testing.assert_array_equal(a, b)
+    d.set_dropout_seed(6)
+    other = d.serve(imgs)
+    assert not np.array_equal(other[0], det[0])
+
+
+def test_chunking_and_batch_position_invariance(full_run):
+    """Detections of an image do not depend on the chunk size or on where the image sits in the batch
+    once the Philox image offset is given (the property image sharding relies on)."""
+    p, w, imgs, d, det = full_run
+    d2 = _driver(p, w, 8, chunk_images=3)
+    d2.set_dropout_seed(5)
+    d2.set_image_offset(16)
+    part = d2.serve(imgs[16:24])
+    d2.close()
+    for a, b in zip(part, det):
+        np.testing.assert_array_equal(a, b[16:24])
+
+
+def test_postprocess_of_own_heads_reproduces_serve(full_run):
+    p, w, imgs, d, det = full_run
+    d.set_dropout_seed(5)
+    d.serve(imgs[:4])
+    cls, box = d.head_outputs(4)
+    assert cls[0].shape == (10, 4, 96, 160, 63) and box[0].shape == (10, 4, 96, 160, 72)
+    again = d.postprocess(cls, box, np.ones(4, np.float32))
+    for a, b in zip(again, det):
+        np.testing.assert_array_equal(a, b[:4])
+
+
+def test_unit_masks_equal_the_deterministic_network(full_run):
+    """MC path with every keep-scale = 1 must equal the non-MC network (checks the shared / per-sample
+    split of the plan at full size)."""
+    p, w, imgs, d, det = full_run
+    ones = {name: np.ones((2, 10, ch), np.float32) for name, ch, _ in d.plan.sites}
+    d.set_dropout_masks(ones)
+    d.serve(imgs[:2])
+    cls_mc, box_mc = d.head_outputs(2)
+    d._injected = False
+    p0 = make_params(image_size="1280x768", loss_attenuation=True)
+    d0 = _driver(p0, w, 2)
+    d0.serve(imgs[:2])
+    cls, box = d0.head_outputs(2)
+    d0.close()
+    for l in range(5):
+        for t in (0, 9):
+            np.testing.assert_array_equal(cls_mc[l][t], cls[l])
+            np.testing.assert_array_equal(box_mc[l][t], box[l])
+
+
+def test_oracle_spot_check_one_image_full_resolution(full_run):
+    """One image at 1280x768 with T=2 against the CPU oracle: heads within f32 tolerance, and the whole
+    post-process (184 140 near-tied candidates per image) bit-exact on the oracle's head outputs."""
+    from oracle import effdet_ref as E, philox_ref as R, post_ref as P, preprocess_ref as PP
+    _, w, imgs, _, _ = full_run
+    p = make_params(**dict(FULL, mc_dropoutsamp=2))
+    d = _driver(p, w, 1)
+    d.set_dropout_seed(9)
+    d.serve(imgs[:1])
+    cls, box = d.head_outputs(1)
+    x, scales = PP.preprocess(imgs[:1], (768, 1280), p["mean_rgb"], p["stddev_rgb"])
+    masks = R.make_masks(E.dropout_sites(p), 9, 1, 2)
+    rcls, rbox = E.forward(w, p, x, masks)
+    for l in range(5):
+        for g, r in ((cls[l], rcls[l]), (box[l], rbox[l])):
+            assert np.abs(g - r).max() <= 2e-4 * np.abs(r).max() + 1e-6
+    want = P.postprocess_global(p, rcls, rbox, scales)
+    got = d.postprocess(rcls, rbox, scales)
+    for g, r in zip(got, want):
+        np.testing.assert_array_equal(g, r)
+    d.close()
