@@ -324,8 +324,11 @@ constexpr int DW_ROWS = 8;  // output rows per block
 // Each thread keeps a K-row x NCOL-column window of its 4 channels in registers and slides it
 // down the DW_ROWS output rows: every input element is loaded once per block column strip
 // (instead of K times), the K*K weight quads of the block's channels sit in LDS.
-template <int K, int S, int XB>
-__global__ __launch_bounds__(256, (K == 5 && XB == 2) ? 2 : 3) void dw_kernel(DwArgs a) {
+// PF = input rows requested ahead of the row being consumed: the window ring holds K + PF rows, so the
+// loads of row r + PF are in flight while the outputs that end at row r are computed (the compiler
+// turns the distance into a counted s_waitcnt vmcnt).
+template <int K, int S, int XB, int PF>
+__global__ __launch_bounds__(256, (K == 5) ? 2 : 3) void dw_kernel(DwArgs a) {
   extern __shared__ float4 dsm[];          // wts[K*K][tc] | red[blockDim]
   float4* wts = dsm;
   float4* red = dsm + K * K * a.tc;
@@ -343,6 +346,7 @@ __global__ __launch_bounds__(256, (K == 5 && XB == 2) ? 2 : 3) void dw_kernel(Dw
   const bool active = (pg < a.pxb) && (c4 < C4) && (x0 < a.Wo);
   constexpr int NCOL = (XB - 1) * S + K;
   constexpr int IN_ROWS = (DW_ROWS - 1) * S + K;
+  constexpr int RING = K + PF;
   float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f);
 
   if (active) {
@@ -357,18 +361,21 @@ __global__ __launch_bounds__(256, (K == 5 && XB == 2) ? 2 : 3) void dw_kernel(Dw
     if (a.mask) mk = *(const float4*)(a.mask + (size_t)b * a.C + c4 * 4);
     const int y0 = blockIdx.y * DW_ROWS;
     const int iy_base = y0 * S - a.pad_t, ix0 = x0 * S - a.pad_l;
-    float4 win[K][NCOL];
+    float4 win[RING][NCOL];
 #pragma unroll
-    for (int r = 0; r < IN_ROWS; ++r) {
-      const int iy = iy_base + r;
-      const bool rowok = (iy >= 0) && (iy < a.H);
-      const float* rowp = inb + (size_t)(rowok ? iy : 0) * a.W * a.C;
+    for (int it = 0; it < IN_ROWS + PF; ++it) {
+      if (it < IN_ROWS) {                      // request input row `it`
+        const int iy = iy_base + it;
+        const bool rowok = (iy >= 0) && (iy < a.H);
+        const float* rowp = inb + (size_t)(rowok ? iy : 0) * a.W * a.C;
 #pragma unroll
-      for (int j = 0; j < NCOL; ++j) {
-        const int ix = ix0 + j;
-        win[r % K][j] = (rowok && ix >= 0 && ix < a.W) ? *(const float4*)(rowp + (size_t)ix * a.C)
-                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < NCOL; ++j) {
+          const int ix = ix0 + j;
+          win[it % RING][j] = (rowok && ix >= 0 && ix < a.W) ? *(const float4*)(rowp + (size_t)ix * a.C)
+                                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
       }
+      const int r = it - PF;                   // newest row that must have arrived
       if (r >= K - 1 && (r - (K - 1)) % S == 0) {
         const int o_row = (r - (K - 1)) / S;
         const int y = y0 + o_row;
@@ -383,7 +390,7 @@ __global__ __launch_bounds__(256, (K == 5 && XB == 2) ? 2 : 3) void dw_kernel(Dw
               const float4 w = wts[(ky * K + kx) * a.tc + c4l];
 #pragma unroll
               for (int o = 0; o < XB; ++o) {
-                const float4 v = win[(o_row * S + ky) % K][o * S + kx];
+                const float4 v = win[(o_row * S + ky) % RING][o * S + kx];
                 acc[o].x = fmaf(v.x, w.x, acc[o].x);
                 acc[o].y = fmaf(v.y, w.y, acc[o].y);
                 acc[o].z = fmaf(v.z, w.z, acc[o].z);
@@ -428,12 +435,7 @@ __global__ __launch_bounds__(256, (K == 5 && XB == 2) ? 2 : 3) void dw_kernel(Dw
   }
 }
 
-static inline int dw_xb5() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("UDA_DW5_XB"); v = e ? atoi(e) : 1; }
-  return v;
-}
-static inline int dw_xb(int k, int stride) { return k == 5 ? dw_xb5() : (stride == 1 ? 4 : 2); }
+static inline int dw_xb(int k, int stride) { return k == 5 ? 1 : (stride == 1 ? 4 : 2); }
 
 void dw_geometry(int C, int Wo, int k, int stride, int* tc, int* pxb, int* n_cchunk, int* grid_x, int* xb) {
   const int C4 = C / 4;
@@ -467,12 +469,10 @@ void launch_dw(DwArgs a, int rows, int k, int stride, hipStream_t s) {
   threads = (threads + 63) / 64 * 64;
   const dim3 grid(gx, gy, rows * a.n_cchunk), block(threads);
   const size_t lds = ((size_t)k * k * a.tc + threads) * sizeof(float4);
-  if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_kernel<3, 1, 4>), grid, block, lds, s, a);
-  else if (k == 3 && stride == 2) hipLaunchKernelGGL((dw_kernel<3, 2, 2>), grid, block, lds, s, a);
-  else if (k == 5 && stride == 1 && xb == 1) hipLaunchKernelGGL((dw_kernel<5, 1, 1>), grid, block, lds, s, a);
-  else if (k == 5 && stride == 2 && xb == 1) hipLaunchKernelGGL((dw_kernel<5, 2, 1>), grid, block, lds, s, a);
-  else if (k == 5 && stride == 1) hipLaunchKernelGGL((dw_kernel<5, 1, 2>), grid, block, lds, s, a);
-  else if (k == 5 && stride == 2) hipLaunchKernelGGL((dw_kernel<5, 2, 2>), grid, block, lds, s, a);
+  if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_kernel<3, 1, 4, 0>), grid, block, lds, s, a);
+  else if (k == 3 && stride == 2) hipLaunchKernelGGL((dw_kernel<3, 2, 2, 0>), grid, block, lds, s, a);
+  else if (k == 5 && stride == 1) hipLaunchKernelGGL((dw_kernel<5, 1, 1, 2>), grid, block, lds, s, a);
+  else hipLaunchKernelGGL((dw_kernel<5, 2, 1, 3>), grid, block, lds, s, a);
 }
 
 // ------------------------------------------------------------------------------------ squeeze-excite

@@ -29,8 +29,7 @@ def dw_tiles_x(C, Wo, k, stride):
     ncc = (C4 + 63) // 64
     t = (C4 + ncc - 1) // ncc
     p = max(1, 256 // t)
-    import os
-    x = int(os.environ.get("UDA_DW5_XB", "1")) if k == 5 else (4 if stride == 1 else 2)
+    x = 1 if k == 5 else (4 if stride == 1 else 2)
     p = min(p, (Wo + x - 1) // x)
     return (Wo + p * x - 1) // (p * x)
 
