@@ -12,10 +12,11 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
-stats = glob.glob(os.path.join(root, "gpurun_out", tag + "_stats", "*", "*kernel_stats.csv"))[0]
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
+stats = newest(os.path.join(root, "gpurun_out", tag + "_stats", "*", "*kernel_stats.csv"))
 shutil.copy(stats, os.path.join(out, tag + "_kernel_stats.csv"))
-fetch = glob.glob(os.path.join(root, "gpurun_out", tag + "_fetch", "*", "*counter_collection.csv"))[0]
-write = glob.glob(os.path.join(root, "gpurun_out", tag + "_write", "*", "*counter_collection.csv"))[0]
+fetch = newest(os.path.join(root, "gpurun_out", tag + "_fetch", "*", "*counter_collection.csv"))
+write = newest(os.path.join(root, "gpurun_out", tag + "_write", "*", "*counter_collection.csv"))
 traffic = os.path.join(out, tag + "_traffic.json")
 subprocess.check_call([sys.executable, os.path.join(root, "tools", "traffic_from_pmc.py"), fetch, write, traffic])
 t = json.load(open(traffic))
