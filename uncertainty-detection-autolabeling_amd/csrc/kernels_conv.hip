@@ -13,6 +13,7 @@
 //
 // Wavefront = 64.  The pointwise GEMM uses v_mfma_f32_32x32x2_f32 (exact f32, runs at the
 // f32 vector rate); everything else is HBM-bound streaming with 16-byte accesses.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "uda_internal.h"
@@ -676,13 +677,20 @@ __global__ __launch_bounds__(256) void mbx_kernel(MbxArgs a) {
   constexpr int XW = TW / GPR;                // outputs per thread along x
   constexpr int NCOL = (XW - 1) * S + K;
   extern __shared__ float mlds[];
-  float* X = mlds;                            // [Cin][XS]
-  float* E = mlds + (size_t)a.Cin * XS;       // [NPP][ES]
+  float* X = mlds;                            // [Cin + 2][XS]: row Cin = 1 inside the image else 0, row Cin+1 = 0
+  float* E = mlds + (size_t)(a.Cin + 2) * XS; // [NPP][ES]
   float* red = E + (size_t)NPP * ES;          // [8][32]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, b_in = b / a.in_div;
+  // diagnostic build only: wave-0 / wave-3 phase stamps of a few blocks (never set in production)
+  unsigned long long* stp = nullptr;
+  int stn = 0;
+  if (a.stamps && (lane == 0) && (wave == 0 || wave == 3) && blockIdx.x == 3 && blockIdx.y == 5 && blockIdx.z < 8)
+    stp = a.stamps + ((size_t)blockIdx.z * 2 + (wave == 3)) * 64;
+#define MBX_STAMP() do { if (stp && stn < 64) stp[stn++] = clock64(); } while (0)
+  MBX_STAMP();
   const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
   const int iy0 = oy0 * S - a.pad_t, ix0 = ox0 * S - a.pad_l;
   const float* xin = a.in + (size_t)b_in * a.H * a.W * a.Cin;
@@ -713,21 +721,17 @@ __global__ __launch_bounds__(256) void mbx_kernel(MbxArgs a) {
       }
     }
   }
-  // which of this lane's 16 accumulator rows of each of its row tiles lie inside the image
-  unsigned inmask[MT_PER_WAVE];
-#pragma unroll
-  for (int t = 0; t < MT_PER_WAVE; ++t) {
-    const int mt = wave + 4 * t;
-    unsigned m = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int p = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int iy = iy0 + p / IW, ix = ix0 + p % IW;
-      if (mt < NMT && p < NP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) m |= 1u << r;
-    }
-    inmask[t] = m;
+  // The BN shift rides on an extra input channel that is 1 inside the image and 0 in the halo /
+  // padding: acc = sum_k x_k (w_k * scale) + inside * shift, so a position outside the image gives
+  // exactly swish(0) = 0 — the zero padding TF applies to the depthwise INPUT — with no per-element test.
+  for (int p = tid; p < NPP; p += 256) {
+    const int iy = iy0 + p / IW, ix = ix0 + p % IW;
+    X[(size_t)a.Cin * XS + p] = (p < NP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? 1.f : 0.f;
+    X[(size_t)(a.Cin + 1) * XS + p] = 0.f;
   }
+  MBX_STAMP();
   __syncthreads();
+  MBX_STAMP();
 
   const int c = tid & 31, g = tid >> 5;       // depthwise stage: channel within the chunk, thread group
   const int orow = g / GPR, oxs = (g % GPR) * XW;
@@ -739,18 +743,18 @@ __global__ __launch_bounds__(256) void mbx_kernel(MbxArgs a) {
   // its output stores: the next expand phase then waits with a counted vmcnt on loads that are
   // older than those stores instead of draining them (vmcnt retires loads and stores in order).
   struct ChunkParams {
-    float bf[KS];
-    float sc0, sh0, mk0;
+    float bf[KS + 1];       // bf[KS]: the (inside, 0) row pair -> BN shift for lh == 0, 0 for lh == 1
+    float mk0;
     float wk[K * K];
     float sc1, sh1, mk1;
   };
   auto load_params = [&](int c0, ChunkParams& q) {
     const int ecol = c0 + li;
     const bool eok = ecol < a.Cmid;
+    const float sc = eok ? a.sc0[ecol] : 0.f;
 #pragma unroll
-    for (int s2 = 0; s2 < KS; ++s2) q.bf[s2] = eok ? a.we[(size_t)(2 * s2 + lh) * a.Cmid + ecol] : 0.f;
-    q.sc0 = eok ? a.sc0[ecol] : 0.f;
-    q.sh0 = eok ? a.sh0[ecol] : 0.f;
+    for (int s2 = 0; s2 < KS; ++s2) q.bf[s2] = eok ? a.we[(size_t)(2 * s2 + lh) * a.Cmid + ecol] * sc : 0.f;
+    q.bf[KS] = (eok && lh == 0) ? a.sh0[ecol] : 0.f;
     q.mk0 = (eok && a.mask0) ? a.mask0[(size_t)b * a.Cmid + ecol] : 1.f;
     const int dcol_ = c0 + c;
     const bool dok = dcol_ < a.Cmid;
@@ -766,9 +770,9 @@ __global__ __launch_bounds__(256) void mbx_kernel(MbxArgs a) {
   for (int c0 = 0; c0 < a.Cmid; c0 += 32) {
     const int col = c0 + c;
     const bool dcol = col < a.Cmid;
-    float (&bfr)[KS] = cur.bf;
+    float (&bfr)[KS + 1] = cur.bf;
     float (&wk)[K * K] = cur.wk;
-    const float sc0 = cur.sc0, sh0 = cur.sh0, mk0 = cur.mk0;
+    const float mk0 = cur.mk0;
     const float sc1 = cur.sc1, sh1 = cur.sh1, mk1 = cur.mk1;
 
     // ---- expand: E[p][j] = swish(bn0(sum_k X[k][p] * We[k][c0 + j])) * mask0, zero outside the image
@@ -781,20 +785,18 @@ __global__ __launch_bounds__(256) void mbx_kernel(MbxArgs a) {
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const float* xa = X + (size_t)lh * XS + mt * 32 + li;
 #pragma unroll
-        for (int s2 = 0; s2 < KS; ++s2)
+        for (int s2 = 0; s2 <= KS; ++s2)
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[(size_t)2 * s2 * XS], bfr[s2], acc, 0, 0, 0);
         float* ep = E + (size_t)(mt * 32 + 4 * lh) * ES + li;
-        const unsigned im = inmask[t];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = swishf(fmaf(acc[r], sc0, sh0)) * mk0;
-          ep[((r & 3) + 8 * (r >> 2)) * ES] = ((im >> r) & 1u) ? v : 0.f;
-        }
+        for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swishf(acc[r]) * mk0;
       }
     }
     // operands of the NEXT chunk: in flight during the depthwise phase, older than its stores
     if (c0 + 32 < a.Cmid) load_params(c0 + 32, nxt);
+    MBX_STAMP();
     __syncthreads();
+    MBX_STAMP();
     // ---- depthwise on E for channel c0 + c
     float ssum = 0.f;
     if (dcol && oy < a.Ho) {
@@ -823,6 +825,7 @@ __global__ __launch_bounds__(256) void mbx_kernel(MbxArgs a) {
         }
       }
     }
+    MBX_STAMP();
     if (a.se_partial) {
       red[g * 32 + c] = ssum;
       __syncthreads();
@@ -834,8 +837,10 @@ __global__ __launch_bounds__(256) void mbx_kernel(MbxArgs a) {
       }
     }
     __syncthreads();   // E (and red) are rewritten by the next channel chunk
+    MBX_STAMP();
     cur = nxt;
   }
+#undef MBX_STAMP
 }
 
 bool mbx_supported(int Cin, int Cmid, int k, int stride) {
@@ -854,7 +859,7 @@ static void launch_mbx_t(const MbxArgs& a, int rows, hipStream_t s) {
   constexpr int TH = mbx_cfg(K, S).th, TW = mbx_cfg(K, S).tw;
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
   constexpr int NPP = (IH * IW + 31) / 32 * 32;
-  const size_t lds = ((size_t)a.Cin * (NPP + 1) + (size_t)NPP * 33 + 256) * sizeof(float);
+  const size_t lds = ((size_t)(a.Cin + 2) * (NPP + 1) + (size_t)NPP * 33 + 256) * sizeof(float);
   static size_t attr_lds = 64 * 1024;      // above the default limit the kernel needs an explicit opt-in
   if (lds > attr_lds) {
     hipFuncSetAttribute((const void*)mbx_kernel<K, S, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -875,7 +880,28 @@ static void launch_mbx_ks(const MbxArgs& a, int rows, hipStream_t s) {
   }
 }
 
-void launch_mbx(const MbxArgs& a, int rows, int k, int stride, hipStream_t s) {
+void launch_mbx(const MbxArgs& a0, int rows, int k, int stride, hipStream_t s) {
+  MbxArgs a = a0;
+  static unsigned long long* d_stamps = nullptr;
+  static int want = -1;
+  if (want < 0) { const char* e = getenv("UDA_MBX_STAMPS"); want = e ? atoi(e) : 0; }
+  if (want) {   // diagnostic: dump the stamps of the previous launch, then arm this one
+    static unsigned long long h[8 * 2 * 64];
+    if (!d_stamps) { hipMalloc((void**)&d_stamps, sizeof(h)); hipMemset(d_stamps, 0, sizeof(h)); }
+    else {
+      hipStreamSynchronize(s);
+      hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost);
+      for (int bz = 0; bz < 2; ++bz)
+        for (int w = 0; w < 2; ++w) {
+          fprintf(stderr, "[mbx stamps z=%d wave%d]", bz, w ? 3 : 0);
+          for (int i = 1; i < 64 && h[(bz * 2 + w) * 64 + i]; ++i)
+            fprintf(stderr, " %llu", h[(bz * 2 + w) * 64 + i] - h[(bz * 2 + w) * 64 + i - 1]);
+          fprintf(stderr, "\n");
+        }
+      hipMemset(d_stamps, 0, sizeof(h));
+    }
+    a.stamps = d_stamps;
+  }
   if (k == 3 && stride == 1) launch_mbx_ks<3, 1>(a, rows, s);
   else if (k == 3 && stride == 2) launch_mbx_ks<3, 2>(a, rows, s);
   else if (k == 5 && stride == 1) launch_mbx_ks<5, 1>(a, rows, s);

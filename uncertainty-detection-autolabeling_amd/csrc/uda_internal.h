@@ -69,7 +69,7 @@ struct MbxArgs {
   int pad_t, pad_l;
   int in_div;
   int n_tiles;
-  int debug;              // ablation switches (UDA_MBX_DEBUG), 0 in production
+  unsigned long long* stamps;  // diagnostic phase stamps (UDA_MBX_STAMPS); null in production
 };
 void launch_mbx(const MbxArgs& a, int rows, int k, int stride, hipStream_t s);
 int mbx_tiles(int Ho, int Wo, int k, int stride);
