@@ -177,6 +177,12 @@ int uda_get_head_outputs(uda_ctx_t* ctx, int32_t level, float* cls, float* box);
 /* Inject head outputs (same layout) and run only the post-process on them. */
 int uda_set_head_outputs(uda_ctx_t* ctx, int32_t level, int32_t n, const float* cls, const float* box);
 int uda_postprocess_heads(uda_ctx_t* ctx, int32_t n, const float* image_scales, int32_t post_mode);
+/* Deep ensembles (BASELINE configs[3]; the reference has no ensemble code): copy the
+ * head outputs of the last run of `src` (a deterministic member network, T = 1) into sample slot
+ * `sample` of `dst` (a handle whose model has mc_samples = number of members and stacked heads);
+ * uda_postprocess_heads(dst) then aggregates the members exactly like MC samples (a8 / a14).
+ * Device-to-device on dst's stream; both handles must live on the same GPU and share the geometry. */
+int uda_copy_heads(uda_ctx_t* dst, const uda_ctx_t* src, int32_t n, int32_t sample);
 /* predict = set_images_f32 + run(no post) ; read back with uda_get_head_outputs */
 int uda_predict(uda_ctx_t* ctx, const float* images, int32_t n);
 

@@ -37,16 +37,3 @@ def make_weights(params, seed=1, cls_spread=1.0):
 
 def make_images(n, h, w, seed=0):
     return np.random.default_rng(seed).integers(0, 256, (n, h, w, 3), dtype=np.uint8)
-
-
-def have_gpu():
-    try:
-        from uda_amd import capi
-        if not os.path.exists(capi.LIB_PATH):
-            return False
-        import ctypes
-        hip = ctypes.CDLL("libamdhip64.so")
-        n = ctypes.c_int(0)
-        return hip.hipGetDeviceCount(ctypes.byref(n)) == 0 and n.value > 0
-    except Exception:
-        return False

@@ -340,3 +340,73 @@ def test_image_sharded_serve_equals_unsharded(tmp_path):
         got = [z["arr_%d" % i] for i in range(len(want))]
         for g, r in zip(got, want):
             np.testing.assert_array_equal(g, r)
+
+
+def test_deep_ensemble_matches_oracle_aggregation():
+    """BASELINE configs[3]: M independently initialised members, aggregated like MC samples."""
+    from oracle import effdet_ref as E, post_ref as P, preprocess_ref as PP
+    from uda_amd.infer_lib import EnsembleDriver
+    p = make_params(**LOSS_ATT)
+    ws = [make_weights(p, seed=40 + m, cls_spread=20.0) for m in range(3)]
+    imgs = make_images(2, 100, 180, seed=44)
+    ens = EnsembleDriver(ws, p["name"], batch_size=2, model_params=p)
+    got = ens.serve(imgs)
+    x, scales = PP.preprocess(imgs, (128, 192), p["mean_rgb"], p["stddev_rgb"])
+    outs = [E.forward_once(w, p, x) for w in ws]
+    pm = dict(p, mc_dropout=True, mc_dropoutrate=1e-9, mc_dropoutsamp=3)
+    # bit-exact aggregation given the members' GPU heads
+    heads = [m.head_outputs(2) for m in ens.members]
+    cls_g = [np.stack([heads[m][0][l] for m in range(3)]) for l in range(5)]
+    box_g = [np.stack([heads[m][1][l] for m in range(3)]) for l in range(5)]
+    want_exact = P.postprocess_global(pm, cls_g, box_g, scales)
+    assert len(got) == len(want_exact) and got[0].shape == (2, 100, 12) and got[2].shape == (2, 100, 8)
+    for g, r in zip(got, want_exact):
+        np.testing.assert_array_equal(g, r)
+    # and the members' heads match the oracle networks
+    for m in range(3):
+        for l in range(5):
+            for g, r in ((heads[m][0][l], outs[m][0][l]), (heads[m][1][l], outs[m][1][l])):
+                assert np.abs(g - r).max() <= 2e-4 * np.abs(r).max() + 1e-6
+    ens.close()
+
+
+def test_bdd_like_padding_and_ten_classes():
+    """BASELINE configs[2]-shaped input: 10 classes, raw height below the network height (scale 1, zero rows padded)."""
+    from oracle import post_ref as P, preprocess_ref as PP
+    p = make_params(num_classes=10, **FULL_MC)
+    w = make_weights(p, seed=51, cls_spread=20.0)
+    imgs = make_images(2, 120, 192, seed=52)
+    d = _driver(p, w, 2)
+    d.set_dropout_seed(3)
+    det = d.serve(imgs)
+    got, scales = d.preprocessed()
+    x, wscales = PP.preprocess(imgs, (128, 192), p["mean_rgb"], p["stddev_rgb"])
+    assert np.all(scales == 1.0) and np.array_equal(got, x) and np.all(got[:, 120:] == 0)
+    cls, box = d.head_outputs(2)
+    assert cls[0].shape[-1] == 90 and det[2].shape == (2, 100, 11) and det[4].shape == (2, 100, 10)
+    (rcls, rbox), _ = _oracle_net(p, w, x, 3)
+    _check_heads(cls, rcls)
+    want = P.postprocess_global(p, cls, box, wscales)
+    for g, r in zip(det, want):
+        np.testing.assert_array_equal(g, r)
+    d.close()
+
+
+def test_d2_per_class_topk_config5_shape():
+    """BASELINE configs[4]-shaped: D2, MC dropout, l-norm decode, per-class NMS with max_nms_inputs (eval settings)."""
+    from oracle import post_ref as P, preprocess_ref as PP
+    over = dict(FULL_MC, **TOPK)
+    p = make_params(model="efficientdet-d2", image_size="128x128", **over)
+    w = make_weights(p, seed=61, cls_spread=20.0)
+    imgs = make_images(1, 128, 128, seed=62)
+    d = _driver(p, w, 1)
+    d.set_dropout_seed(8)
+    det = d.serve(imgs, post_mode="per_class")
+    cls, box = d.head_outputs(1)
+    x, scales = PP.preprocess(imgs, (128, 128), p["mean_rgb"], p["stddev_rgb"])
+    (rcls, rbox), _ = _oracle_net(p, w, x, 8)
+    _check_heads(cls, rcls)
+    want = P.postprocess_per_class(p, cls, box, scales)
+    for g, r in zip(det, want):
+        np.testing.assert_array_equal(g, r)
+    d.close()

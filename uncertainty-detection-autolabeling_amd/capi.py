@@ -83,6 +83,7 @@ _SIGNATURES = {
     "uda_get_head_outputs": (C.c_int, [_P, C.c_int32, _P, _P]),
     "uda_set_head_outputs": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
     "uda_postprocess_heads": (C.c_int, [_P, C.c_int32, _P, C.c_int32]),
+    "uda_copy_heads": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     "uda_predict": (C.c_int, [_P, _P, C.c_int32]),
     "uda_get_candidates": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "uda_num_candidates": (C.c_int32, [_P]),

@@ -910,6 +910,34 @@ extern "C" int uda_set_head_outputs(uda_ctx_t* c, int32_t level, int32_t n, cons
   return 0;
 }
 
+extern "C" int uda_copy_heads(uda_ctx_t* dst, const uda_ctx_t* src, int32_t n, int32_t sample) {
+  if (!dst || !src) return 1;
+  const uda_model_t& md = dst->model;
+  const uda_model_t& ms = src->model;
+  if (dst->device != src->device) return fail(dst, "copy_heads: handles live on different devices");
+  if (md.num_levels != ms.num_levels || dst->cls_ch != src->cls_ch || dst->box_ch != src->box_ch)
+    return fail(dst, "copy_heads: head geometry differs");
+  if (ms.cls_stacked || ms.box_stacked) return fail(dst, "copy_heads: the source must be a deterministic (unstacked) network");
+  if (!md.cls_stacked || !md.box_stacked) return fail(dst, "copy_heads: the destination must stack both heads");
+  if (sample < 0 || sample >= md.mc_samples) return fail(dst, "copy_heads: sample %d outside [0, %d)", sample, md.mc_samples);
+  if (n < 1 || n > md.max_images || n > ms.max_images) return fail(dst, "copy_heads: n=%d", n);
+  HIPC(dst, hipSetDevice(dst->device));
+  HIPC(dst, hipStreamSynchronize(src->stream));       // the member's heads must be complete
+  const int T = md.mc_samples;
+  for (int l = 0; l < md.num_levels; ++l) {
+    if (md.level_h[l] != ms.level_h[l] || md.level_w[l] != ms.level_w[l]) return fail(dst, "copy_heads: level %d size differs", l);
+    const size_t hw = (size_t)md.level_h[l] * md.level_w[l];
+    const size_t cb = hw * dst->cls_ch * sizeof(float), bb = hw * dst->box_ch * sizeof(float);
+    // dst rows are [image][sample]: row pitch T * bytes; src rows are [image]: pitch bytes
+    HIPC(dst, hipMemcpy2DAsync(dst->d_cls[l] + (size_t)sample * hw * dst->cls_ch, (size_t)T * cb, src->d_cls[l], cb, cb, n,
+                               hipMemcpyDeviceToDevice, dst->stream));
+    HIPC(dst, hipMemcpy2DAsync(dst->d_box[l] + (size_t)sample * hw * dst->box_ch, (size_t)T * bb, src->d_box[l], bb, bb, n,
+                               hipMemcpyDeviceToDevice, dst->stream));
+  }
+  dst->n_images = n;
+  return 0;
+}
+
 extern "C" int uda_postprocess_heads(uda_ctx_t* c, int32_t n, const float* image_scales, int32_t post_mode) {
   if (!c) return 1;
   if (n < 1 || n > c->model.max_images) return fail(c, "postprocess_heads: n=%d", n);

@@ -261,6 +261,12 @@ class ServingDriver:
         self._ck(self._lib.uda_get_preprocessed(self._h, _ptr(imgs), _ptr(scales)), "uda_get_preprocessed")
         return imgs, scales
 
+    def preprocessed_scales(self, n):
+        """(None, image scales [n]) of the last uint8 batch (host-side copy kept by the handle)."""
+        scales = np.empty((max(n, self.batch_size),), np.float32)
+        self._ck(self._lib.uda_get_preprocessed(self._h, None, _ptr(scales)), "uda_get_preprocessed")
+        return None, scales[:n]
+
     def _n_last(self):
         return getattr(self, "_last_n", self.batch_size)
 
@@ -362,3 +368,50 @@ class ServingDriver:
 # the reference's concrete driver names resolve to the same implementation
 KerasDriver = ServingDriver
 SavedModelDriver = ServingDriver
+
+
+class EnsembleDriver:
+    """Deep ensemble of M independently initialised / trained detectors (BASELINE configs[3]).
+
+    The reference has no ensemble code: this is the build's extension, defined as
+    "aggregate the members exactly like MC samples" — class logits: mean / population std over
+    members (a8); boxes: per-member decode, mean / std of the corners, mean of the decoded sigma
+    (a14); then the same NMS.  Each member is a deterministic network (no dropout) on its own
+    handle; their head outputs are copied device-to-device into the sample slots of a
+    post-processing handle whose sample axis has length M.
+    """
+
+    def __init__(self, member_weights, model_name="efficientdet-d0", batch_size=1, model_params=None, device=0,
+                 chunk_images=None):
+        params = dict(model_params or {})
+        if params.get("mc_dropout"):
+            raise ValueError("ensemble members are deterministic networks: mc_dropout must be off")
+        self.members = [ServingDriver("_", False, model_name, batch_size=batch_size, model_params=params, weights=w,
+                                      device=device, chunk_images=chunk_images) for w in member_weights]
+        M = len(self.members)
+        if M < 2:
+            raise ValueError("an ensemble needs at least two members")
+        # the aggregator only post-processes: it is planned as an M-sample MC model of the same geometry
+        post_params = dict(params, mc_dropout=True, mc_dropoutrate=1e-9, mc_dropoutsamp=M)
+        self.post = ServingDriver("_", False, model_name, batch_size=batch_size, model_params=post_params,
+                                  weights=member_weights[0], device=device, chunk_images=1)
+        self.params = self.post.params
+        self.batch_size = batch_size
+
+    def serve(self, image_arrays, post_mode=None):
+        a = self.members[0]._as_u8_batch(image_arrays)
+        n, h, w = a.shape[:3]
+        lib = self.post._lib
+        for m, drv in enumerate(self.members):
+            drv._ck(lib.uda_set_images_u8(drv._h, _ptr(a), n, h, w), "uda_set_images_u8")
+            drv._ck(lib.uda_run(drv._h, -1, 0), "uda_run")
+            self.post._ck(lib.uda_copy_heads(self.post._h, drv._h, n, m), "uda_copy_heads")
+        _, scales = self.members[0].preprocessed_scales(n)
+        mode = self.post._mode(post_mode)
+        s = np.ascontiguousarray(scales, dtype=np.float32)
+        self.post._ck(lib.uda_postprocess_heads(self.post._h, n, _ptr(s), mode), "uda_postprocess_heads")
+        return self.post._collect(n, mode)
+
+    def close(self):
+        for d in self.members + [self.post]:
+            d.close()
