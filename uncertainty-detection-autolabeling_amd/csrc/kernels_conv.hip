@@ -663,23 +663,25 @@ __host__ __device__ constexpr MbxCfg mbx_cfg(int k, int s) {
 }
 }  // namespace
 
-template <int K, int S, int KS>   // KS = Cin / 2 MFMA k-steps (compile-time: the operand registers are indexed statically)
-__global__ __launch_bounds__(256) void mbx_kernel(MbxArgs a) {
+template <int K, int S, int KS, int NW>   // KS = Cin / 2 MFMA k-steps; NW = waves per block (4 or 8)
+__global__ __launch_bounds__(NW * 64) void mbx_kernel(MbxArgs a) {
   constexpr int TH = mbx_cfg(K, S).th, TW = mbx_cfg(K, S).tw;
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
   constexpr int NP = IH * IW;
   constexpr int NPP = (NP + 31) / 32 * 32;
   constexpr int NMT = NPP / 32;               // MFMA row tiles of the input tile
-  constexpr int MT_PER_WAVE = (NMT + 3) / 4;
+  constexpr int NTH = NW * 64;                // threads per block
+  constexpr int NG = NTH / 32;                // depthwise thread groups (32 channels each)
+  constexpr int MT_PER_WAVE = (NMT + NW - 1) / NW;
   constexpr int XS = NPP + 1;                 // X row stride (floats)
   constexpr int ES = 33;                      // E row stride
-  constexpr int GPR = 8 / TH;                 // thread groups per output row (8 groups of 32 channels)
+  constexpr int GPR = NG / TH;                // thread groups per output row
   constexpr int XW = TW / GPR;                // outputs per thread along x
   constexpr int NCOL = (XW - 1) * S + K;
   extern __shared__ float mlds[];
   float* X = mlds;                            // [Cin + 2][XS]: row Cin = 1 inside the image else 0, row Cin+1 = 0
   float* E = mlds + (size_t)(a.Cin + 2) * XS; // [NPP][ES]
-  float* red = E + (size_t)NPP * ES;          // [8][32]
+  float* red = E + (size_t)NPP * ES;          // [NG][32]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -687,8 +689,8 @@ __global__ __launch_bounds__(256) void mbx_kernel(MbxArgs a) {
   // diagnostic build only: wave-0 / wave-3 phase stamps of a few blocks (never set in production)
   unsigned long long* stp = nullptr;
   int stn = 0;
-  if (a.stamps && (lane == 0) && (wave == 0 || wave == 3) && blockIdx.x == 3 && blockIdx.y == 5 && blockIdx.z < 8)
-    stp = a.stamps + ((size_t)blockIdx.z * 2 + (wave == 3)) * 64;
+  if (a.stamps && (lane == 0) && (wave == 0 || wave == NW - 1) && blockIdx.x == 3 && blockIdx.y == 5 && blockIdx.z < 8)
+    stp = a.stamps + ((size_t)blockIdx.z * 2 + (wave != 0)) * 64;
 #define MBX_STAMP() do { if (stp && stn < 64) stp[stn++] = clock64(); } while (0)
   MBX_STAMP();
   const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
@@ -698,12 +700,12 @@ __global__ __launch_bounds__(256) void mbx_kernel(MbxArgs a) {
   // ---- stage the input tile (zero outside the image / beyond NP); loads are issued 4 deep
   const int cq = a.Cin >> 2;
   const int nf = NPP * cq;
-  for (int f0 = tid; f0 < nf; f0 += 4 * 256) {
+  for (int f0 = tid; f0 < nf; f0 += 4 * NTH) {
     float4 v[4];
     int pp[4], qq[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int f = f0 + u * 256;
+      const int f = f0 + u * NTH;
       v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       pp[u] = f / cq;
       qq[u] = f - pp[u] * cq;
@@ -715,7 +717,7 @@ __global__ __launch_bounds__(256) void mbx_kernel(MbxArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      if (f0 + u * 256 < nf) {
+      if (f0 + u * NTH < nf) {
         float* xp = X + (size_t)(4 * qq[u]) * XS + pp[u];
         xp[0] = v[u].x; xp[XS] = v[u].y; xp[2 * XS] = v[u].z; xp[3 * XS] = v[u].w;
       }
@@ -724,7 +726,7 @@ __global__ __launch_bounds__(256) void mbx_kernel(MbxArgs a) {
   // The BN shift rides on an extra input channel that is 1 inside the image and 0 in the halo /
   // padding: acc = sum_k x_k (w_k * scale) + inside * shift, so a position outside the image gives
   // exactly swish(0) = 0 — the zero padding TF applies to the depthwise INPUT — with no per-element test.
-  for (int p = tid; p < NPP; p += 256) {
+  for (int p = tid; p < NPP; p += NTH) {
     const int iy = iy0 + p / IW, ix = ix0 + p % IW;
     X[(size_t)a.Cin * XS + p] = (p < NP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? 1.f : 0.f;
     X[(size_t)(a.Cin + 1) * XS + p] = 0.f;
@@ -778,7 +780,7 @@ __global__ __launch_bounds__(256) void mbx_kernel(MbxArgs a) {
     // ---- expand: E[p][j] = swish(bn0(sum_k X[k][p] * We[k][c0 + j])) * mask0, zero outside the image
 #pragma unroll
     for (int t = 0; t < MT_PER_WAVE; ++t) {
-      const int mt = wave + 4 * t;
+      const int mt = wave + NW * t;
       if (mt < NMT) {
         f32x16 acc;
 #pragma unroll
@@ -832,7 +834,7 @@ __global__ __launch_bounds__(256) void mbx_kernel(MbxArgs a) {
       if (g == 0 && dcol) {
         float t = red[c];
 #pragma unroll
-        for (int gg = 1; gg < 8; ++gg) t += red[gg * 32 + c];
+        for (int gg = 1; gg < NG; ++gg) t += red[gg * 32 + c];
         a.se_partial[((size_t)b * a.n_tiles + tile) * a.Cmid + col] = t;
       }
     }
@@ -854,30 +856,38 @@ int mbx_tiles(int Ho, int Wo, int k, int stride) {
   return ((Ho + c.th - 1) / c.th) * ((Wo + c.tw - 1) / c.tw);
 }
 
-template <int K, int S, int KS>
+template <int K, int S, int KS, int NW>
 static void launch_mbx_t(const MbxArgs& a, int rows, hipStream_t s) {
   constexpr int TH = mbx_cfg(K, S).th, TW = mbx_cfg(K, S).tw;
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
   constexpr int NPP = (IH * IW + 31) / 32 * 32;
-  const size_t lds = ((size_t)(a.Cin + 2) * (NPP + 1) + (size_t)NPP * 33 + 256) * sizeof(float);
+  const size_t lds = ((size_t)(a.Cin + 2) * (NPP + 1) + (size_t)NPP * 33 + NW * 64) * sizeof(float);
   static size_t attr_lds = 64 * 1024;      // above the default limit the kernel needs an explicit opt-in
   if (lds > attr_lds) {
-    hipFuncSetAttribute((const void*)mbx_kernel<K, S, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)mbx_kernel<K, S, KS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_lds = lds;
   }
   const dim3 grid((a.Wo + TW - 1) / TW, (a.Ho + TH - 1) / TH, rows);
-  hipLaunchKernelGGL((mbx_kernel<K, S, KS>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((mbx_kernel<K, S, KS, NW>), grid, dim3(NW * 64), lds, s, a);
+}
+
+template <int K, int S, int NW>
+static void launch_mbx_nw(const MbxArgs& a, int rows, hipStream_t s) {
+  switch (a.Cin) {
+    case 16: launch_mbx_t<K, S, 8, NW>(a, rows, s); break;
+    case 24: launch_mbx_t<K, S, 12, NW>(a, rows, s); break;
+    case 32: launch_mbx_t<K, S, 16, NW>(a, rows, s); break;
+    case 40: launch_mbx_t<K, S, 20, NW>(a, rows, s); break;
+    default: launch_mbx_t<K, S, 24, NW>(a, rows, s); break;   // 48
+  }
 }
 
 template <int K, int S>
 static void launch_mbx_ks(const MbxArgs& a, int rows, hipStream_t s) {
-  switch (a.Cin) {
-    case 16: launch_mbx_t<K, S, 8>(a, rows, s); break;
-    case 24: launch_mbx_t<K, S, 12>(a, rows, s); break;
-    case 32: launch_mbx_t<K, S, 16>(a, rows, s); break;
-    case 40: launch_mbx_t<K, S, 20>(a, rows, s); break;
-    default: launch_mbx_t<K, S, 24>(a, rows, s); break;   // 48
-  }
+  static int nw = -1;
+  if (nw < 0) { const char* e = getenv("UDA_MBX_WAVES"); nw = e ? atoi(e) : 4; }
+  if (nw == 4) launch_mbx_nw<K, S, 4>(a, rows, s);
+  else launch_mbx_nw<K, S, 8>(a, rows, s);
 }
 
 void launch_mbx(const MbxArgs& a0, int rows, int k, int stride, hipStream_t s) {
