@@ -92,15 +92,16 @@ void launch_stem(const StemArgs& a, hipStream_t s) {
 //  * epilogue: accumulators go through a wave-private LDS tile so that every lane stores 16
 //    contiguous bytes (a 64-channel row segment = 256 contiguous bytes per 16 lanes), with
 //    bias / BN / swish / dropout keep-scale / residual applied on the float4.
-constexpr int PW_BM = 128, PW_BK = 32;
+constexpr int PW_BK = 32;
 constexpr int PW_STG = 68;  // staging row stride (floats): 64 columns + 4 pad
 
-template <int NT>
-__global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
-  constexpr int BM = PW_BM, BK = PW_BK, BN = 32 * NT;
+template <int NT, int NW>   // NT 32-column tiles per wave, NW waves (32 pixel rows each) per block
+__global__ __launch_bounds__(NW * 64) void pw_kernel(PwArgs a) {
+  constexpr int NTH = NW * 64;
+  constexpr int BM = 32 * NW, BK = PW_BK, BN = 32 * NT;
   constexpr int A_FLOATS = BK * (BM + 1);
   constexpr int B_FLOATS = BK * BN;
-  constexpr int STG_FLOATS = 4 * 32 * PW_STG;
+  constexpr int STG_FLOATS = NW * 32 * PW_STG;
   constexpr int LDS_FLOATS = (A_FLOATS + B_FLOATS) > STG_FLOATS ? (A_FLOATS + B_FLOATS) : STG_FLOATS;
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   float(*As)[BM + 1] = (float(*)[BM + 1])lds;
@@ -120,8 +121,8 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 
-  constexpr int B_VEC_ITERS = (BK * BN / 4 + 255) / 256;
-  constexpr int B_SCL_ITERS = BK * BN / 256;
+  constexpr int B_VEC_ITERS = (BK * BN / 4 + NTH - 1) / NTH;
+  constexpr int B_SCL_ITERS = (BK * BN + NTH - 1) / NTH;
   float4 ra[4];
   float4 rb[B_VEC_ITERS];
   float4 rg = make_float4(1.f, 1.f, 1.f, 1.f);   // SE gate of this thread's 4 k columns (same for its 4 rows)
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
   auto load_chunk = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int f = tid + 256 * i;
+      const int f = tid + NTH * i;
       const int m = f >> 3, kq = f & 7;
       const int k = k0 + 4 * kq;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
     if (vecB) {
 #pragma unroll
       for (int i = 0; i < B_VEC_ITERS; ++i) {
-        const int f = tid + 256 * i;
+        const int f = tid + NTH * i;
         const int kk = f / (BN / 4), nq = f % (BN / 4);
         const int k = k0 + kk, col = n0 + 4 * nq;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
   auto store_chunk = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int f = tid + 256 * i;
+      const int f = tid + NTH * i;
       const int m = f >> 3, kq = f & 7;
       As[4 * kq + 0][m] = ra[i].x * rg.x;
       As[4 * kq + 1][m] = ra[i].y * rg.y;
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
     if (vecB) {
 #pragma unroll
       for (int i = 0; i < B_VEC_ITERS; ++i) {
-        const int f = tid + 256 * i;
+        const int f = tid + NTH * i;
         if (f < BK * BN / 4) {
           const int kk = f / (BN / 4), nq = f % (BN / 4);
           *(float4*)&Bs[kk][4 * nq] = rb[i];
@@ -174,10 +175,10 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
     } else {  // Cout not a multiple of 4 (class head: 9*7 = 63): scalar weight loads
 #pragma unroll
       for (int i = 0; i < B_SCL_ITERS; ++i) {
-        const int f = tid + 256 * i;
+        const int f = tid + NTH * i;
         const int kk = f / BN, n = f % BN;
         const int k = k0 + kk, col = n0 + n;
-        Bs[kk][n] = (k < a.Cin && col < a.Cout) ? a.w[(size_t)k * a.Cout + col] : 0.f;
+        if (f < BK * BN) Bs[kk][n] = (k < a.Cin && col < a.Cout) ? a.w[(size_t)k * a.Cout + col] : 0.f;
       }
     }
   };
@@ -290,8 +291,19 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
   }
 }
 
+template <int NW>
+static void launch_pw_nw(const PwArgs& a, int rows, int nt, hipStream_t s) {
+  const int gx = (a.HW + 32 * NW - 1) / (32 * NW);
+  const dim3 grid(gx, (a.Cout + 32 * nt - 1) / (32 * nt), rows), block(NW * 64);
+  switch (nt) {
+    case 1: hipLaunchKernelGGL((pw_kernel<1, NW>), grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((pw_kernel<2, NW>), grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((pw_kernel<3, NW>), grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((pw_kernel<4, NW>), grid, block, 0, s, a); break;
+  }
+}
+
 void launch_pw(const PwArgs& a, int rows, hipStream_t s) {
-  const int gx = (a.HW + PW_BM - 1) / PW_BM;
   // one pass over the columns when Cout <= 192, else the fewest passes of <= 6 column tiles
   static int maxnt = -1, maxnt_small = -1;
   if (maxnt < 0) {
@@ -303,16 +315,13 @@ void launch_pw(const PwArgs& a, int rows, hipStream_t s) {
   const int cap = 32 * (a.Cin <= 48 ? maxnt_small : maxnt);
   const int passes = (a.Cout + cap - 1) / cap;
   const int per = (a.Cout + passes - 1) / passes;
-  const int nt = (per + 31) / 32;
-  const dim3 grid(gx, (a.Cout + 32 * nt - 1) / (32 * nt), rows), block(256);
-  switch (nt) {
-    case 1: hipLaunchKernelGGL(pw_kernel<1>, grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL(pw_kernel<2>, grid, block, 0, s, a); break;
-    case 3: hipLaunchKernelGGL(pw_kernel<3>, grid, block, 0, s, a); break;
-    case 4: hipLaunchKernelGGL(pw_kernel<4>, grid, block, 0, s, a); break;
-    case 5: hipLaunchKernelGGL(pw_kernel<5>, grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL(pw_kernel<6>, grid, block, 0, s, a); break;
-  }
+  int nt = (per + 31) / 32;
+  if (nt > 4) nt = 4;
+  static int big = -1;
+  if (big < 0) { const char* e = getenv("UDA_PW_BIG"); big = e ? atoi(e) : 0; }
+  // 256-pixel blocks (8 waves) halve the weight-tile traffic per pixel; measured 6 % slower on the deep layers (off)
+  if (big && a.Cin >= 80 && a.HW >= 256) launch_pw_nw<8>(a, rows, nt, s);
+  else launch_pw_nw<4>(a, rows, nt, s);
 }
 
 // ------------------------------------------------------------------------------------ depthwise
