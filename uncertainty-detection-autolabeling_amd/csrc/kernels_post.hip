@@ -601,6 +601,8 @@ __global__ __launch_bounds__(256) void nms_eval_kernel(NmsArgs a, int k) {
 
 // C commit: the winner is selected; every candidate whose STALE priority outranks it is popped
 // once in this epoch (score <- updated score, begin <- k), exactly the reference's heap traffic.
+// The same pass then does the bound step of epoch k+1 (its chunk's best candidate by upper bound,
+// evaluated against the k+1 selected boxes), so an epoch costs two launches instead of three.
 __global__ __launch_bounds__(256) void nms_commit_kernel(NmsArgs a, int k) {
   __shared__ NmsLds L;
   const int n = blockIdx.y;
@@ -628,12 +630,18 @@ __global__ __launch_bounds__(256) void nms_commit_kernel(NmsArgs a, int k) {
     }
   }
   nms_run_list(a, L, base, k);      // (ends with a barrier: tent[] of this chunk is visible below)
+  unsigned long long best = 0ull;   // best upper bound left in this chunk, for the next epoch's bound
 #pragma unroll
   for (int it = 0; it < NMS_ITEMS; ++it) {
     const int i = i0 + it * 256 + threadIdx.x;
+    if (i >= a.K) continue;
+    float u = a.ub[base + i];
+    bool alive = a.stale[base + i] != -INFINITY;
     if (pop[it]) {
-      a.stale[base + i] = a.tent[base + i];
+      u = a.tent[base + i];
+      a.stale[base + i] = u;
       a.begin[base + i] = k;
+      alive = (u != -INFINITY);
     }
     if (i == widx) {
       const size_t o = (size_t)n * a.M + k;
@@ -646,7 +654,26 @@ __global__ __launch_bounds__(256) void nms_commit_kernel(NmsArgs a, int k) {
       a.sel_box[o * 4 + 3] = bx[3];
       a.stale[base + i] = -INFINITY;
       a.nsel[n] = k + 1;
+      alive = false;
     }
+    if (alive && u != -INFINITY) {
+      const unsigned long long key = nms_key(u, i);
+      best = key > best ? key : best;
+    }
+  }
+  if (k + 1 >= a.M) return;
+  best = block_max_key(best);
+  // bound of epoch k+1: selected box k is the winner's box (read from the candidate table: the
+  // sel_box row may be written by another block of this launch)
+  if (threadIdx.x < 4) L.sel[4 * k + threadIdx.x] = a.boxes[((size_t)(n / a.segs) * a.K + widx) * 4 + threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0 && best != 0ull) {
+    const int idx = (int)(0xFFFFFFFFu - (uint32_t)best);
+    const float s = nms_chain_eval(a, L, base, idx, k + 1);
+    a.tent[base + idx] = s;
+    a.ub[base + idx] = s;
+    a.ev[base + idx] = k + 1;
+    if (s != -INFINITY) atomicMax(&a.bound_key[(size_t)n * a.M + k + 1], nms_key(s, idx));
   }
 }
 
@@ -659,7 +686,7 @@ void launch_nms_init(const NmsArgs& a, const float* scores, hipStream_t s) {
 
 void launch_nms_epoch(const NmsArgs& a, int epoch, hipStream_t s) {
   const dim3 grid((a.K + NMS_CHUNK - 1) / NMS_CHUNK, a.n_img), block(256);
-  hipLaunchKernelGGL(nms_bound_kernel, grid, block, 0, s, a, epoch);
+  if (epoch == 0) hipLaunchKernelGGL(nms_bound_kernel, grid, block, 0, s, a, epoch);   // later bounds ride on the commit pass
   hipLaunchKernelGGL(nms_eval_kernel, grid, block, 0, s, a, epoch);
   hipLaunchKernelGGL(nms_commit_kernel, grid, block, 0, s, a, epoch);
 }
