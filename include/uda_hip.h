@@ -201,6 +201,16 @@ int uda_nms(uda_ctx_t* ctx, const float* boxes, const float* scores, int32_t n_i
             int32_t max_out, float iou_thresh, float score_thresh, float soft_sigma, int32_t pad,
             int32_t* idx, float* out_scores, int32_t* valid);
 
+/* Standalone 1x1 convolution on host arrays (op-level parity tests and timing of the pointwise kernels):
+ * out[r, p, :] = (act(bn(in[r / in_div, p, :] * se[r / in_div, :] @ w + bias)) * mask[r, :]) + res[r, p, :]
+ * in [rows/in_div, hw, cin], w [cin, cout], se [rows/in_div, cin], mask [rows, cout], res/out [rows, hw, cout];
+ * optional arguments may be NULL.  terms: 0 = f32-input MFMA, 3 / 6 = split-bf16 MFMA with 3 / 6 cross terms
+ * (kernels_pwb.hip).  The launch is repeated `reps` times for *avg_ms (HIP events). */
+int uda_debug_pw(int32_t device, const float* in, const float* w, const float* bias, const float* bn_scale,
+                 const float* bn_shift, const float* se, const float* mask, const float* res,
+                 int32_t rows, int32_t in_div, int32_t hw, int32_t cin, int32_t cout, int32_t act,
+                 int32_t terms, int32_t reps, float* out, float* avg_ms);
+
 /* Per-op-kind device timing with HIP events recorded on the handle's stream.
  * kind_mask: bit (1 << uda_op_kind) selects op kinds; bit 16 post-process aggregate, bit 17 NMS. */
 int uda_profile_enable(uda_ctx_t* ctx, uint32_t kind_mask);

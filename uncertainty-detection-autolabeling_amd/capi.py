@@ -91,6 +91,8 @@ _SIGNATURES = {
     "uda_get_preprocessed": (C.c_int, [_P, _P, _P]),
     "uda_nms": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float,
                           C.c_int32, _P, _P, _P]),
+    "uda_debug_pw": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                               C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(C.c_float)]),
     "uda_profile_enable": (C.c_int, [_P, C.c_uint32]),
     "uda_profile_read": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
 }

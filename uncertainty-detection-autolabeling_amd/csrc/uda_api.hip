@@ -32,6 +32,10 @@ struct uda_ctx {
 
   float* d_weights = nullptr;
   int64_t n_weights = 0;
+  // split-bf16 copies of the 1x1 kernels in MFMA fragment order (kernels_pwb.hip); -1 = op keeps the f32 path
+  uint16_t* d_wsplit = nullptr;
+  std::vector<int64_t> wsplit_off;
+  int pw_parts = 2;            // UDA_PW_TERMS: 3 -> 2 pieces (default), 6 -> 3 pieces, 0 -> f32 MFMA everywhere
   float* d_arena = nullptr;
   // chunk lanes: consecutive chunks alternate between independent (stream, arena) pairs so that the
   // barrier-heavy kernels of one chunk overlap the streaming kernels of the other
@@ -176,7 +180,7 @@ extern "C" void uda_destroy(uda_ctx_t* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   for (int k = 0; k < 32; ++k) prof_collect(c, k);
-  void* ptrs[] = {c->d_weights, c->d_arena, c->d_anchors, c->d_u8, c->d_images, c->d_scales, c->d_masks,
+  void* ptrs[] = {c->d_weights, c->d_wsplit, c->d_arena, c->d_anchors, c->d_u8, c->d_images, c->d_scales, c->d_masks,
                   c->d_site_off, c->d_site_ch, c->d_site_rate, c->d_cboxes, c->d_cscores, c->d_clogits,
                   c->d_cclasses, c->d_ucls, c->d_ual, c->d_uep, c->d_clsmean, c->d_cand_flat, c->d_merge_keys,
                   c->d_oboxes, c->d_oscores, c->d_oclasses, c->d_ologits, c->d_ovalid};
@@ -321,6 +325,28 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
 
   CK(dalloc(&c->d_weights, (size_t)n_weights));
   CK(hipMemcpy(c->d_weights, weights, (size_t)n_weights * sizeof(float), hipMemcpyHostToDevice));
+  {
+    // split-precision copies of every 1x1 kernel, packed once (host) in B-fragment order
+    const char* e = getenv("UDA_PW_TERMS");
+    const int terms = e ? atoi(e) : 3;
+    c->pw_parts = terms == 0 ? 0 : (terms == 6 ? 3 : 2);
+    c->wsplit_off.assign(n_ops, -1);
+    if (c->pw_parts) {
+      std::vector<uint16_t> packed;
+      for (int i = 0; i < n_ops; ++i) {
+        const uda_op_t& o = ops[i];
+        if (o.kind != UDA_OP_PW || o.w_off < 0) continue;
+        const int K = bufs[o.in[0]].C, Nn = bufs[o.out].C;
+        const size_t at = packed.size();
+        packed.resize(at + pwb_packed_elems(K, Nn, c->pw_parts));
+        pwb_pack_weights(weights + o.w_off, K, Nn, c->pw_parts, packed.data() + at);
+        c->wsplit_off[i] = (int64_t)at;
+      }
+      CK(dalloc(&c->d_wsplit, packed.size()));
+      if (!packed.empty())
+        CK(hipMemcpy(c->d_wsplit, packed.data(), packed.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+  }
   CK(dalloc(&c->d_arena, (size_t)m.arena_floats));
   {
     const char* e = getenv("UDA_LANES");
@@ -578,7 +604,13 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       a.in_div = v.div(ib, ob);
       a.res_div = o.residual >= 0 ? v.div(c->bufs[o.residual], ob) : 1;
       a.act = o.act;
-      launch_pw(a, rows, v.stream());
+      if (c->wsplit_off[oi] >= 0) {
+        a.wsplit = c->d_wsplit + c->wsplit_off[oi];
+        a.wparts = c->pw_parts;
+        launch_pwb(a, rows, v.stream());
+      } else {
+        launch_pw(a, rows, v.stream());
+      }
       break;
     }
     case UDA_OP_DW: {
@@ -1095,5 +1127,73 @@ extern "C" int uda_profile_read(uda_ctx_t* c, int32_t kind, double* total_ms, in
   if (total_ms) *total_ms = c->prof[kind].total_ms;
   if (launches) *launches = c->prof[kind].launches;
   if (reset) { c->prof[kind].total_ms = 0; c->prof[kind].launches = 0; }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ standalone 1x1 conv
+extern "C" int uda_debug_pw(int32_t device, const float* in, const float* w, const float* bias, const float* bn_scale,
+                            const float* bn_shift, const float* se, const float* mask, const float* res,
+                            int32_t rows, int32_t in_div, int32_t hw, int32_t cin, int32_t cout, int32_t act,
+                            int32_t terms, int32_t reps, float* out, float* avg_ms) {
+  if (!in || !w || !out || rows < 1 || in_div < 1 || rows % in_div || hw < 1 || cin < 4 || cin % 4 || cout < 1)
+    return fail(nullptr, "uda_debug_pw: bad argument");
+  if (terms != 0 && terms != 3 && terms != 6) return fail(nullptr, "uda_debug_pw: terms must be 0 (f32 MFMA), 3 or 6");
+  HIPC(nullptr, hipSetDevice(device));
+  const size_t rows_in = rows / in_div;
+  std::vector<void*> owned;
+  auto up = [&](const float* h, size_t n) -> float* {
+    if (!h) return nullptr;
+    float* d = nullptr;
+    if (hipMalloc((void**)&d, n * sizeof(float)) != hipSuccess) return nullptr;
+    owned.push_back(d);
+    hipMemcpy(d, h, n * sizeof(float), hipMemcpyHostToDevice);
+    return d;
+  };
+  PwArgs a{};
+  a.in = up(in, rows_in * hw * cin);
+  a.w = up(w, (size_t)cin * cout);
+  a.bias = up(bias, cout);
+  a.bn_scale = up(bn_scale, cout);
+  a.bn_shift = up(bn_shift, cout);
+  a.se = up(se, rows_in * cin);
+  a.mask = up(mask, (size_t)rows * cout);
+  a.res = up(res, (size_t)rows * hw * cout);
+  float* d_out = nullptr;
+  HIPC(nullptr, hipMalloc((void**)&d_out, (size_t)rows * hw * cout * sizeof(float)));
+  owned.push_back(d_out);
+  a.out = d_out;
+  a.HW = hw; a.Cin = cin; a.Cout = cout; a.in_div = in_div; a.res_div = 1; a.act = act;
+  uint16_t* d_ws = nullptr;
+  if (terms) {
+    const int parts = terms == 6 ? 3 : 2;
+    std::vector<uint16_t> packed(pwb_packed_elems(cin, cout, parts));
+    pwb_pack_weights(w, cin, cout, parts, packed.data());
+    HIPC(nullptr, hipMalloc((void**)&d_ws, packed.size() * sizeof(uint16_t)));
+    owned.push_back(d_ws);
+    HIPC(nullptr, hipMemcpy(d_ws, packed.data(), packed.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    a.wsplit = d_ws;
+    a.wparts = parts;
+  }
+  hipStream_t st;
+  HIPC(nullptr, hipStreamCreate(&st));
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  auto go = [&]() { if (terms) launch_pwb(a, rows, st); else launch_pw(a, rows, st); };
+  go();                                   // warm-up (and the result that is read back)
+  hipEventRecord(e0, st);
+  for (int i = 0; i < reps; ++i) go();
+  hipEventRecord(e1, st);
+  hipError_t err = hipStreamSynchronize(st);
+  if (err == hipSuccess) err = hipGetLastError();
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  if (avg_ms) *avg_ms = reps > 0 ? ms / reps : 0.f;
+  if (err == hipSuccess) err = hipMemcpy(out, d_out, (size_t)rows * hw * cout * sizeof(float), hipMemcpyDeviceToHost);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  hipStreamDestroy(st);
+  for (void* p : owned) hipFree(p);
+  if (err != hipSuccess) return fail(nullptr, "uda_debug_pw: %s", hipGetErrorString(err));
   return 0;
 }

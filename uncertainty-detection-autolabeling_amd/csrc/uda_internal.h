@@ -33,7 +33,12 @@ struct PwArgs {
   int in_div;            // rows_in = rows / in_div (input shared by the MC samples of an image)
   int res_div;
   int act;
+  const void* wsplit;    // split-bf16 weights in MFMA fragment order (kernels_pwb.hip) or null
+  int wparts;            // bf16 pieces per value: 2 (three cross terms) or 3 (six: float32-equivalent)
 };
+void launch_pwb(const PwArgs& a, int rows, hipStream_t s);
+size_t pwb_packed_elems(int K, int N, int parts);
+void pwb_pack_weights(const float* w, int K, int N, int parts, uint16_t* out);
 
 struct DwArgs {
   const float* in;       // [rows_in, H, W, C]
