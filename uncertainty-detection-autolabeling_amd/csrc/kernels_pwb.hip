@@ -279,6 +279,218 @@ void launch_pwb(const PwArgs& a, int rows, hipStream_t s) {
   }
 }
 
+// ---------------------------------------------------------------- fused MBConv front half, split-bf16 expand
+// expand 1x1 + BN + swish + dropout -> depthwise kxk / stride s (TF SAME) + BN + swish + dropout + SE tile
+// sums, one output tile per block, 32 expanded channels at a time (backbone/efficientnet_model.py:446-464).
+//   A  : every wave keeps the split-bf16 operand fragments of ITS 32-pixel slices of the input tile (with
+//        halo) in registers for the whole block: the tile is read from HBM/L2 once, straight into fragment
+//        shape (lane = pixel, 8 consecutive channels), no LDS image of the input.
+//   B  : the expand kernel times the BN scale, plus one extra k row holding the BN shift, packed on the host
+//        in fragment order.  The matching extra input channel is 1 inside the image and 0 in the halo /
+//        padding, so a position outside the image gives exactly swish(0) = 0 - the zero padding TF applies to
+//        the depthwise INPUT - with no per-element test.
+//   E  : the expanded + activated 32-channel slab [pixel][33] in LDS; the depthwise stage reads it with a
+//        sliding window along x, writes the output tile (128-byte channel segments) and the SE tile sums.
+// Two barriers per 32-channel slab (E complete / E free); the SE reduction rides on the second one.
+namespace {
+struct MbxCfgB { int th, tw; };
+__host__ __device__ constexpr MbxCfgB mbxb_cfg(int k, int s) {
+  return s == 1 ? MbxCfgB{8, 16} : (k == 3 ? MbxCfgB{4, 16} : MbxCfgB{4, 8});
+}
+}  // namespace
+
+template <int K, int S, int KSF>   // KSF = 16-deep MFMA k-steps covering Cin + 1
+__global__ __launch_bounds__(256) void mbxb_kernel(MbxArgs a) {
+  constexpr int NW = 4;
+  constexpr int TH = mbxb_cfg(K, S).th, TW = mbxb_cfg(K, S).tw;
+  constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
+  constexpr int NP = IH * IW;
+  constexpr int NPP = (NP + 31) / 32 * 32;
+  constexpr int NMT = NPP / 32;
+  constexpr int NG = NW * 2;                  // depthwise thread groups (32 channels each)
+  constexpr int MTW = (NMT + NW - 1) / NW;    // pixel slices per wave
+  constexpr int ES = 33;
+  constexpr int GPR = NG / TH;                // thread groups per output row
+  constexpr int XW = TW / GPR;                // outputs per thread along x
+  constexpr int NCOL = (XW - 1) * S + K;
+  extern __shared__ float mlds[];
+  float* E = mlds;                            // [NPP][ES]
+  float* red = E + (size_t)NPP * ES;          // [NG][32]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, b_in = b / a.in_div;
+  const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+  const int iy0 = oy0 * S - a.pad_t, ix0 = ox0 * S - a.pad_l;
+  const float* xin = a.in + (size_t)b_in * a.H * a.W * a.Cin;
+
+  // ---- this wave's operand fragments: pixel = slice * 32 + li, channels 16 ks + 8 lh .. + 7
+  bf16x8 ah[MTW][KSF], al[MTW][KSF];
+#pragma unroll
+  for (int t = 0; t < MTW; ++t) {
+    const int mt = wave + NW * t;
+    const int p = mt * 32 + li;
+    const int iy = iy0 + p / IW, ix = ix0 + p % IW;
+    const bool in = (mt < NMT) && (p < NP) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    const float* px = xin + ((size_t)(in ? iy : 0) * a.W + (in ? ix : 0)) * a.Cin;
+#pragma unroll
+    for (int ks = 0; ks < KSF; ++ks) {
+      const int k = ks * 16 + 8 * lh;
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      if (in && k < a.Cin) {       // Cin % 8 == 0: a group of 8 is either inside or past the channels
+        v0 = *(const float4*)(px + k);
+        v1 = *(const float4*)(px + k + 4);
+      }
+      if (k == a.Cin) v0.x = in ? 1.f : 0.f;          // the "inside the image" channel that carries the BN shift
+      const unsigned h0 = pack_bf16(v0.x, v0.y), h1 = pack_bf16(v0.z, v0.w);
+      const unsigned h2 = pack_bf16(v1.x, v1.y), h3 = pack_bf16(v1.z, v1.w);
+      const unsigned l0 = pack_bf16(v0.x - bf16_lo_f32(h0), v0.y - bf16_hi_f32(h0));
+      const unsigned l1 = pack_bf16(v0.z - bf16_lo_f32(h1), v0.w - bf16_hi_f32(h1));
+      const unsigned l2 = pack_bf16(v1.x - bf16_lo_f32(h2), v1.y - bf16_hi_f32(h2));
+      const unsigned l3 = pack_bf16(v1.z - bf16_lo_f32(h3), v1.w - bf16_hi_f32(h3));
+      ah[t][ks] = __builtin_bit_cast(bf16x8, make_uint4(h0, h1, h2, h3));
+      al[t][ks] = __builtin_bit_cast(bf16x8, make_uint4(l0, l1, l2, l3));
+    }
+  }
+
+  const int c = tid & 31, g = tid >> 5;       // depthwise stage: channel within the slab, thread group
+  const int orow = g / GPR, oxs = (g % GPR) * XW;
+  const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  const int oy = oy0 + orow;
+  const int NCH = (a.Cmid + 31) >> 5;
+  const uint4* Wp = (const uint4*)a.wsplit;
+
+  struct SlabParams {
+    uint4 bh[KSF], bl[KSF];
+    float mk0;
+    float wk[K * K];
+    float sc1, sh1, mk1;
+  };
+  auto load_params = [&](int ch, SlabParams& q) {
+#pragma unroll
+    for (int ks = 0; ks < KSF; ++ks) {
+      q.bh[ks] = Wp[(((size_t)ks * NCH + ch) * 2 + 0) * 64 + lane];
+      q.bl[ks] = Wp[(((size_t)ks * NCH + ch) * 2 + 1) * 64 + lane];
+    }
+    const int ecol = ch * 32 + li;
+    q.mk0 = (ecol < a.Cmid && a.mask0) ? a.mask0[(size_t)b * a.Cmid + ecol] : 1.f;
+    const int dcol_ = ch * 32 + c;
+    const bool dok = dcol_ < a.Cmid;
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) q.wk[t] = dok ? a.wd[(size_t)t * a.Cmid + dcol_] : 0.f;
+    q.sc1 = dok ? a.sc1[dcol_] : 0.f;
+    q.sh1 = dok ? a.sh1[dcol_] : 0.f;
+    q.mk1 = (dok && a.mask1) ? a.mask1[(size_t)b * a.Cmid + dcol_] : 1.f;
+  };
+  SlabParams cur, nxt;
+  load_params(0, cur);
+
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int col = ch * 32 + c;
+    const bool dcol = col < a.Cmid;
+    // ---- expand: E[p][j] = swish(sum_k X[p][k] We'[k][32 ch + j]) * mask0
+#pragma unroll
+    for (int t = 0; t < MTW; ++t) {
+      const int mt = wave + NW * t;
+      if (mt < NMT) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSF; ++ks) {
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, cur.bh[ks]), bl = __builtin_bit_cast(bf16x8, cur.bl[ks]);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t][ks], bh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t][ks], bl, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t][ks], bh, acc, 0, 0, 0);
+        }
+        float* ep = E + (size_t)(mt * 32 + 4 * lh) * ES + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swishf_b(acc[r]) * cur.mk0;
+      }
+    }
+    if (ch + 1 < NCH) load_params(ch + 1, nxt);   // in flight during the depthwise phase
+    __syncthreads();
+    // ---- depthwise on E for channel 32 ch + c
+    float ssum = 0.f;
+    if (dcol && oy < a.Ho) {
+      float acc[XW];
+#pragma unroll
+      for (int o = 0; o < XW; ++o) acc[o] = 0.f;
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        float rowv[NCOL];
+        const float* er = E + ((size_t)(orow * S + ky) * IW + oxs * S) * ES + c;
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) rowv[j] = er[j * ES];
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+#pragma unroll
+          for (int o = 0; o < XW; ++o) acc[o] = fmaf(rowv[o * S + kx], cur.wk[ky * K + kx], acc[o]);
+        }
+      }
+      float* op = a.out + (((size_t)b * a.Ho + oy) * a.Wo + ox0 + oxs) * a.Cmid + col;
+#pragma unroll
+      for (int o = 0; o < XW; ++o) {
+        if (ox0 + oxs + o < a.Wo) {
+          const float v = swishf_b(fmaf(acc[o], cur.sc1, cur.sh1)) * cur.mk1;
+          op[(size_t)o * a.Cmid] = v;
+          ssum += v;
+        }
+      }
+    }
+    if (a.se_partial) red[g * 32 + c] = ssum;
+    __syncthreads();   // E may be rewritten; red[] of this slab is complete (next written after the next barrier)
+    if (a.se_partial && g == 0 && dcol) {
+      float t = red[c];
+#pragma unroll
+      for (int gg = 1; gg < NG; ++gg) t += red[gg * 32 + c];
+      a.se_partial[((size_t)b * a.n_tiles + tile) * a.Cmid + col] = t;
+    }
+    cur = nxt;
+  }
+}
+
+bool mbxb_supported(int Cin, int Cmid, int k, int stride) {
+  return Cin % 8 == 0 && Cin >= 16 && Cin <= 48 && Cmid % 4 == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2);
+}
+
+template <int K, int S, int KSF>
+static void launch_mbxb_t(const MbxArgs& a, int rows, hipStream_t s) {
+  constexpr int TH = mbxb_cfg(K, S).th, TW = mbxb_cfg(K, S).tw;
+  constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
+  constexpr int NPP = (IH * IW + 31) / 32 * 32;
+  const size_t lds = ((size_t)NPP * 33 + 8 * 32) * sizeof(float);
+  const dim3 grid((a.Wo + TW - 1) / TW, (a.Ho + TH - 1) / TH, rows);
+  hipLaunchKernelGGL((mbxb_kernel<K, S, KSF>), grid, dim3(256), lds, s, a);
+}
+
+template <int K, int S>
+static void launch_mbxb_ks(const MbxArgs& a, int rows, hipStream_t s) {
+  switch ((a.Cin + 1 + 15) / 16) {
+    case 2: launch_mbxb_t<K, S, 2>(a, rows, s); break;
+    case 3: launch_mbxb_t<K, S, 3>(a, rows, s); break;
+    default: launch_mbxb_t<K, S, 4>(a, rows, s); break;
+  }
+}
+
+void launch_mbxb(const MbxArgs& a, int rows, int k, int stride, hipStream_t s) {
+  if (k == 3 && stride == 1) launch_mbxb_ks<3, 1>(a, rows, s);
+  else if (k == 3 && stride == 2) launch_mbxb_ks<3, 2>(a, rows, s);
+  else if (k == 5 && stride == 1) launch_mbxb_ks<5, 1>(a, rows, s);
+  else launch_mbxb_ks<5, 2>(a, rows, s);
+}
+
+// expand kernel [Cin][Cmid] times the BN scale, plus the BN shift as row Cin -> packed split-bf16 fragments
+size_t mbxb_packed_elems(int Cin, int Cmid) { return pwb_packed_elems(Cin + 1, Cmid, 2); }
+void mbxb_pack_weights(const float* we, const float* sc0, const float* sh0, int Cin, int Cmid, uint16_t* out) {
+  float* w = (float*)malloc((size_t)(Cin + 1) * Cmid * sizeof(float));
+  for (int k = 0; k < Cin; ++k)
+    for (int n = 0; n < Cmid; ++n) w[(size_t)k * Cmid + n] = we[(size_t)k * Cmid + n] * sc0[n];
+  for (int n = 0; n < Cmid; ++n) w[(size_t)Cin * Cmid + n] = sh0[n];
+  pwb_pack_weights(w, Cin + 1, Cmid, 2, out);
+  free(w);
+}
+
 // ---------------------------------------------------------------- host-side weight split / packing
 static inline uint16_t f32_to_bf16_rne(float x) {
   uint32_t u;

@@ -331,15 +331,25 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
     const int terms = e ? atoi(e) : 3;
     c->pw_parts = terms == 0 ? 0 : (terms == 6 ? 3 : 2);
     c->wsplit_off.assign(n_ops, -1);
+    const char* em = getenv("UDA_MBX_BF16");
+    const bool mbx_bf16 = em ? atoi(em) != 0 : true;
     if (c->pw_parts) {
       std::vector<uint16_t> packed;
       for (int i = 0; i < n_ops; ++i) {
         const uda_op_t& o = ops[i];
-        if (o.kind != UDA_OP_PW || o.w_off < 0) continue;
+        if (o.w_off < 0) continue;
         const int K = bufs[o.in[0]].C, Nn = bufs[o.out].C;
         const size_t at = packed.size();
-        packed.resize(at + pwb_packed_elems(K, Nn, c->pw_parts));
-        pwb_pack_weights(weights + o.w_off, K, Nn, c->pw_parts, packed.data() + at);
+        if (o.kind == UDA_OP_PW) {
+          packed.resize(at + pwb_packed_elems(K, Nn, c->pw_parts));
+          pwb_pack_weights(weights + o.w_off, K, Nn, c->pw_parts, packed.data() + at);
+        } else if (o.kind == UDA_OP_MBX && mbx_bf16 && o.bn_scale_off >= 0 && o.bn_shift_off >= 0 &&
+                   mbxb_supported(K, Nn, o.k, o.stride)) {
+          packed.resize(at + mbxb_packed_elems(K, Nn));
+          mbxb_pack_weights(weights + o.w_off, weights + o.bn_scale_off, weights + o.bn_shift_off, K, Nn, packed.data() + at);
+        } else {
+          continue;
+        }
         c->wsplit_off[i] = (int64_t)at;
       }
       CK(dalloc(&c->d_wsplit, packed.size()));
@@ -664,7 +674,12 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
           return fail(c, "op %d: SE partial buffer [%d,%d,%d] does not match %d tiles", oi, pb.H, pb.W, pb.C, a.n_tiles);
         a.se_partial = v.ptr(o.se_partial);
       }
-      launch_mbx(a, rows, o.k, o.stride, v.stream());
+      if (c->wsplit_off[oi] >= 0) {
+        a.wsplit = c->d_wsplit + c->wsplit_off[oi];
+        launch_mbxb(a, rows, o.k, o.stride, v.stream());
+      } else {
+        launch_mbx(a, rows, o.k, o.stride, v.stream());
+      }
       break;
     }
     case UDA_OP_SE: {

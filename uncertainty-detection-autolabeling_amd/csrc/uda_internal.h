@@ -75,7 +75,12 @@ struct MbxArgs {
   int in_div;
   int n_tiles;
   unsigned long long* stamps;  // diagnostic phase stamps (UDA_MBX_STAMPS); null in production
+  const void* wsplit;     // expand kernel * BN scale (+ BN shift row) as split-bf16 fragments (kernels_pwb.hip) or null
 };
+void launch_mbxb(const MbxArgs& a, int rows, int k, int stride, hipStream_t s);
+bool mbxb_supported(int Cin, int Cmid, int k, int stride);
+size_t mbxb_packed_elems(int Cin, int Cmid);
+void mbxb_pack_weights(const float* we, const float* sc0, const float* sh0, int Cin, int Cmid, uint16_t* out);
 void launch_mbx(const MbxArgs& a, int rows, int k, int stride, hipStream_t s);
 int mbx_tiles(int Ho, int Wo, int k, int stride);
 bool mbx_supported(int Cin, int Cmid, int k, int stride);
