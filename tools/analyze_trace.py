@@ -27,7 +27,7 @@ p = cfg.as_dict()
 pl = plan_mod.Plan(p, weights_mod.init_weights(p, 0), chunk_images=a.chunk, max_images=a.batch)
 
 rows = list(csv.DictReader(open(a.trace)))
-names = ("stem_kernel", "pw_kernel", "dw_kernel", "se_kernel", "fuse_kernel", "mbx_kernel")
+names = ("stem_kernel", "pw_kernel", "pwb_kernel", "dw_kernel", "se_kernel", "fuse_kernel", "mbx_kernel", "mbxb_kernel")
 idx = [i for i, r in enumerate(rows) if "preprocess" in r["Kernel_Name"]]
 rows = rows[idx[-1]:]
 conv = [r for r in rows if any(n in r["Kernel_Name"] for n in names)]

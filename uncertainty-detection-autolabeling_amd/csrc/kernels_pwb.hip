@@ -300,7 +300,7 @@ __host__ __device__ constexpr MbxCfgB mbxb_cfg(int k, int s) {
 }  // namespace
 
 template <int K, int S, int KSF>   // KSF = 16-deep MFMA k-steps covering Cin + 1
-__global__ __launch_bounds__(256) void mbxb_kernel(MbxArgs a) {
+__global__ __launch_bounds__(256, (KSF >= 3 ? 2 : 3)) void mbxb_kernel(MbxArgs a) {
   constexpr int NW = 4;
   constexpr int TH = mbxb_cfg(K, S).th, TW = mbxb_cfg(K, S).tw;
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
@@ -360,13 +360,13 @@ __global__ __launch_bounds__(256) void mbxb_kernel(MbxArgs a) {
   const int NCH = (a.Cmid + 31) >> 5;
   const uint4* Wp = (const uint4*)a.wsplit;
 
-  struct SlabParams {
+  // B fragments (and the expand-side dropout scale) are requested one slab ahead; the depthwise-side
+  // operands of a slab are requested when its expand phase starts and are consumed after it.
+  struct SlabB {
     uint4 bh[KSF], bl[KSF];
     float mk0;
-    float wk[K * K];
-    float sc1, sh1, mk1;
   };
-  auto load_params = [&](int ch, SlabParams& q) {
+  auto load_b = [&](int ch, SlabB& q) {
 #pragma unroll
     for (int ks = 0; ks < KSF; ++ks) {
       q.bh[ks] = Wp[(((size_t)ks * NCH + ch) * 2 + 0) * 64 + lane];
@@ -374,20 +374,18 @@ __global__ __launch_bounds__(256) void mbxb_kernel(MbxArgs a) {
     }
     const int ecol = ch * 32 + li;
     q.mk0 = (ecol < a.Cmid && a.mask0) ? a.mask0[(size_t)b * a.Cmid + ecol] : 1.f;
-    const int dcol_ = ch * 32 + c;
-    const bool dok = dcol_ < a.Cmid;
-#pragma unroll
-    for (int t = 0; t < K * K; ++t) q.wk[t] = dok ? a.wd[(size_t)t * a.Cmid + dcol_] : 0.f;
-    q.sc1 = dok ? a.sc1[dcol_] : 0.f;
-    q.sh1 = dok ? a.sh1[dcol_] : 0.f;
-    q.mk1 = (dok && a.mask1) ? a.mask1[(size_t)b * a.Cmid + dcol_] : 1.f;
   };
-  SlabParams cur, nxt;
-  load_params(0, cur);
+  SlabB cur, nxt;
+  load_b(0, cur);
 
   for (int ch = 0; ch < NCH; ++ch) {
     const int col = ch * 32 + c;
     const bool dcol = col < a.Cmid;
+    float wk[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) wk[t] = dcol ? a.wd[(size_t)t * a.Cmid + col] : 0.f;
+    const float sc1 = dcol ? a.sc1[col] : 0.f, sh1 = dcol ? a.sh1[col] : 0.f;
+    const float mk1 = (dcol && a.mask1) ? a.mask1[(size_t)b * a.Cmid + col] : 1.f;
     // ---- expand: E[p][j] = swish(sum_k X[p][k] We'[k][32 ch + j]) * mask0
 #pragma unroll
     for (int t = 0; t < MTW; ++t) {
@@ -408,7 +406,7 @@ __global__ __launch_bounds__(256) void mbxb_kernel(MbxArgs a) {
         for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swishf_b(acc[r]) * cur.mk0;
       }
     }
-    if (ch + 1 < NCH) load_params(ch + 1, nxt);   // in flight during the depthwise phase
+    if (ch + 1 < NCH) load_b(ch + 1, nxt);   // in flight during the depthwise phase
     __syncthreads();
     // ---- depthwise on E for channel 32 ch + c
     float ssum = 0.f;
@@ -425,14 +423,14 @@ __global__ __launch_bounds__(256) void mbxb_kernel(MbxArgs a) {
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
 #pragma unroll
-          for (int o = 0; o < XW; ++o) acc[o] = fmaf(rowv[o * S + kx], cur.wk[ky * K + kx], acc[o]);
+          for (int o = 0; o < XW; ++o) acc[o] = fmaf(rowv[o * S + kx], wk[ky * K + kx], acc[o]);
         }
       }
       float* op = a.out + (((size_t)b * a.Ho + oy) * a.Wo + ox0 + oxs) * a.Cmid + col;
 #pragma unroll
       for (int o = 0; o < XW; ++o) {
         if (ox0 + oxs + o < a.Wo) {
-          const float v = swishf_b(fmaf(acc[o], cur.sc1, cur.sh1)) * cur.mk1;
+          const float v = swishf_b(fmaf(acc[o], sc1, sh1)) * mk1;
           op[(size_t)o * a.Cmid] = v;
           ssum += v;
         }
