@@ -111,7 +111,13 @@ def test_sample_axis_propagation():
     full, _ = _plan(FULL_MC)
     bn = full.buffer_names
     assert not full.bufs[bn["image"]].per_sample and not full.bufs[bn["stem"]].per_sample
-    assert full.bufs[bn["blocks_0/dw"]].per_sample and full.bufs[bn["blocks_15/out"]].per_sample
+    # block 0: the dropout after the shared depthwise is deferred into the SE gate (it commutes with the
+    # squeeze and with the 1x1 projection), so the sample axis starts at the gate / the projection output
+    assert not full.bufs[bn["blocks_0/dw"]].per_sample and full.bufs[bn["blocks_0/se"]].per_sample
+    assert full.bufs[bn["blocks_0/out"]].per_sample and full.bufs[bn["blocks_15/out"]].per_sample
+    se0 = [o for o in full.ops if full.bufs[o["out"]].name == "blocks_0/se"][0]
+    assert se0["drop_site"] == full.site_index["blocks_0/dw"]
+    assert all(o["drop_site"] == -1 for o in full.ops if full.bufs[o["out"]].name == "blocks_0/dw")
     assert full.cls_stacked_dev and full.box_stacked_dev
     head, _ = _plan(HEAD_MC)
     hb = head.buffer_names

@@ -16,6 +16,8 @@ ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--samples", type=int, default=10)
 ap.add_argument("--variant", default="full")
 ap.add_argument("--top", type=int, default=40)
+ap.add_argument("--fetch", default="", help="counter_collection.csv of a --pmc FETCH_SIZE run of the same command")
+ap.add_argument("--write", default="", help="counter_collection.csv of a --pmc WRITE_SIZE run")
 a = ap.parse_args()
 
 cfg = hparams_config.get_efficientdet_config("efficientdet-d0")
@@ -25,6 +27,16 @@ over.update(dict(mc_dropoutrate=0.05) if a.variant == "full" else dict(mc_classh
 cfg.override(over)
 p = cfg.as_dict()
 pl = plan_mod.Plan(p, weights_mod.init_weights(p, 0), chunk_images=a.chunk, max_images=a.batch)
+
+def pmc_per_op(path, counter, scale):
+    """bytes per op of the first chunk of the last step, in op order (same selection as the trace)."""
+    rr = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+    rr.sort(key=lambda r: int(r["Dispatch_Id"]))
+    ix = [i for i, r in enumerate(rr) if "preprocess" in r["Kernel_Name"]]
+    rr = rr[ix[-1]:]
+    cv = [r for r in rr if any(n in r["Kernel_Name"] for n in names)]
+    return [float(r["Counter_Value"]) * 1024 * scale for r in cv[:len(pl.ops)]]
+
 
 rows = list(csv.DictReader(open(a.trace)))
 names = ("stem_kernel", "pw_kernel", "pwb_kernel", "dw_kernel", "se_kernel", "fuse_kernel", "mbx_kernel", "mbxb_kernel")
@@ -60,6 +72,10 @@ for o, r in zip(pl.ops, first):
     else:
         desc = {1: "stem", 4: "se", 5: "fuse", 6: "pool"}[o["kind"]] + " C=%d @%dx%d" % (ob.C, ob.H, ob.W)
     res.append((dur, desc, ob.name, by * 4, fl, r["Kernel_Name"].split("(")[0][-16:], r["VGPR_Count"]))
+fetch = pmc_per_op(a.fetch, "FETCH_SIZE", 2.0) if a.fetch else None   # gfx950: 64 B counted per 128-B request
+write = pmc_per_op(a.write, "WRITE_SIZE", 1.0) if a.write else None
+if fetch or write:
+    res = [r + ((fetch[i] if fetch else 0.0) + (write[i] if write else 0.0),) for i, r in enumerate(res)]
 tot = sum(r[0] for r in res)
 print("chunk of %d images: %d ops, %.2f ms kernel time" % (a.chunk, nops, tot / 1e3))
 for kind in ("pw", "dw", "mbx", "se", "fuse", "stem", "pool"):
@@ -69,5 +85,7 @@ for kind in ("pw", "dw", "mbx", "se", "fuse", "stem", "pool"):
         print("  %-5s %8.2f ms  %7.1f GB/s  %6.1f TFLOP/s" % (kind, t / 1e3, sum(r[3] for r in sel) / t / 1e3,
                                                               sum(r[4] for r in sel) / t / 1e6))
 print("top ops:")
-for dur, desc, name, by, fl, kn, vg in sorted(res, reverse=True)[:a.top]:
-    print("  %8.1f us  %-28s %-22s %7.1f GB/s %6.1f TF/s  %s v%s" % (dur, desc, name, by / dur / 1e3, fl / dur / 1e6, kn, vg))
+for r in sorted(res, reverse=True)[:a.top]:
+    dur, desc, name, by, fl, kn, vg = r[:7]
+    extra = "  hbm %7.1f MB = %.2fx alg, %6.0f GB/s" % (r[7] / 1e6, r[7] / by, r[7] / dur / 1e3) if len(r) > 7 else ""
+    print("  %8.1f us  %-28s %-22s %7.1f GB/s %6.1f TF/s  %s v%s%s" % (dur, desc, name, by / dur / 1e3, fl / dur / 1e6, kn, vg, extra))

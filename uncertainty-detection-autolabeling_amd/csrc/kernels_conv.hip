@@ -112,7 +112,7 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(PwArgs a) {
   const int b = blockIdx.z, b_in = b / a.in_div;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const float* A = a.in + (size_t)b_in * a.HW * a.Cin;
-  const float* se = a.se ? a.se + (size_t)b_in * a.Cin : nullptr;
+  const float* se = a.se ? a.se + (size_t)(b / a.se_div) * a.Cin : nullptr;
   const bool vecB = (a.Cout & 3) == 0;
 
   f32x16 acc[NT];
@@ -329,7 +329,8 @@ void launch_pw(const PwArgs& a, int rows, hipStream_t s) {
 // threads walk the channel quads of a pixel first (16-byte loads, fully coalesced NHWC),
 // then the x-groups.  The per-tile channel sums for squeeze-excite are reduced in a fixed
 // order (deterministic; no float atomics).
-constexpr int DW_ROWS = 8;  // output rows per block
+// output rows per block: 8, 16 for 5x5 stride 1 (vertical halo re-read (R + 4) / R: 1.5 -> 1.25)
+static inline int dw_rows(int k, int stride) { return (k == 5 && stride == 1) ? 16 : 8; }
 
 // Each thread keeps a K-row x NCOL-column window of its 4 channels in registers and slides it
 // down the DW_ROWS output rows: every input element is loaded once per block column strip
@@ -339,6 +340,7 @@ constexpr int DW_ROWS = 8;  // output rows per block
 // turns the distance into a counted s_waitcnt vmcnt).
 template <int K, int S, int XB, int PF>
 __global__ __launch_bounds__(256, (K == 5) ? 2 : 3) void dw_kernel(DwArgs a) {
+  constexpr int DW_ROWS = (K == 5 && S == 1) ? 16 : 8;
   extern __shared__ float4 dsm[];          // wts[K*K][tc] | red[blockDim]
   float4* wts = dsm;
   float4* red = dsm + K * K * a.tc;
@@ -449,14 +451,18 @@ static inline int dw_xb(int k, int stride) { return k == 5 ? 1 : (stride == 1 ? 
 
 void dw_geometry(int C, int Wo, int k, int stride, int* tc, int* pxb, int* n_cchunk, int* grid_x, int* xb) {
   const int C4 = C / 4;
-  const int ncc = (C4 + 63) / 64;   // <= 64 channel quads per block: the K*K weight quads in LDS stay <= 25.6 KB
+  // channel quads per block: <= 64 for 3x3 (K*K weight quads in LDS <= 9.2 KB); <= 16 for 5x5 so that a block
+  // spans >= 16 output columns (horizontal halo re-read (16 + 4) / 16 instead of (4 + 4) / 4)
+  const int cap = (k == 5) ? 16 : 64;
+  const int ncc = (C4 + cap - 1) / cap;
   const int t = (C4 + ncc - 1) / ncc;
   int p = 256 / t;
   if (p < 1) p = 1;
   const int x = dw_xb(k, stride);
-  // do not spread one block over more columns than the row has
+  // do not spread one block over more columns than the row has, and balance the blocks of a row
   const int need = (Wo + x - 1) / x;
   if (p > need) p = need;
+  if (k == 5) p = (need + (need + p - 1) / p - 1) / ((need + p - 1) / p);
   *tc = t;
   *pxb = p;
   *n_cchunk = ncc;
@@ -467,13 +473,13 @@ void dw_geometry(int C, int Wo, int k, int stride, int* tc, int* pxb, int* n_cch
 int dw_tiles(int C, int Ho, int Wo, int k, int stride) {
   int tc, pxb, ncc, gx, xb;
   dw_geometry(C, Wo, k, stride, &tc, &pxb, &ncc, &gx, &xb);
-  return ((Ho + DW_ROWS - 1) / DW_ROWS) * gx;
+  return ((Ho + dw_rows(k, stride) - 1) / dw_rows(k, stride)) * gx;
 }
 
 void launch_dw(DwArgs a, int rows, int k, int stride, hipStream_t s) {
   int gx, xb;
   dw_geometry(a.C, a.Wo, k, stride, &a.tc, &a.pxb, &a.n_cchunk, &gx, &xb);
-  const int gy = (a.Ho + DW_ROWS - 1) / DW_ROWS;
+  const int gy = (a.Ho + dw_rows(k, stride) - 1) / dw_rows(k, stride);
   a.n_tiles = gy * gx;
   int threads = a.tc * a.pxb;
   threads = (threads + 63) / 64 * 64;
@@ -495,7 +501,11 @@ __global__ __launch_bounds__(256) void se_kernel(SeArgs a) {
   float* mid = mean + a.C;
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
-  const float* part = a.partial + (size_t)b * a.n_tiles * a.C;
+  // deferred dropout: the depthwise output is shared by the samples of an image and its keep-scale m[b][c]
+  // (per sample row, per channel) commutes with the spatial mean: mean_b = m[b] * mean_image; the gate that
+  // the projection applies to its (shared) input is then sigmoid(...) * m[b]   (SpatialDropout2D, noise [N,1,1,C])
+  const float* part = a.partial + (size_t)(b / a.in_div) * a.n_tiles * a.C;
+  const float* dm = a.mask ? a.mask + (size_t)b * a.C : nullptr;
   const int C4 = a.C >> 2;
   // channel sums: thread = (channel quad, tile group); groups are combined in a fixed order
   for (int cbase = 0; cbase < C4; cbase += 256) {
@@ -516,10 +526,12 @@ __global__ __launch_bounds__(256) void se_kernel(SeArgs a) {
         const float4 v = red[g2 * cw + tid];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
-      mean[c4 * 4 + 0] = s.x * a.inv_hw;
-      mean[c4 * 4 + 1] = s.y * a.inv_hw;
-      mean[c4 * 4 + 2] = s.z * a.inv_hw;
-      mean[c4 * 4 + 3] = s.w * a.inv_hw;
+      float4 m1 = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (dm) m1 = *(const float4*)(dm + c4 * 4);
+      mean[c4 * 4 + 0] = s.x * a.inv_hw * m1.x;
+      mean[c4 * 4 + 1] = s.y * a.inv_hw * m1.y;
+      mean[c4 * 4 + 2] = s.z * a.inv_hw * m1.z;
+      mean[c4 * 4 + 3] = s.w * a.inv_hw * m1.w;
     }
     __syncthreads();
   }
@@ -532,7 +544,7 @@ __global__ __launch_bounds__(256) void se_kernel(SeArgs a) {
   for (int c = tid; c < a.C; c += blockDim.x) {
     float s = 0.f;
     for (int j = 0; j < a.mid; ++j) s = fmaf(mid[j], a.w2[(size_t)j * a.C + c], s);
-    a.scale[(size_t)b * a.C + c] = sigmoidf_(s + a.b2[c]);
+    a.scale[(size_t)b * a.C + c] = sigmoidf_(s + a.b2[c]) * (dm ? dm[c] : 1.f);
   }
 }
 

@@ -47,8 +47,8 @@ constexpr int PWB_BK = 32;         // k per staged chunk = 2 MFMA k-steps of 16
 constexpr int PWB_AROW = 80;       // bytes per A image row: 32 bf16 + 16 pad
 constexpr int PWB_STG = 68;        // epilogue staging row stride (floats)
 
-template <int MT, int NT, int WM, int WN, int PARTS>
-__global__ __launch_bounds__(256) void pwb_kernel(PwArgs a) {
+template <int MT, int NT, int WM, int WN, int PARTS, int OCC>
+__global__ __launch_bounds__(256, OCC) void pwb_kernel(PwArgs a) {
   static_assert(WM * WN == 4, "four waves per block");
   constexpr int BM = 32 * MT * WM, NTB = NT * WN, BN = 32 * NTB;
   constexpr int A_BYTES = PARTS * BM * PWB_AROW;
@@ -62,11 +62,13 @@ __global__ __launch_bounds__(256) void pwb_kernel(PwArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wr = wave / WN, wc = wave % WN;
+  // (an XCD-aware block order that keeps the column blocks of a pixel tile on one XCD's L2 was measured: no gain)
+  const int bx = blockIdx.x, by = blockIdx.y;
   const int b = blockIdx.z, b_in = b / a.in_div;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int nt0 = blockIdx.y * NTB;
+  const int m0 = bx * BM, n0 = by * BN;
+  const int nt0 = by * NTB;
   const float* A = a.in + (size_t)b_in * a.HW * a.Cin;
-  const float* se = a.se ? a.se + (size_t)b_in * a.Cin : nullptr;
+  const float* se = a.se ? a.se + (size_t)(b / a.se_div) * a.Cin : nullptr;
   const uint4* Wp = (const uint4*)a.wsplit;
   const int KS = (a.Cin + 15) >> 4;        // MFMA k-steps in the packed weights
   const int NTL = (a.Cout + 31) >> 5;      // 32-column tiles in the packed weights
@@ -259,8 +261,9 @@ template <int MT, int NT, int WM, int WN>
 static void launch_pwb_cfg(const PwArgs& a, int rows, hipStream_t s) {
   constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
   const dim3 grid((a.HW + BM - 1) / BM, (a.Cout + BN - 1) / BN, rows), block(256);
-  if (a.wparts == 3) hipLaunchKernelGGL((pwb_kernel<MT, NT, WM, WN, 3>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((pwb_kernel<MT, NT, WM, WN, 2>), grid, block, 0, s, a);
+  // three blocks per CU (<= 168 registers): measured 10-20 % faster than the unconstrained allocation (2 per CU)
+  if (a.wparts == 3) hipLaunchKernelGGL((pwb_kernel<MT, NT, WM, WN, 3, 2>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((pwb_kernel<MT, NT, WM, WN, 2, 3>), grid, block, 0, s, a);
 }
 
 // tile = 128 pixels x {32, 64, 96, 128} channels (four waves stacked along the pixels for narrow outputs,
@@ -274,7 +277,6 @@ void launch_pwb(const PwArgs& a, int rows, hipStream_t s) {
     case 1: launch_pwb_cfg<1, 1, 4, 1>(a, rows, s); break;
     case 2: launch_pwb_cfg<1, 2, 4, 1>(a, rows, s); break;
     case 3: launch_pwb_cfg<1, 3, 4, 1>(a, rows, s); break;
-    case 5: launch_pwb_cfg<2, 4, 2, 2>(a, rows, s); break;
     default: launch_pwb_cfg<2, 2, 2, 2>(a, rows, s); break;
   }
 }

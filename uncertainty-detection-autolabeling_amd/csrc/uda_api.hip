@@ -606,8 +606,13 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       a.bn_scale = v.wt(o.bn_scale_off);
       a.bn_shift = v.wt(o.bn_shift_off);
       a.se = o.se_scale >= 0 ? v.ptr(o.se_scale) : nullptr;
-      if (o.se_scale >= 0 && c->bufs[o.se_scale].per_sample != ib.per_sample)
-        return fail(c, "op %d: SE gate and input disagree on the sample axis", oi);
+      a.se_div = 1;
+      if (o.se_scale >= 0) {
+        const uda_buf_desc_t& sb = c->bufs[o.se_scale];
+        if (sb.per_sample && !ob.per_sample) return fail(c, "op %d: per-sample SE gate on a per-image output", oi);
+        if (!sb.per_sample && ib.per_sample) return fail(c, "op %d: per-image SE gate on a per-sample input", oi);
+        a.se_div = v.div(sb, ob);
+      }
       a.mask = v.mask(o.drop_site);
       a.res = o.residual >= 0 ? v.ptr(o.residual) : nullptr;
       a.HW = ob.H * ob.W; a.Cin = ib.C; a.Cout = ob.C;
@@ -693,6 +698,11 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       a.C = src.C; a.mid = o.se_mid; a.n_tiles = pb.H * pb.W;   // the producer (DW / MBX) validated this count
       a.inv_hw = 1.0f / (float)(src.H * src.W);
       if (pb.C != src.C || ob.C != src.C) return fail(c, "op %d: SE channel mismatch", oi);
+      // deferred dropout site (plan.py): the squeezed tensor is per image, its keep-scale per sample row
+      a.mask = v.mask(o.drop_site);
+      a.in_div = v.div(pb, ob);
+      if (o.drop_site >= 0 && !ob.per_sample) return fail(c, "op %d: deferred dropout needs a per-sample gate", oi);
+      if (pb.per_sample != src.per_sample) return fail(c, "op %d: SE sums and source disagree on the sample axis", oi);
       launch_se(a, rows, v.stream());
       break;
     }
@@ -1177,7 +1187,7 @@ extern "C" int uda_debug_pw(int32_t device, const float* in, const float* w, con
   HIPC(nullptr, hipMalloc((void**)&d_out, (size_t)rows * hw * cout * sizeof(float)));
   owned.push_back(d_out);
   a.out = d_out;
-  a.HW = hw; a.Cin = cin; a.Cout = cout; a.in_div = in_div; a.res_div = 1; a.act = act;
+  a.HW = hw; a.Cin = cin; a.Cout = cout; a.in_div = in_div; a.res_div = 1; a.se_div = in_div; a.act = act;
   uint16_t* d_ws = nullptr;
   if (terms) {
     const int parts = terms == 6 ? 3 : 2;

@@ -26,12 +26,13 @@ struct PwArgs {
   const float* bias;     // [Cout] or null
   const float* bn_scale; // [Cout] or null
   const float* bn_shift;
-  const float* se;       // [rows_in, Cin] gate on the input or null
+  const float* se;       // [rows / se_div, Cin] gate on the input or null
   const float* mask;     // [rows, Cout] dropout keep-scale or null
   const float* res;      // [rows, HW, Cout] residual or null
   int HW, Cin, Cout;
   int in_div;            // rows_in = rows / in_div (input shared by the MC samples of an image)
   int res_div;
+  int se_div;            // 1: one gate per output row (per sample); in_div: one per input row
   int act;
   const void* wsplit;    // split-bf16 weights in MFMA fragment order (kernels_pwb.hip) or null
   int wparts;            // bf16 pieces per value: 2 (three cross terms) or 3 (six: float32-equivalent)
@@ -94,6 +95,8 @@ struct SeArgs {
   const float* b2;       // [C]
   int C, mid, n_tiles;
   float inv_hw;
+  const float* mask;     // [rows, C] deferred dropout keep-scale of the squeezed tensor, or null
+  int in_div;            // partial sums are per input row: rows / in_div
 };
 
 struct FuseArgs {

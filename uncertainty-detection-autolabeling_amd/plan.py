@@ -26,20 +26,27 @@ ALIGN = 256  # floats
 def dw_tiles_x(C, Wo, k, stride):
     """gridDim.x of the depthwise kernel (mirror of dw_geometry in csrc/kernels_conv.hip)."""
     C4 = C // 4
-    ncc = (C4 + 63) // 64
+    cap = 16 if k == 5 else 64
+    ncc = (C4 + cap - 1) // cap
     t = (C4 + ncc - 1) // ncc
     p = max(1, 256 // t)
     x = 1 if k == 5 else (4 if stride == 1 else 2)
-    p = min(p, (Wo + x - 1) // x)
+    need = (Wo + x - 1) // x
+    p = min(p, need)
+    if k == 5:
+        nb = (need + p - 1) // p
+        p = (need + nb - 1) // nb
     return (Wo + p * x - 1) // (p * x)
 
 
-DW_ROWS = 8  # mirror of DW_ROWS in csrc/kernels_conv.hip
+def dw_rows(k, stride):
+    """output rows per depthwise block (mirror of dw_rows in csrc/kernels_conv.hip)."""
+    return 16 if (k == 5 and stride == 1) else 8
 
 
 def dw_tiles(C, Ho, Wo, k, stride):
     """SE tile sums one depthwise launch leaves per sample row (mirror of dw_tiles in csrc)."""
-    return -(-Ho // DW_ROWS) * dw_tiles_x(C, Wo, k, stride)
+    return -(-Ho // dw_rows(k, stride)) * dw_tiles_x(C, Wo, k, stride)
 
 
 def mbx_tile(k, stride):
@@ -85,6 +92,8 @@ class Plan:
         self.sites = []          # (name, channels, rate)
         self.site_index = {}
         self.buffer_names = {}
+        import os
+        self.defer_dropout = bool(int(os.environ.get("UDA_DEFER_DROPOUT", "1")))
         self._build_sites()
         self._lower()
         self._plan_memory()
@@ -152,7 +161,7 @@ class Plan:
     def _pw(self, x, cout, kernel, name, bias=None, bn=None, act=capi.ACT_NONE, site=-1, se=-1,
             residual=-1, out_kind=0, level=0):
         xb = self.bufs[x]
-        ps = xb.per_sample or site >= 0
+        ps = xb.per_sample or site >= 0 or (se >= 0 and self.bufs[se].per_sample)
         out = self._buf(xb.H, xb.W, cout, ps, out_kind, level, name)
         kw = dict(w_off=self._pack(self.w[kernel]), act=act, drop_site=site, se_scale=se, residual=residual)
         if bias is not None:
@@ -161,9 +170,15 @@ class Plan:
             kw["bn_scale_off"], kw["bn_shift_off"] = self._bn(bn)
         return self._op(capi.OP_PW, [x], out, **kw)
 
-    def _dw(self, x, k, stride, kernel, name, bn=None, act=capi.ACT_NONE, site=-1, with_se=False):
+    def _dw(self, x, k, stride, kernel, name, bn=None, act=capi.ACT_NONE, site=-1, with_se=False, defer_site=False):
+        """defer_site: the dropout site after this depthwise is NOT applied here.  Its keep-scale is per
+        (sample, channel) and the consumers are the SE squeeze (a spatial mean) and a 1x1 conv, both linear in a
+        per-channel scale of their input: the SE op folds it into the mean and into the gate, so the depthwise
+        output stays one row per image instead of one per (image, sample)."""
         xb = self.bufs[x]
         Ho, Wo = same_out(xb.H, stride), same_out(xb.W, stride)
+        if defer_site:
+            site = -1
         ps = xb.per_sample or site >= 0
         out = self._buf(Ho, Wo, xb.C, ps, name=name)
         kw = dict(k=k, stride=stride, w_off=self._pack(self.w[kernel]), act=act, drop_site=site)
@@ -207,6 +222,7 @@ class Plan:
             p = "%s/blocks_%d/" % (bb, i)
             bn_names = [p + "tpu_batch_normalization" + ("" if j == 0 else "_%d" % j) for j in range(3)]
             inp, nb = x, 0
+            deferred = -1
             mid = b["cin"] * b["expand"]
             if b["expand"] != 1 and mbx_supported(b["cin"], mid, b["kernel"], b["stride"]):
                 # fused expand + depthwise: the expanded tensor stays on-chip
@@ -236,14 +252,20 @@ class Plan:
                     proj = p + "conv2d_1/kernel"
                 else:
                     proj = p + "conv2d/kernel"
+                dsite = self._site("blocks_%d/dw" % i)
+                # a shared (per-image) depthwise input + SE: the dropout after the depthwise is deferred into
+                # the SE gate, the depthwise runs once per image (block 0 under full MC dropout)
+                deferred = dsite if (dsite >= 0 and b["se"] and not self.bufs[x].per_sample and self.defer_dropout) else -1
                 x, part = self._dw(x, b["kernel"], b["stride"], p + "depthwise_conv2d/depthwise_kernel",
                                    "blocks_%d/dw" % i, bn=bn_names[nb], act=capi.ACT_SWISH,
-                                   site=self._site("blocks_%d/dw" % i), with_se=bool(b["se"]))
+                                   site=dsite, with_se=bool(b["se"]), defer_site=deferred >= 0)
                 nb += 1
             gate = -1
             if b["se"]:
                 xb = self.bufs[x]
-                gate = self._op(capi.OP_SE, [part, x], self._buf(1, 1, xb.C, xb.per_sample, name="blocks_%d/se" % i),
+                gate = self._op(capi.OP_SE, [part, x],
+                                self._buf(1, 1, xb.C, xb.per_sample or deferred >= 0, name="blocks_%d/se" % i),
+                                drop_site=deferred,
                                 k=b["kernel"], stride=b["stride"], se_mid=b["se"],
                                 se_w1_off=self._pack(w[p + "se/conv2d/kernel"]),
                                 se_b1_off=self._pack(w[p + "se/conv2d/bias"]),
