@@ -148,7 +148,15 @@ __device__ __forceinline__ void decode_one(const AggArgs& a, const float* bp, in
   }
 }
 
-__global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a) {
+// One thread per candidate, 64-thread blocks.  Every head value is read from HBM exactly ONCE: the T class
+// logits and the T decoded boxes of the candidate are parked in LDS ([slot][lane], conflict-free) between
+// the mean pass and the deviation pass, so the two-pass population std keeps the oracle's arithmetic order
+// (bit-exact) without a second trip to memory and without decoding twice.
+constexpr int AGG_BLOCK = 64;
+
+__global__ __launch_bounds__(AGG_BLOCK) void aggregate_kernel(AggArgs a) {
+  extern __shared__ float park[];          // [Tc * C + Tb * 4][AGG_BLOCK]
+  const int lane = threadIdx.x;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (int64_t)a.n_img * a.K) return;
   const int n = (int)(gid / a.K);
@@ -170,22 +178,34 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a) {
   const float* cbase = a.lv.cls[lvl] + ((size_t)n * a.Tc * hw + p) * cch + al * C;
   const size_t cstride = (size_t)hw * cch;
   const float fT = (float)a.Tc;
+  // park_all: slot (t * C + c), every logit parked up front (sample-major reads: the C logits of a sample
+  // are contiguous); otherwise slot t, one class at a time (large T * C that would not fit LDS)
+  float* pc = park + lane;
+  const int cs = a.park_all ? C : 0;                        // slot of (t, c) = t * cs' + c' below
+  if (a.Tc > 1 && a.park_all)
+    for (int t = 0; t < a.Tc; ++t)
+      for (int c = 0; c < C; ++c) pc[(t * C + c) * AGG_BLOCK] = cbase[t * cstride + c];
   float best = -INFINITY;
   int best_c = 0;
   for (int c = 0; c < C; ++c) {
-    float m = cbase[c];
-    float sd = 0.f;
+    float m, sd = 0.f;
     if (a.Tc > 1) {
-      for (int t = 1; t < a.Tc; ++t) m = m + cbase[t * cstride + c];
+      const int c0 = a.park_all ? c : 0, ts = a.park_all ? cs : 1;
+      if (!a.park_all)
+        for (int t = 0; t < a.Tc; ++t) pc[t * AGG_BLOCK] = cbase[t * cstride + c];
+      m = pc[c0 * AGG_BLOCK];
+      for (int t = 1; t < a.Tc; ++t) m = m + pc[(t * ts + c0) * AGG_BLOCK];
       m = m / fT;
       if (a.u_cls && (fixed_c < 0 || fixed_c == c)) {
         float v = 0.f;
         for (int t = 0; t < a.Tc; ++t) {
-          const float dlt = cbase[t * cstride + c] - m;
+          const float dlt = pc[(t * ts + c0) * AGG_BLOCK] - m;
           v = v + dlt * dlt;
         }
         sd = sqrtf(v / fT);
       }
+    } else {
+      m = cbase[c];
     }
     a.logits[(size_t)gid * C + c] = m;
     if (fixed_c < 0) {
@@ -217,14 +237,17 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a) {
     if (a.u_ep) for (int k = 0; k < 4; ++k) a.u_ep[(size_t)gid * 4 + k] = 0.f;
     return;
   }
+  float* pb = park + (size_t)a.cls_slots * AGG_BLOCK + lane;   // slot (t * 4 + k)
   const float fTb = (float)a.Tb;
   float sb[4] = {d.box[0], d.box[1], d.box[2], d.box[3]};
   float ss[4] = {d.sig[0], d.sig[1], d.sig[2], d.sig[3]};
+  for (int k = 0; k < 4; ++k) pb[k * AGG_BLOCK] = d.box[k];
   for (int t = 1; t < a.Tb; ++t) {
     decode_one(a, bbase + t * bstride, a.A, an, d);
     for (int k = 0; k < 4; ++k) {
       sb[k] = sb[k] + d.box[k];
       ss[k] = ss[k] + d.sig[k];
+      pb[(t * 4 + k) * AGG_BLOCK] = d.box[k];
     }
   }
   float mb[4];
@@ -236,9 +259,8 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a) {
   if (a.u_ep) {
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < a.Tb; ++t) {
-      decode_one(a, bbase + t * bstride, a.A, an, d);
       for (int k = 0; k < 4; ++k) {
-        const float dlt = d.box[k] - mb[k];
+        const float dlt = pb[(t * 4 + k) * AGG_BLOCK] - mb[k];
         v[k] = v[k] + dlt * dlt;
       }
     }
@@ -246,9 +268,19 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a) {
   }
 }
 
-void launch_aggregate(const AggArgs& a, hipStream_t s) {
+void launch_aggregate(const AggArgs& a0, hipStream_t s) {
+  AggArgs a = a0;
   const int64_t total = (int64_t)a.n_img * a.K;
-  hipLaunchKernelGGL(aggregate_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+  const int box_slots = a.Tb > 1 ? a.Tb * 4 : 0;
+  a.park_all = (a.Tc * a.C + box_slots) * AGG_BLOCK * (int)sizeof(float) <= 48 * 1024;   // >= 3 blocks per CU
+  a.cls_slots = a.Tc > 1 ? (a.park_all ? a.Tc * a.C : a.Tc) : 0;
+  const size_t lds = (size_t)(a.cls_slots + box_slots) * AGG_BLOCK * sizeof(float);
+  static size_t attr_lds = 64 * 1024;
+  if (lds > attr_lds) {
+    hipFuncSetAttribute((const void*)aggregate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL(aggregate_kernel, dim3((unsigned)((total + AGG_BLOCK - 1) / AGG_BLOCK)), dim3(AGG_BLOCK), lds, s, a);
 }
 
 // ------------------------------------------------------------------------------------ top-k pre-selection

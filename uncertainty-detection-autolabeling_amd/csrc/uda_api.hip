@@ -44,6 +44,12 @@ struct uda_ctx {
   float* lane_arena[2] = {nullptr, nullptr};
   hipEvent_t ev_start = nullptr, ev_done[2] = {nullptr, nullptr};
   int last_lane = 0;
+  // post-process of chunk i (aggregate, NMS, gather: small latency-bound launches) runs on its own stream
+  // beside the conv stack of chunk i + 1; only the last chunk's post-process is exposed
+  hipStream_t post_stream = nullptr;
+  std::vector<hipEvent_t> ev_chunk;
+  hipEvent_t ev_post = nullptr;
+  int post_overlap = 1;
   float* d_anchors = nullptr;
   int A_tot = 0;
   int a_off[UDA_MAX_LEVELS + 1];
@@ -199,6 +205,9 @@ extern "C" void uda_destroy(uda_ctx_t* c) {
     if (c->lane_stream[l]) hipStreamDestroy(c->lane_stream[l]);
     if (c->lane_arena[l]) hipFree(c->lane_arena[l]);
   }
+  if (c->post_stream) hipStreamDestroy(c->post_stream);
+  for (auto e : c->ev_chunk) if (e) hipEventDestroy(e);
+  if (c->ev_post) hipEventDestroy(c->ev_post);
   if (c->ev_start) hipEventDestroy(c->ev_start);
   for (auto e : c->ev_done) if (e) hipEventDestroy(e);
   if (c->stream) hipStreamDestroy(c->stream);
@@ -367,6 +376,17 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
     c->lane_stream[0] = c->stream;
     c->lane_arena[0] = c->d_arena;
     CK(hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
+    const char* ep = getenv("UDA_POST_OVERLAP");
+    c->post_overlap = ep ? atoi(ep) : 1;
+    {   // highest priority: the post-process is a chain of ~200 tiny dependent launches that must slip in
+        // between the workgroups of the conv kernels instead of queueing behind them
+      int lo = 0, hi = 0;
+      CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      CK(hipStreamCreateWithPriority(&c->post_stream, hipStreamNonBlocking, hi));
+    }
+    CK(hipEventCreateWithFlags(&c->ev_post, hipEventDisableTiming));
+    c->ev_chunk.assign((size_t)(m.max_images + m.chunk_images - 1) / m.chunk_images, nullptr);
+    for (auto& e : c->ev_chunk) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (int l = 0; l < c->n_lanes; ++l) CK(hipEventCreateWithFlags(&c->ev_done[l], hipEventDisableTiming));
     for (int l = 1; l < c->n_lanes; ++l) {
       CK(hipStreamCreateWithFlags(&c->lane_stream[l], hipStreamNonBlocking));
@@ -749,7 +769,9 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
   return 0;
 }
 
-static int run_network(uda_ctx* c) {
+static int run_post_range(uda_ctx* c, int i0, int n, int post_mode, hipStream_t st);
+
+static int run_network(uda_ctx* c, int post_mode = 0, bool chunk_post = false) {
   const uda_model_t& m = c->model;
   const int n = c->n_images, T = m.mc_samples;
   if (c->have_u8) {
@@ -795,6 +817,18 @@ static int run_network(uda_ctx* c) {
     c->last_chunk_i0 = i0;
     c->last_chunk_n = v.nc;
     c->last_lane = v.lane;
+    if (chunk_post) {     // this chunk's head outputs are complete once its lane stream reaches the event
+      HIPC(c, hipEventRecord(c->ev_chunk[ci], v.stream()));
+      HIPC(c, hipStreamWaitEvent(c->post_stream, c->ev_chunk[ci], 0));
+      const int rc = run_post_range(c, i0, v.nc, post_mode, c->post_stream);
+      if (rc) return rc;
+    }
+  }
+  if (chunk_post) {
+    HIPC(c, hipEventRecord(c->ev_post, c->post_stream));
+    HIPC(c, hipStreamWaitEvent(c->stream, c->ev_post, 0));
+    c->last_post_mode = post_mode;
+    c->last_n = n;
   }
   for (int l = 1; l < lanes; ++l) {       // the post-process on the main stream needs every lane's head outputs
     HIPC(c, hipEventRecord(c->ev_done[l], c->lane_stream[l]));
@@ -805,17 +839,6 @@ static int run_network(uda_ctx* c) {
 }
 
 // ------------------------------------------------------------------------------------ post-process
-static NmsArgs nms_args_of(uda_ctx::NmsWs& w, int problems, int K, int M, const float* boxes) {
-  NmsArgs a{};
-  a.boxes = boxes;
-  a.stale = w.stale; a.begin = w.begin; a.tent = w.tent; a.ub = w.ub; a.ev = w.ev;
-  a.sel_idx = w.sel_idx; a.sel_score = w.sel_score; a.sel_box = w.sel_box;
-  a.bound_key = w.bound; a.win_key = w.win; a.nsel = w.nsel; a.done = w.done;
-  a.n_img = problems; a.K = K; a.M = M;
-  a.segs = 1; a.classes = nullptr;
-  return a;
-}
-
 static void nms_params(NmsArgs& a, float iou_thr, float score_thr, float soft_sigma) {
   a.iou_thr = iou_thr;
   a.score_thr = score_thr;
@@ -824,109 +847,159 @@ static void nms_params(NmsArgs& a, float iou_thr, float score_thr, float soft_si
 }
 
 // a8-a14: class statistics, (top-k pre-selection), per-sample decode and MC aggregation -> candidates
-static int run_candidates(uda_ctx* c, int n) {
+// All post-process stages work on the image range [i0, i0 + n) and on stream `st`.
+static int run_candidates(uda_ctx* c, int i0, int n, hipStream_t st) {
   const uda_model_t& m = c->model;
-  ProfScope ps(c, 16);
+  ProfScope ps(c, 16, st);
   AggArgs a{};
   a.lv.num_levels = m.num_levels;
+  const int Tc = m.cls_stacked ? m.mc_samples : 1, Tb = m.box_stacked ? m.mc_samples : 1;
+  const size_t K = (size_t)c->Kc, C = (size_t)m.num_classes;
+  const size_t uc = m.max_nms_inputs > 0 ? 1 : C;     // class-std values per candidate
   for (int l = 0; l < m.num_levels; ++l) {
-    a.lv.hw[l] = m.level_h[l] * m.level_w[l];
+    const size_t hw = (size_t)m.level_h[l] * m.level_w[l];
+    a.lv.hw[l] = (int)hw;
     a.lv.a_off[l] = c->a_off[l];
-    a.lv.cls[l] = c->d_cls[l];
-    a.lv.box[l] = c->d_box[l];
+    a.lv.cls[l] = c->d_cls[l] + (size_t)i0 * Tc * hw * c->cls_ch;
+    a.lv.box[l] = c->d_box[l] + (size_t)i0 * Tb * hw * c->box_ch;
   }
   a.lv.a_off[m.num_levels] = c->A_tot;
   a.anchors = c->d_anchors;
   a.n_img = n; a.A_tot = c->A_tot; a.A = m.anchors_per_loc; a.C = m.num_classes;
   a.K = c->Kc;
-  a.Tc = m.cls_stacked ? m.mc_samples : 1;
-  a.Tb = m.box_stacked ? m.mc_samples : 1;
+  a.Tc = Tc;
+  a.Tb = Tb;
   a.loss_att = m.loss_attenuation;
   a.decode = m.decode_method;
-  a.boxes = c->d_cboxes; a.scores = c->d_cscores; a.classes = c->d_cclasses; a.logits = c->d_clogits;
-  a.u_cls = c->d_ucls; a.u_al = c->d_ual; a.u_ep = c->d_uep;
+  a.boxes = c->d_cboxes + (size_t)i0 * K * 4; a.scores = c->d_cscores + (size_t)i0 * K;
+  a.classes = c->d_cclasses + (size_t)i0 * K; a.logits = c->d_clogits + (size_t)i0 * K * C;
+  a.u_cls = c->d_ucls ? c->d_ucls + (size_t)i0 * K * uc : nullptr;
+  a.u_al = c->d_ual ? c->d_ual + (size_t)i0 * K * 4 : nullptr;
+  a.u_ep = c->d_uep ? c->d_uep + (size_t)i0 * K * 4 : nullptr;
   a.cand_flat = nullptr;
   if (m.max_nms_inputs > 0) {
-    launch_class_mean(a, c->d_clsmean, c->stream);
-    launch_topk(c->d_clsmean, n, c->A_tot * m.num_classes, c->Kc, c->d_cand_flat, c->stream);
-    a.cand_flat = c->d_cand_flat;
+    float* cm = c->d_clsmean + (size_t)i0 * c->A_tot * C;
+    int32_t* cf = c->d_cand_flat + (size_t)i0 * K;
+    launch_class_mean(a, cm, st);
+    launch_topk(cm, n, c->A_tot * m.num_classes, c->Kc, cf, st);
+    a.cand_flat = cf;
   }
-  launch_aggregate(a, c->stream);
+  launch_aggregate(a, st);
   return 0;
 }
 
-static int run_post_global(uda_ctx* c, int n) {
+static NmsArgs nms_args_at(uda_ctx::NmsWs& w, size_t p0, int problems, int K, int M, const float* boxes) {
+  NmsArgs a{};
+  a.boxes = boxes;
+  const size_t k = (size_t)K, mm = (size_t)M;
+  a.stale = w.stale + p0 * k; a.begin = w.begin + p0 * k; a.tent = w.tent + p0 * k; a.ub = w.ub + p0 * k; a.ev = w.ev + p0 * k;
+  a.sel_idx = w.sel_idx + p0 * mm; a.sel_score = w.sel_score + p0 * mm; a.sel_box = w.sel_box + p0 * mm * 4;
+  a.bound_key = w.bound + p0 * mm; a.win_key = w.win + p0 * mm; a.nsel = w.nsel + p0; a.done = w.done + p0;
+  a.n_img = problems; a.K = K; a.M = M;
+  a.segs = 1; a.classes = nullptr;
+  return a;
+}
+
+static int run_post_global(uda_ctx* c, int i0, int n, hipStream_t st) {
   const uda_model_t& m = c->model;
-  int rc = run_candidates(c, n);
+  int rc = run_candidates(c, i0, n, st);
   if (rc) return rc;
   const int K = c->Kc, M = m.max_output_size;
+  const size_t k = (size_t)K, mm = (size_t)M, C = (size_t)m.num_classes;
+  const size_t uc = m.max_nms_inputs > 0 ? 1 : C;
   {
-    ProfScope ps(c, 17);
-    NmsArgs na = nms_args_of(c->ws[0], n, K, M, c->d_cboxes);
+    ProfScope ps(c, 17, st);
+    NmsArgs na = nms_args_at(c->ws[0], (size_t)i0, n, K, M, c->d_cboxes + (size_t)i0 * k * 4);
     nms_params(na, m.nms_iou_thresh, m.nms_score_thresh, m.nms_soft_sigma);
-    launch_nms_init(na, c->d_cscores, c->stream);
-    for (int k = 0; k < M; ++k) launch_nms_epoch(na, k, c->stream);
+    launch_nms_init(na, c->d_cscores + (size_t)i0 * k, st);
+    for (int e = 0; e < M; ++e) launch_nms_epoch(na, e, st);
   }
   GatherArgs g{};
-  g.sel_idx = c->ws[0].sel_idx; g.sel_score = c->ws[0].sel_score; g.nsel = c->ws[0].nsel;
-  g.boxes = c->d_cboxes; g.classes = c->d_cclasses; g.logits = c->d_clogits;
-  g.u_cls = c->d_ucls; g.u_al = c->d_ual; g.u_ep = c->d_uep;
-  g.scales = c->d_scales;
-  g.out_boxes = c->d_oboxes; g.out_scores = c->d_oscores; g.out_classes = c->d_oclasses;
-  g.out_valid = c->d_ovalid; g.out_logits = c->d_ologits;
-  g.n_img = n; g.K = K; g.M = M; g.C = m.num_classes;
   g.box_cols = box_cols_of(m, UDA_POST_GLOBAL);
   g.cls_cols = cls_cols_of(m, UDA_POST_GLOBAL);
   g.ucls_cols = g.cls_cols - 1;
+  g.sel_idx = c->ws[0].sel_idx + i0 * mm; g.sel_score = c->ws[0].sel_score + i0 * mm; g.nsel = c->ws[0].nsel + i0;
+  g.boxes = c->d_cboxes + i0 * k * 4; g.classes = c->d_cclasses + i0 * k; g.logits = c->d_clogits + i0 * k * C;
+  g.u_cls = c->d_ucls ? c->d_ucls + i0 * k * uc : nullptr;
+  g.u_al = c->d_ual ? c->d_ual + i0 * k * 4 : nullptr;
+  g.u_ep = c->d_uep ? c->d_uep + i0 * k * 4 : nullptr;
+  g.scales = c->d_scales + i0;
+  g.out_boxes = c->d_oboxes + i0 * mm * g.box_cols; g.out_scores = c->d_oscores + i0 * mm;
+  g.out_classes = c->d_oclasses + i0 * mm * g.cls_cols;
+  g.out_valid = c->d_ovalid + i0; g.out_logits = c->d_ologits + i0 * mm * C;
+  g.n_img = n; g.K = K; g.M = M; g.C = m.num_classes;
   g.clip_h = (float)m.image_h; g.clip_w = (float)m.image_w; g.clip = 1;
-  launch_gather(g, c->stream);
+  launch_gather(g, st);
   HIPC(c, hipGetLastError());
-  c->last_post_mode = UDA_POST_GLOBAL;
-  c->last_n = n;
   return 0;
 }
 
 // a17: one NMS problem per (image, class), then concat / pad / top-M (postprocess.py:624-740)
-static int run_post_per_class(uda_ctx* c, int n) {
+static int run_post_per_class(uda_ctx* c, int i0, int n, hipStream_t st) {
   const uda_model_t& m = c->model;
-  int rc = run_candidates(c, n);
+  int rc = run_candidates(c, i0, n, st);
   if (rc) return rc;
   const int K = c->Kc, M = m.max_output_size, C = m.num_classes;
-  const size_t N = (size_t)m.max_images;
-  HIPC(c, alloc_nms_ws(c->ws[1], N * C, (size_t)K, (size_t)M));
-  if (!c->d_merge_keys) HIPC(c, dalloc(&c->d_merge_keys, N * ((size_t)C * M + M)));
+  const size_t k = (size_t)K, mm = (size_t)M;
+  const size_t p0 = (size_t)i0 * C;
   {
-    ProfScope ps(c, 17);
-    NmsArgs na = nms_args_of(c->ws[1], n * C, K, M, c->d_cboxes);
+    ProfScope ps(c, 17, st);
+    NmsArgs na = nms_args_at(c->ws[1], p0, n * C, K, M, c->d_cboxes + (size_t)i0 * k * 4);
     na.segs = C;
-    na.classes = c->d_cclasses;
+    na.classes = c->d_cclasses + (size_t)i0 * k;
     nms_params(na, m.nms_iou_thresh, m.nms_score_thresh, m.nms_soft_sigma);
-    launch_nms_init(na, c->d_cscores, c->stream);
-    for (int k = 0; k < M; ++k) launch_nms_epoch(na, k, c->stream);
+    launch_nms_init(na, c->d_cscores + (size_t)i0 * k, st);
+    for (int e = 0; e < M; ++e) launch_nms_epoch(na, e, st);
   }
   MergeArgs g{};
-  g.sel_idx = c->ws[1].sel_idx; g.sel_score = c->ws[1].sel_score; g.nsel = c->ws[1].nsel;
-  g.boxes = c->d_cboxes; g.scales = c->d_scales; g.keys = c->d_merge_keys;
-  g.out_boxes = c->d_oboxes; g.out_scores = c->d_oscores; g.out_classes = c->d_oclasses; g.out_valid = c->d_ovalid;
+  g.sel_idx = c->ws[1].sel_idx + p0 * mm; g.sel_score = c->ws[1].sel_score + p0 * mm; g.nsel = c->ws[1].nsel + p0;
+  g.boxes = c->d_cboxes + (size_t)i0 * k * 4; g.scales = c->d_scales + i0;
+  g.keys = c->d_merge_keys + (size_t)i0 * ((size_t)C * M + M);
+  g.out_boxes = c->d_oboxes + i0 * mm * 4; g.out_scores = c->d_oscores + i0 * mm;
+  g.out_classes = c->d_oclasses + i0 * mm; g.out_valid = c->d_ovalid + i0;
   g.n_img = n; g.K = K; g.M = M; g.C = C;
-  launch_merge_per_class(g, c->stream);
+  launch_merge_per_class(g, st);
   HIPC(c, hipGetLastError());
-  c->last_post_mode = UDA_POST_PER_CLASS;
-  c->last_n = n;
+  return 0;
+}
+
+static int run_post_range(uda_ctx* c, int i0, int n, int pm, hipStream_t st) {
+  if (pm == UDA_POST_GLOBAL) return run_post_global(c, i0, n, st);
+  if (pm == UDA_POST_PER_CLASS) return run_post_per_class(c, i0, n, st);
+  return fail(c, "unknown post mode %d", pm);
+}
+
+static int prepare_post(uda_ctx* c, int pm) {
+  if (pm != UDA_POST_PER_CLASS) return 0;
+  const uda_model_t& m = c->model;
+  const size_t N = (size_t)m.max_images, C = (size_t)m.num_classes, M = (size_t)m.max_output_size;
+  HIPC(c, alloc_nms_ws(c->ws[1], N * C, (size_t)c->Kc, M));
+  if (!c->d_merge_keys) HIPC(c, dalloc(&c->d_merge_keys, N * (C * M + M)));
   return 0;
 }
 
 static int run_post(uda_ctx* c, int n, int post_mode) {
   const int pm = post_mode < 0 ? c->model.post_mode : post_mode;
-  if (pm == UDA_POST_GLOBAL) return run_post_global(c, n);
-  if (pm == UDA_POST_PER_CLASS) return run_post_per_class(c, n);
-  return fail(c, "unknown post mode %d", pm);
+  int rc = prepare_post(c, pm);
+  if (rc) return rc;
+  rc = run_post_range(c, 0, n, pm, c->stream);
+  if (rc) return rc;
+  c->last_post_mode = pm;
+  c->last_n = n;
+  return 0;
 }
 
 extern "C" int uda_run(uda_ctx_t* c, int32_t post_mode, int32_t do_post) {
   if (!c) return 1;
   if (c->n_images < 1) return fail(c, "uda_run: no images set");
   HIPC(c, hipSetDevice(c->device));
+  if (do_post && c->post_overlap) {
+    const int pm = post_mode < 0 ? c->model.post_mode : post_mode;
+    if (pm != UDA_POST_GLOBAL && pm != UDA_POST_PER_CLASS) return fail(c, "unknown post mode %d", pm);
+    int rc = prepare_post(c, pm);
+    if (rc) return rc;
+    return run_network(c, pm, true);
+  }
   int rc = run_network(c);
   if (rc) return rc;
   if (do_post) rc = run_post(c, c->n_images, post_mode);

@@ -152,6 +152,7 @@ struct AggArgs {
   float* u_cls;          // [n, K, C] (argmax path) / [n, K, 1] (top-k path) or null
   float* u_al;           // [n, A_tot, 4] or null
   float* u_ep;           // [n, A_tot, 4] or null
+  int park_all, cls_slots;   // set by launch_aggregate: LDS parking layout of the class logits
 };
 void launch_aggregate(const AggArgs& a, hipStream_t s);
 // mean logits of every (anchor, class): out [n, A_tot*C]   (input of the top-k pre-selection)
