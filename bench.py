@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 KIND_NAMES = {1: "stem_kernel", 2: "pw_kernel", 3: "dw_kernel", 4: "se_kernel", 5: "fuse_kernel",
-              6: "fuse_kernel(pool)", 7: "mbx_kernel", 16: "aggregate_kernel", 17: "nms_*", 18: "preprocess_kernel"}
+              6: "fuse_kernel(pool)", 7: "mbx_kernel", 8: "sep_kernel", 16: "aggregate_kernel", 17: "nms_*", 18: "preprocess_kernel"}
 
 
 def parse():
@@ -144,7 +144,7 @@ def main():
         return det
 
     # warm-up; the first warm-up step also ranks the kernel kinds by device time
-    kinds = [1, 2, 3, 4, 5, 6, 7, 16, 17, 18]
+    kinds = [1, 2, 3, 4, 5, 6, 7, 8, 16, 17, 18]
     calib = {}
     for i in range(max(1, a.warmup)):
         if i == 0:

@@ -54,9 +54,12 @@ enum uda_op_kind {
   UDA_OP_SE = 4,    /* mean -> fc+bias -> swish -> fc+bias -> sigmoid   :219-232 */
   UDA_OP_FUSE = 5,  /* BiFPN weighted fusion of resampled inputs + swish  efficientdet_keras.py:86-127,229-231 */
   UDA_OP_POOL = 6,  /* max pool (stride+1) x (stride+1), stride s, SAME   efficientdet_keras.py:280-290 */
-  UDA_OP_MBX = 7    /* fused MBConv front half: 1x1 expand + BN + swish + dropout -> depthwise kxk/s + BN + swish
+  UDA_OP_MBX = 7,   /* fused MBConv front half: 1x1 expand + BN + swish + dropout -> depthwise kxk/s + BN + swish
                        + dropout + SE tile sums, the 6x-expanded tensor never leaves the CU
                        (efficientnet_model.py:446-464) */
+  UDA_OP_SEP = 8    /* fused SeparableConv2D: depthwise 3x3 stride 1 SAME (kernel at w2_off) -> 1x1 (kernel at w_off)
+                       (+bias)(+BN)(+swish)(+dropout); the depthwise result never leaves the CU
+                       (efficientdet_keras.py:207-227,421-446,584-626) */
 };
 enum uda_act { UDA_ACT_NONE = 0, UDA_ACT_SWISH = 1 };
 enum uda_resample { UDA_RS_NONE = 0, UDA_RS_NEAREST_UP = 1, UDA_RS_MAXPOOL = 2 };
@@ -81,7 +84,7 @@ typedef struct uda_op {
   float fuse_w[UDA_MAX_FUSE_INPUTS];     /* FUSE: relu(w_i) / (sum relu(w) + 1e-4) */
   int32_t n_in;
   int32_t drop_site2;              /* MBX: dropout site after the depthwise stage (drop_site = after the expand stage) */
-  int64_t w2_off;                  /* MBX: depthwise kernel [k*k][Cmid] */
+  int64_t w2_off;                  /* MBX: depthwise kernel [k*k][Cmid]; SEP: depthwise kernel [9][C] */
   int64_t bn2_scale_off, bn2_shift_off; /* MBX: BN after the depthwise stage */
 } uda_op_t;
 

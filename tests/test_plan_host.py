@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 
+
 from common import FULL_MC, HEAD_MC, LOSS_ATT, PLAIN, BOX_ONLY_MC, make_params, make_weights
 from uda_amd import arch, capi, hparams_config as hp, plan as plan_mod, weights as W
 
@@ -100,10 +101,12 @@ def test_op_list_shape_d0():
     kinds = [o["kind"] for o in pl.ops]
     fused = kinds.count(capi.OP_MBX)           # blocks 1-5 (Cin <= 48) run expand+depthwise as one op
     assert fused == (5 if plan_mod.mbx_supported(16, 96, 3, 2) else 0)
-    assert len(pl.ops) == 224 - fused
+    sep = kinds.count(capi.OP_SEP)             # 24 BiFPN nodes + 2 heads x 5 levels x (3 + 1) separable convs
+    assert sep == (64 if pl.fuse_sep else 0)
+    assert len(pl.ops) == 224 - fused - sep
     assert kinds.count(capi.OP_STEM) == 1 and kinds.count(capi.OP_SE) == 16 and kinds.count(capi.OP_FUSE) == 24
-    assert kinds.count(capi.OP_POOL) == 2 and kinds.count(capi.OP_DW) == 16 + 24 + 40 - fused
-    assert kinds.count(capi.OP_PW) == 31 + 1 + 5 + 24 + 40 - fused
+    assert kinds.count(capi.OP_POOL) == 2 and kinds.count(capi.OP_DW) == 16 + 24 + 40 - fused - sep
+    assert kinds.count(capi.OP_PW) == 31 + 1 + 5 + 24 + 40 - fused - sep
     assert len(pl.sites) == 61 and pl.T == 3
 
 
@@ -122,7 +125,8 @@ def test_sample_axis_propagation():
     head, _ = _plan(HEAD_MC)
     hb = head.buffer_names
     assert not head.bufs[hb["blocks_15/out"]].per_sample and not head.bufs[hb["cell2/fnode7/out"]].per_sample
-    assert not head.bufs[hb["class-0-3/dw"]].per_sample          # depthwise before the first head dropout is shared
+    assert "class-0-3/dw" not in hb                                # the head's separable convs are single fused ops
+    assert any(o["kind"] == capi.OP_SEP and head.bufs[o["out"]].name == "class-0-3" for o in head.ops)
     assert head.bufs[hb["class-0-3"]].per_sample and head.bufs[hb["box-predict-7"]].per_sample
     assert all(o["drop_site"] == -1 for o in head.ops if head.bufs[o["out"]].name.startswith("blocks_"))
     box_only, _ = _plan(BOX_ONLY_MC)
@@ -199,6 +203,8 @@ def test_cost_accounting_close_to_survey_figures():
     pl = plan_mod.Plan(p, make_weights(p), chunk_images=2, max_images=32)
     costs = plan_mod.op_costs(pl, 32)
     gmac_per_w = sum(v["flops"] for v in costs.values()) / 2 / 320 / 1e9
-    assert 8.0 < gmac_per_w < 8.5
+    assert 7.9 < gmac_per_w < 8.5        # block 0's depthwise also runs once per image (deferred dropout)
     fused = costs.get(capi.OP_MBX, dict(launches=0))["launches"] // 16
-    assert costs[capi.OP_PW]["launches"] == (101 - fused) * 16 and costs[capi.OP_DW]["launches"] == (80 - fused) * 16
+    sep = costs.get(capi.OP_SEP, dict(launches=0))["launches"] // 16
+    assert costs[capi.OP_PW]["launches"] == (101 - fused - sep) * 16
+    assert costs[capi.OP_DW]["launches"] == (80 - fused - sep) * 16

@@ -39,7 +39,7 @@ def pmc_per_op(path, counter, scale):
 
 
 rows = list(csv.DictReader(open(a.trace)))
-names = ("stem_kernel", "pw_kernel", "pwb_kernel", "dw_kernel", "se_kernel", "fuse_kernel", "mbx_kernel", "mbxb_kernel")
+names = ("stem_kernel", "pw_kernel", "pwb_kernel", "dw_kernel", "se_kernel", "fuse_kernel", "mbx_kernel", "mbxb_kernel", "sep_kernel")
 idx = [i for i, r in enumerate(rows) if "preprocess" in r["Kernel_Name"]]
 rows = rows[idx[-1]:]
 conv = [r for r in rows if any(n in r["Kernel_Name"] for n in names)]
@@ -69,6 +69,10 @@ for o, r in zip(pl.ops, first):
         ib = pl.bufs[o["ins"][0]]
         fl = 2 * rows_ * (ib.H * ib.W * ib.C * ob.C + ob.H * ob.W * ob.C * o["k"] ** 2)
         desc = "mbx %d->%d k%d s%d @%dx%d" % (ib.C, ob.C, o["k"], o["stride"], ob.H, ob.W)
+    elif o["kind"] == capi.OP_SEP:
+        ib = pl.bufs[o["ins"][0]]
+        fl = 2 * rows_ * ob.H * ob.W * (9 * ib.C + ib.C * ob.C)
+        desc = "sep %d->%d @%dx%d" % (ib.C, ob.C, ob.H, ob.W)
     else:
         desc = {1: "stem", 4: "se", 5: "fuse", 6: "pool"}[o["kind"]] + " C=%d @%dx%d" % (ob.C, ob.H, ob.W)
     res.append((dur, desc, ob.name, by * 4, fl, r["Kernel_Name"].split("(")[0][-16:], r["VGPR_Count"]))
@@ -78,7 +82,7 @@ if fetch or write:
     res = [r + ((fetch[i] if fetch else 0.0) + (write[i] if write else 0.0),) for i, r in enumerate(res)]
 tot = sum(r[0] for r in res)
 print("chunk of %d images: %d ops, %.2f ms kernel time" % (a.chunk, nops, tot / 1e3))
-for kind in ("pw", "dw", "mbx", "se", "fuse", "stem", "pool"):
+for kind in ("pw", "dw", "mbx", "sep", "se", "fuse", "stem", "pool"):
     sel = [r for r in res if r[1].startswith(kind)]
     if sel:
         t = sum(r[0] for r in sel)

@@ -18,7 +18,7 @@ UDA_ABI_VERSION = 1
 MAX_LEVELS = 8
 MAX_FUSE = 3
 
-OP_STEM, OP_PW, OP_DW, OP_SE, OP_FUSE, OP_POOL, OP_MBX = 1, 2, 3, 4, 5, 6, 7
+OP_STEM, OP_PW, OP_DW, OP_SE, OP_FUSE, OP_POOL, OP_MBX, OP_SEP = 1, 2, 3, 4, 5, 6, 7, 8
 ACT_NONE, ACT_SWISH = 0, 1
 RS_NONE, RS_NEAREST_UP, RS_MAXPOOL = 0, 1, 2
 DECODE_PLAIN, DECODE_LNORM, DECODE_FALSEDEC = 0, 1, 2

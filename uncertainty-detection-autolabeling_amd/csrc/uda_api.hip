@@ -307,8 +307,15 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
       uda_destroy(c);
       return 1;
     }
+    if (o.kind == UDA_OP_SEP && (o.w_off < 0 || o.w2_off < 0 || !sep_supported(bufs[o.in[0]].C, bufs[o.out].C) ||
+                                 bufs[o.in[0]].H != bufs[o.out].H || bufs[o.in[0]].W != bufs[o.out].W)) {
+      fail(nullptr, "op %d: fused separable conv %d->%d unsupported (needs both kernels, C %% 8 == 0, 16 <= C <= 128, same size)",
+           i, bufs[o.in[0]].C, bufs[o.out].C);
+      uda_destroy(c);
+      return 1;
+    }
     const int64_t offs[] = {o.w_off, o.bias_off, o.bn_scale_off, o.bn_shift_off, o.se_w1_off, o.se_b1_off, o.se_w2_off, o.se_b2_off,
-                            o.kind == UDA_OP_MBX ? o.w2_off : -1, o.kind == UDA_OP_MBX ? o.bn2_scale_off : -1,
+                            (o.kind == UDA_OP_MBX || o.kind == UDA_OP_SEP) ? o.w2_off : -1, o.kind == UDA_OP_MBX ? o.bn2_scale_off : -1,
                             o.kind == UDA_OP_MBX ? o.bn2_shift_off : -1};
     for (int64_t off : offs)
       if (off >= n_weights) { fail(nullptr, "op %d: weight offset %lld beyond blob (%lld)", i, (long long)off, (long long)n_weights); uda_destroy(c); return 1; }
@@ -349,7 +356,7 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
         if (o.w_off < 0) continue;
         const int K = bufs[o.in[0]].C, Nn = bufs[o.out].C;
         const size_t at = packed.size();
-        if (o.kind == UDA_OP_PW) {
+        if (o.kind == UDA_OP_PW || o.kind == UDA_OP_SEP) {
           packed.resize(at + pwb_packed_elems(K, Nn, c->pw_parts));
           pwb_pack_weights(weights + o.w_off, K, Nn, c->pw_parts, packed.data() + at);
         } else if (o.kind == UDA_OP_MBX && mbx_bf16 && o.bn_scale_off >= 0 && o.bn_shift_off >= 0 &&
@@ -705,6 +712,25 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       } else {
         launch_mbx(a, rows, o.k, o.stride, v.stream());
       }
+      break;
+    }
+    case UDA_OP_SEP: {
+      const uda_buf_desc_t& ib = c->bufs[o.in[0]];
+      if (c->wsplit_off[oi] < 0) return fail(c, "op %d: fused separable conv needs the split-bf16 path (UDA_PW_TERMS != 0)", oi);
+      SepArgs a{};
+      a.in = v.ptr(o.in[0]);
+      a.out = v.ptr(o.out);
+      a.wd = v.wt(o.w2_off);
+      a.wsplit = c->d_wsplit + c->wsplit_off[oi];
+      a.wparts = c->pw_parts;
+      a.bias = v.wt(o.bias_off);
+      a.bn_scale = v.wt(o.bn_scale_off);
+      a.bn_shift = v.wt(o.bn_shift_off);
+      a.mask = v.mask(o.drop_site);
+      a.H = ob.H; a.W = ob.W; a.C = ib.C; a.Cout = ob.C;
+      a.in_div = v.div(ib, ob);
+      a.act = o.act;
+      launch_sep(a, rows, v.stream());
       break;
     }
     case UDA_OP_SE: {

@@ -41,6 +41,23 @@ void launch_pwb(const PwArgs& a, int rows, hipStream_t s);
 size_t pwb_packed_elems(int K, int N, int parts);
 void pwb_pack_weights(const float* w, int K, int N, int parts, uint16_t* out);
 
+struct SepArgs {          // fused depthwise 3x3 (stride 1, SAME) + 1x1 (kernels_pwb.hip)
+  const float* in;        // [rows / in_div, H, W, C]
+  float* out;             // [rows, H, W, Cout]
+  const float* wd;        // depthwise kernel [9, C]
+  const void* wsplit;     // 1x1 kernel [C, Cout] as split-bf16 fragments
+  const float* bias;      // [Cout] or null
+  const float* bn_scale;  // [Cout] or null
+  const float* bn_shift;
+  const float* mask;      // [rows, Cout] dropout keep-scale or null
+  int H, W, C, Cout;
+  int in_div;
+  int act;
+  int wparts;
+};
+void launch_sep(const SepArgs& a, int rows, hipStream_t s);
+bool sep_supported(int C, int Cout);
+
 struct DwArgs {
   const float* in;       // [rows_in, H, W, C]
   float* out;            // [rows, Ho, Wo, C]

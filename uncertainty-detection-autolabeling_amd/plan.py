@@ -94,6 +94,7 @@ class Plan:
         self.buffer_names = {}
         import os
         self.defer_dropout = bool(int(os.environ.get("UDA_DEFER_DROPOUT", "1")))
+        self.fuse_sep = bool(int(os.environ.get("UDA_FUSE_SEP", "1"))) and int(os.environ.get("UDA_PW_TERMS", "3")) != 0
         self._build_sites()
         self._lower()
         self._plan_memory()
@@ -188,6 +189,24 @@ class Plan:
             kw["se_partial"] = self._buf(dw_tiles(xb.C, Ho, Wo, k, stride), 1, xb.C, ps, name=name + "/se_partial")
         self._op(capi.OP_DW, [x], out, **kw)
         return out, kw.get("se_partial", -1)
+
+    def _sepconv(self, x, cout, dw_kernel, pw_kernel, name, bias=None, bn=None, act=capi.ACT_NONE, site=-1,
+                 out_kind=0, level=0):
+        """SeparableConv2D = depthwise 3x3 (no bias / BN / act) -> 1x1 + bias (+BN)(+act)(+dropout).  One fused op
+        when the kernel supports the channel count, else the depthwise / pointwise pair."""
+        xb = self.bufs[x]
+        if not (self.fuse_sep and xb.C % 8 == 0 and 16 <= xb.C <= 128):
+            d, _ = self._dw(x, 3, 1, dw_kernel, name + "/dw")
+            return self._pw(d, cout, pw_kernel, name, bias=bias, bn=bn, act=act, site=site, out_kind=out_kind, level=level)
+        ps = xb.per_sample or site >= 0
+        out = self._buf(xb.H, xb.W, cout, ps, out_kind, level, name)
+        kw = dict(k=3, stride=1, w_off=self._pack(self.w[pw_kernel]), w2_off=self._pack(self.w[dw_kernel]), act=act,
+                  drop_site=site)
+        if bias is not None:
+            kw["bias_off"] = self._pack(self.w[bias])
+        if bn is not None:
+            kw["bn_scale_off"], kw["bn_shift_off"] = self._bn(bn)
+        return self._op(capi.OP_SEP, [x], out, **kw)
 
     def _resample(self, x, th, tw, prefix, name):
         """ResampleFeatureMap.call: optional 1x1+BN to F channels, then (mode for the consumer)."""
@@ -318,9 +337,8 @@ class Plan:
                 fused = self._op(capi.OP_FUSE, ins, self._buf(tgt.H, tgt.W, F, ps, name="cell%d/fnode%d/fused" % (rep, n)),
                                  act=capi.ACT_SWISH, resample=(modes + [0, 0, 0])[:3], fuse_w=(fw + [0, 0, 0])[:3])
                 op = p + "op_after_combine%d" % nf
-                d, _ = self._dw(fused, 3, 1, op + "/conv/depthwise_kernel", "cell%d/fnode%d/dw" % (rep, n))
-                cell.append(self._pw(d, F, op + "/conv/pointwise_kernel", "cell%d/fnode%d/out" % (rep, n),
-                                     bias=op + "/conv/bias", bn=op + "/bn"))
+                cell.append(self._sepconv(fused, F, op + "/conv/depthwise_kernel", op + "/conv/pointwise_kernel",
+                                          "cell%d/fnode%d/out" % (rep, n), bias=op + "/conv/bias", bn=op + "/bn"))
             feats = []
             for lvl in range(lo, hi + 1):
                 for i, node in enumerate(reversed(nodes)):
@@ -339,14 +357,13 @@ class Plan:
                 x = f
                 for i in range(cfg["box_class_repeats"]):
                     pre = "%s/%s-%d" % (net, tag, i)
-                    d, _ = self._dw(x, 3, 1, pre + "/depthwise_kernel", "%s-%d-%d/dw" % (tag, i, lo + li))
-                    x = self._pw(d, F, pre + "/pointwise_kernel", "%s-%d-%d" % (tag, i, lo + li),
-                                 bias=pre + "/bias", bn="%s/%s-%d-bn-%d" % (net, tag, i, lo + li),
-                                 act=capi.ACT_SWISH, site=self._site("%s-%d-%d" % (tag, i, lo + li)))
+                    x = self._sepconv(x, F, pre + "/depthwise_kernel", pre + "/pointwise_kernel",
+                                      "%s-%d-%d" % (tag, i, lo + li), bias=pre + "/bias",
+                                      bn="%s/%s-%d-bn-%d" % (net, tag, i, lo + li), act=capi.ACT_SWISH,
+                                      site=self._site("%s-%d-%d" % (tag, i, lo + li)))
                 pre = "%s/%s-predict" % (net, tag)
-                d, _ = self._dw(x, 3, 1, pre + "/depthwise_kernel", "%s-predict-%d/dw" % (tag, lo + li))
-                out = self._pw(d, outc, pre + "/pointwise_kernel", "%s-predict-%d" % (tag, lo + li),
-                               bias=pre + "/bias", out_kind=kind, level=li)
+                out = self._sepconv(x, outc, pre + "/depthwise_kernel", pre + "/pointwise_kernel",
+                                    "%s-predict-%d" % (tag, lo + li), bias=pre + "/bias", out_kind=kind, level=li)
                 self.head_out[tag].append(out)
         # the head buffers must carry the sample axis exactly when the reference stacks them
         for tag, stacked in (("class", self.cls_stacked), ("box", self.box_stacked)):
@@ -564,6 +581,10 @@ def op_costs(plan, n_images):
             ib = plan.bufs[o["ins"][0]]
             by += ib.C * ob.C + o["k"] * o["k"] * ob.C
             fl = 2 * rows * (ib.H * ib.W * ib.C * ob.C + ob.H * ob.W * ob.C * o["k"] * o["k"])
+        elif k == capi.OP_SEP:
+            ib = plan.bufs[o["ins"][0]]
+            by += ib.C * ob.C + 9 * ib.C
+            fl = 2 * rows * ob.H * ob.W * (9 * ib.C + ib.C * ob.C)
         elif k == capi.OP_SE:
             fl = 4 * rows * ob.C * o["se_mid"]
         elif k in (capi.OP_FUSE, capi.OP_POOL):
