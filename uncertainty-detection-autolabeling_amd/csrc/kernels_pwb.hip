@@ -558,6 +558,8 @@ __global__ __launch_bounds__(256, (KSF >= 3 ? 2 : 3)) void mbxb_kernel(MbxArgs a
   extern __shared__ float mlds[];
   float* E = mlds;                            // [NPP][ES]
   float* red = E + (size_t)NPP * ES;          // [NG][32]
+  constexpr int NPAR = (K * K + 3) * 32;      // per slab: depthwise taps [K*K][32] | BN scale | BN shift | mask1
+  float* par = red + NG * 32;                 // [2][NPAR]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -617,17 +619,26 @@ __global__ __launch_bounds__(256, (KSF >= 3 ? 2 : 3)) void mbxb_kernel(MbxArgs a
     const int ecol = ch * 32 + li;
     q.mk0 = (ecol < a.Cmid && a.mask0) ? a.mask0[(size_t)b * a.Cmid + ecol] : 1.f;
   };
+  // the depthwise-side operands of a slab go through LDS, requested (like the B fragments) before the previous
+  // slab's output stores are issued: vmcnt retires loads and stores in order
+  auto par_value = [&](int chn, int f) -> float {
+    const int row = f >> 5, pcol = chn * 32 + (f & 31);
+    if (pcol >= a.Cmid) return 0.f;
+    if (row < K * K) return a.wd[(size_t)row * a.Cmid + pcol];
+    if (row == K * K) return a.sc1[pcol];
+    if (row == K * K + 1) return a.sh1[pcol];
+    return a.mask1 ? a.mask1[(size_t)b * a.Cmid + pcol] : 1.f;
+  };
+  constexpr int P_PER = (NPAR + 255) / 256;
   SlabB cur, nxt;
   load_b(0, cur);
+  for (int f = tid; f < NPAR; f += 256) par[f] = par_value(0, f);
+  __syncthreads();
 
   for (int ch = 0; ch < NCH; ++ch) {
     const int col = ch * 32 + c;
     const bool dcol = col < a.Cmid;
-    float wk[K * K];
-#pragma unroll
-    for (int t = 0; t < K * K; ++t) wk[t] = dcol ? a.wd[(size_t)t * a.Cmid + col] : 0.f;
-    const float sc1 = dcol ? a.sc1[col] : 0.f, sh1 = dcol ? a.sh1[col] : 0.f;
-    const float mk1 = (dcol && a.mask1) ? a.mask1[(size_t)b * a.Cmid + col] : 1.f;
+    const float* pcur = par + (ch & 1) * NPAR;
     // ---- expand: E[p][j] = swish(sum_k X[p][k] We'[k][32 ch + j]) * mask0
 #pragma unroll
     for (int t = 0; t < MTW; ++t) {
@@ -648,9 +659,20 @@ __global__ __launch_bounds__(256, (KSF >= 3 ? 2 : 3)) void mbxb_kernel(MbxArgs a
         for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swishf_b(acc[r]) * cur.mk0;
       }
     }
-    if (ch + 1 < NCH) load_b(ch + 1, nxt);   // in flight during the depthwise phase
+    const bool more = ch + 1 < NCH;
+    if (more) load_b(ch + 1, nxt);   // in flight during the depthwise phase
+    float np_[P_PER];
+#pragma unroll
+    for (int i = 0; i < P_PER; ++i) {
+      const int f = tid + 256 * i;
+      np_[i] = (more && f < NPAR) ? par_value(ch + 1, f) : 0.f;
+    }
     __syncthreads();
     // ---- depthwise on E for channel 32 ch + c
+    float wk[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) wk[t] = pcur[t * 32 + c];
+    const float sc1 = pcur[K * K * 32 + c], sh1 = pcur[(K * K + 1) * 32 + c], mk1 = pcur[(K * K + 2) * 32 + c];
     float ssum = 0.f;
     if (dcol && oy < a.Ho) {
       float acc[XW];
@@ -679,7 +701,15 @@ __global__ __launch_bounds__(256, (KSF >= 3 ? 2 : 3)) void mbxb_kernel(MbxArgs a
       }
     }
     if (a.se_partial) red[g * 32 + c] = ssum;
-    __syncthreads();   // E may be rewritten; red[] of this slab is complete (next written after the next barrier)
+    {
+      float* pnext = par + ((ch + 1) & 1) * NPAR;
+#pragma unroll
+      for (int i = 0; i < P_PER; ++i) {
+        const int f = tid + 256 * i;
+        if (more && f < NPAR) pnext[f] = np_[i];
+      }
+    }
+    __syncthreads();   // E may be rewritten; red[] of this slab and the next slab's operands are complete
     if (a.se_partial && g == 0 && dcol) {
       float t = red[c];
 #pragma unroll
@@ -699,7 +729,7 @@ static void launch_mbxb_t(const MbxArgs& a, int rows, hipStream_t s) {
   constexpr int TH = mbxb_cfg(K, S).th, TW = mbxb_cfg(K, S).tw;
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
   constexpr int NPP = (IH * IW + 31) / 32 * 32;
-  const size_t lds = ((size_t)NPP * 33 + 8 * 32) * sizeof(float);
+  const size_t lds = ((size_t)NPP * 33 + 8 * 32 + 2 * (K * K + 3) * 32) * sizeof(float);
   const dim3 grid((a.Wo + TW - 1) / TW, (a.Ho + TH - 1) / TH, rows);
   hipLaunchKernelGGL((mbxb_kernel<K, S, KSF>), grid, dim3(256), lds, s, a);
 }
@@ -718,6 +748,243 @@ void launch_mbxb(const MbxArgs& a, int rows, int k, int stride, hipStream_t s) {
   else if (k == 3 && stride == 2) launch_mbxb_ks<3, 2>(a, rows, s);
   else if (k == 5 && stride == 1) launch_mbxb_ks<5, 1>(a, rows, s);
   else launch_mbxb_ks<5, 2>(a, rows, s);
+}
+
+// ---------------------------------------------------------------- fused MBConv front half, deep blocks
+// The same fusion for the deep stride-1 blocks (Cin 56..208, expanded width up to 6 * Cin): 8 waves per block,
+// wave w keeps the operand fragments of the w-th 32-pixel slice of the input tile (12 x 16 + halo for 3x3,
+// 8 x 16 + halo for 5x5 = 8 slices) in registers; the packed expand weights of a 32-channel slab are shared
+// through a double-buffered LDS image (requested during the depthwise phase of the previous slab).
+// Per slab: expand (3 MFMAs per k-step) -> E slab in LDS -> barrier -> depthwise + output + SE sums -> barrier.
+template <int K, int KSF>
+__global__ __launch_bounds__(512, 2) void mbxd_kernel(MbxArgs a) {
+  constexpr int NW = 8;
+  constexpr int TH = (K == 3) ? 12 : 8, TW = 16;
+  constexpr int IH = TH + K - 1, IW = TW + K - 1;
+  constexpr int NP = IH * IW;
+  static_assert(NP <= 256, "input tile must fit 8 slices of 32 pixels");
+  constexpr int NPP = 256;
+  constexpr int NG = NW * 2;                  // depthwise thread groups (32 channels each)
+  constexpr int ES = 33;
+  constexpr int XW = (K == 3) ? 4 : 8;        // outputs per unit along x
+  constexpr int UPR = TW / XW;                // units per output row
+  constexpr int NUNIT = TH * UPR;             // 48 (3x3) / 16 (5x5) units over 16 groups
+  constexpr int NCOL = XW + K - 1;
+  constexpr int BSLAB = KSF * 2 * 64;         // uint4 per slab of packed expand weights
+  extern __shared__ __attribute__((aligned(16))) float dlds[];
+  float* E = dlds;                            // [NPP][ES]
+  float* red = E + (size_t)NPP * ES;          // [NG][32]
+  constexpr int NPAR = (K * K + 4) * 32;      // per slab: depthwise taps [K*K][32] | BN scale | BN shift | mask1 | mask0
+  float* par = red + NG * 32;                 // [2][NPAR]
+  uint4* Bs = (uint4*)(par + 2 * NPAR);       // [2][KSF][2 parts][64 lanes]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, b_in = b / a.in_div;
+  const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+  const int iy0 = oy0 - a.pad_t, ix0 = ox0 - a.pad_l;
+  const float* xin = a.in + (size_t)b_in * a.H * a.W * a.Cin;
+  const int NCH = (a.Cmid + 31) >> 5;
+  const uint4* Wp = (const uint4*)a.wsplit;
+  // Every per-slab operand (packed expand weights, depthwise taps, BN / dropout scalars) is requested while the
+  // PREVIOUS slab's expand phase ends, i.e. before that slab's output stores are issued: vmcnt retires loads and
+  // stores in order, so a load issued after the stores would make its consumer wait for the stores' HBM round trip.
+  auto par_value = [&](int chn, int f) -> float {
+    const int row = f >> 5, col = chn * 32 + (f & 31);
+    if (col >= a.Cmid) return 0.f;
+    if (row < K * K) return a.wd[(size_t)row * a.Cmid + col];
+    if (row == K * K) return a.sc1[col];
+    if (row == K * K + 1) return a.sh1[col];
+    if (row == K * K + 2) return a.mask1 ? a.mask1[(size_t)b * a.Cmid + col] : 1.f;
+    return a.mask0 ? a.mask0[(size_t)b * a.Cmid + col] : 1.f;
+  };
+
+  // ---- slab 0 operands -> LDS buffers 0
+  for (int f = tid; f < BSLAB; f += 512) {
+    const int ks = f >> 7, rest = f & 127;     // [ks][part][lane]
+    Bs[f] = Wp[(((size_t)ks * NCH + 0) * 2 + (rest >> 6)) * 64 + (rest & 63)];
+  }
+  for (int f = tid; f < NPAR; f += 512) par[f] = par_value(0, f);
+
+  // ---- this wave's operand fragments: pixel = wave * 32 + li, channels 16 ks + 8 lh .. + 7
+  bf16x8 ah[KSF], al[KSF];
+  {
+    const int p = wave * 32 + li;
+    const int iy = iy0 + p / IW, ix = ix0 + p % IW;
+    const bool in = (p < NP) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    const float* px = xin + ((size_t)(in ? iy : 0) * a.W + (in ? ix : 0)) * a.Cin;
+#pragma unroll
+    for (int ks = 0; ks < KSF; ++ks) {
+      const int k = ks * 16 + 8 * lh;
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      if (in && k < a.Cin) {
+        v0 = *(const float4*)(px + k);
+        v1 = *(const float4*)(px + k + 4);
+      }
+      if (k == a.Cin) v0.x = in ? 1.f : 0.f;          // the "inside the image" channel that carries the BN shift
+      const unsigned h0 = pack_bf16(v0.x, v0.y), h1 = pack_bf16(v0.z, v0.w);
+      const unsigned h2 = pack_bf16(v1.x, v1.y), h3 = pack_bf16(v1.z, v1.w);
+      const unsigned l0 = pack_bf16(v0.x - bf16_lo_f32(h0), v0.y - bf16_hi_f32(h0));
+      const unsigned l1 = pack_bf16(v0.z - bf16_lo_f32(h1), v0.w - bf16_hi_f32(h1));
+      const unsigned l2 = pack_bf16(v1.x - bf16_lo_f32(h2), v1.y - bf16_hi_f32(h2));
+      const unsigned l3 = pack_bf16(v1.z - bf16_lo_f32(h3), v1.w - bf16_hi_f32(h3));
+      ah[ks] = __builtin_bit_cast(bf16x8, make_uint4(h0, h1, h2, h3));
+      al[ks] = __builtin_bit_cast(bf16x8, make_uint4(l0, l1, l2, l3));
+    }
+  }
+  __syncthreads();
+
+  const int c = tid & 31, g = tid >> 5;       // depthwise stage: channel within the slab, thread group
+  const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  constexpr int B_PER = (BSLAB + 511) / 512;  // uint4 of the next slab per thread
+
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int col = ch * 32 + c;
+    const bool dcol = col < a.Cmid;
+    const uint4* bcur = Bs + (size_t)(ch & 1) * BSLAB;
+    const float* pcur = par + (ch & 1) * NPAR;
+    const float mk0 = pcur[(K * K + 3) * 32 + li];
+    // ---- expand: E[p][j] = swish(sum_k X[p][k] We'[k][32 ch + j]) * mask0 for this wave's 32 pixels
+    {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KSF; ++ks) {
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, bcur[(ks * 2 + 0) * 64 + lane]);
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, bcur[(ks * 2 + 1) * 64 + lane]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh, acc, 0, 0, 0);
+      }
+      float* ep = E + (size_t)(wave * 32 + 4 * lh) * ES + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swishf_b(acc[r]) * mk0;
+    }
+    // next slab's packed weights: in flight during the depthwise phase
+    uint4 nb[B_PER];
+    const bool more = ch + 1 < NCH;
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int f = tid + 512 * i;
+      const int ks = f >> 7, rest = f & 127;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (more && f < BSLAB) v = Wp[(((size_t)ks * NCH + (ch + 1)) * 2 + (rest >> 6)) * 64 + (rest & 63)];
+      nb[i] = v;
+    }
+    constexpr int P_PER = (NPAR + 511) / 512;
+    float np_[P_PER];
+#pragma unroll
+    for (int i = 0; i < P_PER; ++i) {
+      const int f = tid + 512 * i;
+      np_[i] = (more && f < NPAR) ? par_value(ch + 1, f) : 0.f;
+    }
+    __syncthreads();
+    // ---- depthwise on E for channel 32 ch + c
+    float wk[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) wk[t] = pcur[t * 32 + c];
+    const float sc1 = pcur[K * K * 32 + c], sh1 = pcur[(K * K + 1) * 32 + c], mk1 = pcur[(K * K + 2) * 32 + c];
+    float ssum = 0.f;
+    if (dcol) {
+      for (int u = g; u < NUNIT; u += NG) {
+        const int orow = u / UPR, oxs = (u % UPR) * XW;
+        const int oy = oy0 + orow;
+        if (oy >= a.Ho) continue;
+        float acc[XW];
+#pragma unroll
+        for (int o = 0; o < XW; ++o) acc[o] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+          float rowv[NCOL];
+          const float* er = E + ((size_t)(orow + ky) * IW + oxs) * ES + c;
+#pragma unroll
+          for (int j = 0; j < NCOL; ++j) rowv[j] = er[j * ES];
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) {
+#pragma unroll
+            for (int o = 0; o < XW; ++o) acc[o] = fmaf(rowv[o + kx], wk[ky * K + kx], acc[o]);
+          }
+        }
+        float* op = a.out + (((size_t)b * a.Ho + oy) * a.Wo + ox0 + oxs) * a.Cmid + col;
+#pragma unroll
+        for (int o = 0; o < XW; ++o) {
+          if (ox0 + oxs + o < a.Wo) {
+            const float v = swishf_b(fmaf(acc[o], sc1, sh1)) * mk1;
+            op[(size_t)o * a.Cmid] = v;
+            ssum += v;
+          }
+        }
+      }
+    }
+    if (a.se_partial) red[g * 32 + c] = ssum;
+    {
+      uint4* bnext = Bs + (size_t)((ch + 1) & 1) * BSLAB;
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i) {
+        const int f = tid + 512 * i;
+        if (more && f < BSLAB) bnext[f] = nb[i];
+      }
+      float* pnext = par + ((ch + 1) & 1) * NPAR;
+#pragma unroll
+      for (int i = 0; i < P_PER; ++i) {
+        const int f = tid + 512 * i;
+        if (more && f < NPAR) pnext[f] = np_[i];
+      }
+    }
+    __syncthreads();   // E may be rewritten; red[] and the next slab's operands are complete
+    if (a.se_partial && g == 0 && dcol) {
+      float t = red[c];
+#pragma unroll
+      for (int gg = 1; gg < NG; ++gg) t += red[gg * 32 + c];
+      a.se_partial[((size_t)b * a.n_tiles + tile) * a.Cmid + col] = t;
+    }
+  }
+}
+
+bool mbxd_supported(int Cin, int Cmid, int k, int stride) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("UDA_FUSE_MBXD"); on = e ? atoi(e) : 1; }
+  const int ksf = (Cin + 1 + 15) / 16;
+  return on && stride == 1 && (k == 3 || k == 5) && Cin % 8 == 0 && Cin > 48 && (ksf == 6 || ksf == 8 || ksf == 13 || ksf == 14) &&
+         Cmid % 4 == 0;
+}
+
+int mbxd_tiles(int Ho, int Wo, int k) {
+  const int th = (k == 3) ? 12 : 8;
+  return ((Ho + th - 1) / th) * ((Wo + 15) / 16);
+}
+
+template <int K, int KSF>
+static void launch_mbxd_t(const MbxArgs& a, int rows, hipStream_t s) {
+  constexpr int TH = (K == 3) ? 12 : 8;
+  const size_t lds = ((size_t)256 * 33 + 16 * 32 + 2 * (K * K + 4) * 32) * sizeof(float) + (size_t)2 * KSF * 2 * 64 * sizeof(uint4);
+  static bool set = false;
+  if (!set && lds > 64 * 1024) {
+    hipFuncSetAttribute((const void*)mbxd_kernel<K, KSF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    set = true;
+  }
+  const dim3 grid((a.Wo + 15) / 16, (a.Ho + TH - 1) / TH, rows);
+  hipLaunchKernelGGL((mbxd_kernel<K, KSF>), grid, dim3(512), lds, s, a);
+}
+
+void launch_mbxd(const MbxArgs& a, int rows, int k, hipStream_t s) {
+  const int ksf = (a.Cin + 1 + 15) / 16;
+  if (k == 3) {
+    switch (ksf) {
+      case 6: launch_mbxd_t<3, 6>(a, rows, s); break;
+      case 8: launch_mbxd_t<3, 8>(a, rows, s); break;
+      case 13: launch_mbxd_t<3, 13>(a, rows, s); break;
+      default: launch_mbxd_t<3, 14>(a, rows, s); break;
+    }
+  } else {
+    switch (ksf) {
+      case 6: launch_mbxd_t<5, 6>(a, rows, s); break;
+      case 8: launch_mbxd_t<5, 8>(a, rows, s); break;
+      case 13: launch_mbxd_t<5, 13>(a, rows, s); break;
+      default: launch_mbxd_t<5, 14>(a, rows, s); break;
+    }
+  }
 }
 
 // expand kernel [Cin][Cmid] times the BN scale, plus the BN shift as row Cin -> packed split-bf16 fragments

@@ -360,7 +360,7 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
           packed.resize(at + pwb_packed_elems(K, Nn, c->pw_parts));
           pwb_pack_weights(weights + o.w_off, K, Nn, c->pw_parts, packed.data() + at);
         } else if (o.kind == UDA_OP_MBX && mbx_bf16 && o.bn_scale_off >= 0 && o.bn_shift_off >= 0 &&
-                   mbxb_supported(K, Nn, o.k, o.stride)) {
+                   (mbxb_supported(K, Nn, o.k, o.stride) || mbxd_supported(K, Nn, o.k, o.stride))) {
           packed.resize(at + mbxb_packed_elems(K, Nn));
           mbxb_pack_weights(weights + o.w_off, weights + o.bn_scale_off, weights + o.bn_shift_off, K, Nn, packed.data() + at);
         } else {
@@ -684,7 +684,9 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
     }
     case UDA_OP_MBX: {
       const uda_buf_desc_t& ib = c->bufs[o.in[0]];
-      if (!mbx_supported(ib.C, ob.C, o.k, o.stride)) return fail(c, "op %d: fused MBConv %d->%d k%d s%d unsupported", oi, ib.C, ob.C, o.k, o.stride);
+      const bool deep = ib.C > 48;
+      if (deep ? !(mbxd_supported(ib.C, ob.C, o.k, o.stride) && c->wsplit_off[oi] >= 0) : !mbx_supported(ib.C, ob.C, o.k, o.stride))
+        return fail(c, "op %d: fused MBConv %d->%d k%d s%d unsupported", oi, ib.C, ob.C, o.k, o.stride);
       if (o.drop_site2 >= c->model.n_drop_sites || (o.drop_site2 >= 0 && c->sites[o.drop_site2].channels != ob.C))
         return fail(c, "op %d: bad second dropout site", oi);
       MbxArgs a{};
@@ -699,7 +701,7 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       a.pad_t = same_pad_before(ib.H, ob.H, o.k, o.stride);
       a.pad_l = same_pad_before(ib.W, ob.W, o.k, o.stride);
       a.in_div = v.div(ib, ob);
-      a.n_tiles = mbx_tiles(ob.H, ob.W, o.k, o.stride);
+      a.n_tiles = deep ? mbxd_tiles(ob.H, ob.W, o.k) : mbx_tiles(ob.H, ob.W, o.k, o.stride);
       if (o.se_partial >= 0) {
         const uda_buf_desc_t& pb = c->bufs[o.se_partial];
         if ((int64_t)pb.H * pb.W != (int64_t)a.n_tiles || pb.C != ob.C || pb.per_sample != ob.per_sample)
@@ -708,7 +710,8 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       }
       if (c->wsplit_off[oi] >= 0) {
         a.wsplit = c->d_wsplit + c->wsplit_off[oi];
-        launch_mbxb(a, rows, o.k, o.stride, v.stream());
+        if (deep) launch_mbxd(a, rows, o.k, v.stream());
+        else launch_mbxb(a, rows, o.k, o.stride, v.stream());
       } else {
         launch_mbx(a, rows, o.k, o.stride, v.stream());
       }

@@ -96,6 +96,9 @@ struct MbxArgs {
   const void* wsplit;     // expand kernel * BN scale (+ BN shift row) as split-bf16 fragments (kernels_pwb.hip) or null
 };
 void launch_mbxb(const MbxArgs& a, int rows, int k, int stride, hipStream_t s);
+void launch_mbxd(const MbxArgs& a, int rows, int k, hipStream_t s);     // deep stride-1 blocks (Cin > 48)
+bool mbxd_supported(int Cin, int Cmid, int k, int stride);
+int mbxd_tiles(int Ho, int Wo, int k);
 bool mbxb_supported(int Cin, int Cmid, int k, int stride);
 size_t mbxb_packed_elems(int Cin, int Cmid);
 void mbxb_pack_weights(const float* we, const float* sc0, const float* sh0, int Cin, int Cmid, uint16_t* out);

@@ -49,20 +49,31 @@ def dw_tiles(C, Ho, Wo, k, stride):
     return -(-Ho // dw_rows(k, stride)) * dw_tiles_x(C, Wo, k, stride)
 
 
-def mbx_tile(k, stride):
-    """(TH, TW) output tile of the fused expand+depthwise kernel (mirror of mbx_cfg in csrc)."""
+def mbx_deep(cin):
+    """Cin > 48: the deep variant of the fused kernel (mbxd_kernel in csrc/kernels_pwb.hip)."""
+    return cin > 48
+
+
+def mbx_tile(k, stride, cin=16):
+    """(TH, TW) output tile of the fused expand+depthwise kernels (mirror of mbx_cfg / mbxd_kernel in csrc)."""
+    if mbx_deep(cin):
+        return (12, 16) if k == 3 else (8, 16)
     return (8, 16) if stride == 1 else ((4, 16) if k == 3 else (4, 8))
 
 
-def mbx_tiles(Ho, Wo, k, stride):
-    th, tw = mbx_tile(k, stride)
+def mbx_tiles(Ho, Wo, k, stride, cin=16):
+    th, tw = mbx_tile(k, stride, cin)
     return -(-Ho // th) * -(-Wo // tw)
 
 
 def mbx_supported(cin, cmid, k, stride):
     import os
-    return (int(os.environ.get("UDA_FUSE_MBX", "1")) and cin % 8 == 0 and 16 <= cin <= 48 and cmid % 4 == 0
-            and k in (3, 5) and stride in (1, 2))
+    if not (int(os.environ.get("UDA_FUSE_MBX", "1")) and cin % 8 == 0 and cmid % 4 == 0 and k in (3, 5)):
+        return False
+    if mbx_deep(cin):       # mirror of mbxd_supported: stride 1, 16-deep k-steps of Cin + 1 in {6, 8, 13, 14}, split-bf16 path on
+        return (int(os.environ.get("UDA_FUSE_MBXD", "1")) and int(os.environ.get("UDA_PW_TERMS", "3")) != 0
+                and int(os.environ.get("UDA_MBX_BF16", "1")) and stride == 1 and (cin + 1 + 15) // 16 in (6, 8, 13, 14))
+    return 16 <= cin and stride in (1, 2)
 
 
 def same_out(n, s):
@@ -257,7 +268,7 @@ class Plan:
                 kw["bn_scale_off"], kw["bn_shift_off"] = self._bn(bn_names[0])
                 kw["bn2_scale_off"], kw["bn2_shift_off"] = self._bn(bn_names[1])
                 if b["se"]:
-                    part = self._buf(mbx_tiles(Ho, Wo, b["kernel"], b["stride"]), 1, mid, ps,
+                    part = self._buf(mbx_tiles(Ho, Wo, b["kernel"], b["stride"], b["cin"]), 1, mid, ps,
                                      name="blocks_%d/dw/se_partial" % i)
                     kw["se_partial"] = part
                 x = self._op(capi.OP_MBX, [x], out, **kw)
