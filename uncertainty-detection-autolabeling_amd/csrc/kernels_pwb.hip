@@ -35,6 +35,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ float sigmoidf_b(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float swishf_b(float x) { return x * sigmoidf_b(x); }
 
+// swish with the exponent scale folded into the producer: y = -log2(e) * x comes out of the GEMM / BN (weights,
+// shift and BN scale are pre-multiplied on the host or when they are staged), k = -keep_scale / log2(e):
+//   x * sigmoid(x) * keep_scale = y * k / (1 + 2^y)        (v_exp, v_add, v_rcp, 2 v_mul: 5 VALU instead of 7)
+constexpr float UDA_NEG_LOG2E = -1.4426950408889634f;
+constexpr float UDA_NEG_LN2 = -0.6931471805599453f;
+__device__ __forceinline__ float swish_folded(float y, float k) {
+  return (y * k) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y));
+}
+
 // two floats -> packed bf16 pair (round to nearest even; v_cvt_pk_bf16_f32), element 0 in the low half
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   const f32x2 v = {a, b};
@@ -537,12 +546,14 @@ void launch_sep(const SepArgs& a, int rows, hipStream_t s) {
 namespace {
 struct MbxCfgB { int th, tw; };
 __host__ __device__ constexpr MbxCfgB mbxb_cfg(int k, int s) {
-  return s == 1 ? MbxCfgB{8, 16} : (k == 3 ? MbxCfgB{4, 16} : MbxCfgB{4, 8});
+  // input tile (with halo) = 8 slices of 32 pixels, two per wave: 3x3 s1 12x16 (14x18 = 252), 3x3 s2 4x12
+  // (9x25 = 225), 5x5 s2 4x10 (11x23 = 253), 5x5 s1 8x16 (12x20 = 240)
+  return s == 1 ? (k == 3 ? MbxCfgB{12, 16} : MbxCfgB{8, 16}) : (k == 3 ? MbxCfgB{4, 12} : MbxCfgB{4, 10});
 }
 }  // namespace
 
 template <int K, int S, int KSF>   // KSF = 16-deep MFMA k-steps covering Cin + 1
-__global__ __launch_bounds__(256, (KSF >= 3 ? 2 : 3)) void mbxb_kernel(MbxArgs a) {
+__global__ __launch_bounds__(256, ((K == 3 && S == 2 && KSF <= 3) ? 3 : 2)) void mbxb_kernel(MbxArgs a) {
   constexpr int NW = 4;
   constexpr int TH = mbxb_cfg(K, S).th, TW = mbxb_cfg(K, S).tw;
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
@@ -552,8 +563,11 @@ __global__ __launch_bounds__(256, (KSF >= 3 ? 2 : 3)) void mbxb_kernel(MbxArgs a
   constexpr int NG = NW * 2;                  // depthwise thread groups (32 channels each)
   constexpr int MTW = (NMT + NW - 1) / NW;    // pixel slices per wave
   constexpr int ES = 33;
-  constexpr int GPR = NG / TH;                // thread groups per output row
-  constexpr int XW = TW / GPR;                // outputs per thread along x
+  // depthwise units: XW consecutive outputs of one row; NUNIT units over the NG thread groups
+  constexpr int XW = (S == 1) ? 8 : (K == 3 ? 6 : 5);
+  constexpr int UPR = TW / XW;                // units per output row
+  constexpr int NUNIT = TH * UPR;             // 24 (3x3 s1), 16 (5x5 s1), 8 (stride 2)
+  static_assert(TW % XW == 0 && NUNIT % NG == 0, "units must tile the output tile and the thread groups");
   constexpr int NCOL = (XW - 1) * S + K;
   extern __shared__ float mlds[];
   float* E = mlds;                            // [NPP][ES]
@@ -598,9 +612,7 @@ __global__ __launch_bounds__(256, (KSF >= 3 ? 2 : 3)) void mbxb_kernel(MbxArgs a
   }
 
   const int c = tid & 31, g = tid >> 5;       // depthwise stage: channel within the slab, thread group
-  const int orow = g / GPR, oxs = (g % GPR) * XW;
   const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-  const int oy = oy0 + orow;
   const int NCH = (a.Cmid + 31) >> 5;
   const uint4* Wp = (const uint4*)a.wsplit;
 
@@ -617,7 +629,7 @@ __global__ __launch_bounds__(256, (KSF >= 3 ? 2 : 3)) void mbxb_kernel(MbxArgs a
       q.bl[ks] = Wp[(((size_t)ks * NCH + ch) * 2 + 1) * 64 + lane];
     }
     const int ecol = ch * 32 + li;
-    q.mk0 = (ecol < a.Cmid && a.mask0) ? a.mask0[(size_t)b * a.Cmid + ecol] : 1.f;
+    q.mk0 = ((ecol < a.Cmid && a.mask0) ? a.mask0[(size_t)b * a.Cmid + ecol] : 1.f) * UDA_NEG_LN2;
   };
   // the depthwise-side operands of a slab go through LDS, requested (like the B fragments) before the previous
   // slab's output stores are issued: vmcnt retires loads and stores in order
@@ -625,9 +637,9 @@ __global__ __launch_bounds__(256, (KSF >= 3 ? 2 : 3)) void mbxb_kernel(MbxArgs a
     const int row = f >> 5, pcol = chn * 32 + (f & 31);
     if (pcol >= a.Cmid) return 0.f;
     if (row < K * K) return a.wd[(size_t)row * a.Cmid + pcol];
-    if (row == K * K) return a.sc1[pcol];
-    if (row == K * K + 1) return a.sh1[pcol];
-    return a.mask1 ? a.mask1[(size_t)b * a.Cmid + pcol] : 1.f;
+    if (row == K * K) return a.sc1[pcol] * UDA_NEG_LOG2E;
+    if (row == K * K + 1) return a.sh1[pcol] * UDA_NEG_LOG2E;
+    return (a.mask1 ? a.mask1[(size_t)b * a.Cmid + pcol] : 1.f) * UDA_NEG_LN2;
   };
   constexpr int P_PER = (NPAR + 255) / 256;
   SlabB cur, nxt;
@@ -656,7 +668,7 @@ __global__ __launch_bounds__(256, (KSF >= 3 ? 2 : 3)) void mbxb_kernel(MbxArgs a
         }
         float* ep = E + (size_t)(mt * 32 + 4 * lh) * ES + li;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swishf_b(acc[r]) * cur.mk0;
+        for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swish_folded(acc[r], cur.mk0);
       }
     }
     const bool more = ch + 1 < NCH;
@@ -674,29 +686,36 @@ __global__ __launch_bounds__(256, (KSF >= 3 ? 2 : 3)) void mbxb_kernel(MbxArgs a
     for (int t = 0; t < K * K; ++t) wk[t] = pcur[t * 32 + c];
     const float sc1 = pcur[K * K * 32 + c], sh1 = pcur[(K * K + 1) * 32 + c], mk1 = pcur[(K * K + 2) * 32 + c];
     float ssum = 0.f;
-    if (dcol && oy < a.Ho) {
-      float acc[XW];
+    if (dcol) {
 #pragma unroll
-      for (int o = 0; o < XW; ++o) acc[o] = 0.f;
+      for (int ui = 0; ui < NUNIT / NG; ++ui) {
+        const int u = g + NG * ui;
+        const int orow = u / UPR, oxs = (u % UPR) * XW;
+        const int oy = oy0 + orow;
+        if (oy >= a.Ho) continue;
+        float acc[XW];
 #pragma unroll
-      for (int ky = 0; ky < K; ++ky) {
-        float rowv[NCOL];
-        const float* er = E + ((size_t)(orow * S + ky) * IW + oxs * S) * ES + c;
+        for (int o = 0; o < XW; ++o) acc[o] = 0.f;
 #pragma unroll
-        for (int j = 0; j < NCOL; ++j) rowv[j] = er[j * ES];
+        for (int ky = 0; ky < K; ++ky) {
+          float rowv[NCOL];
+          const float* er = E + ((size_t)(orow * S + ky) * IW + oxs * S) * ES + c;
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
+          for (int j = 0; j < NCOL; ++j) rowv[j] = er[j * ES];
 #pragma unroll
-          for (int o = 0; o < XW; ++o) acc[o] = fmaf(rowv[o * S + kx], wk[ky * K + kx], acc[o]);
+          for (int kx = 0; kx < K; ++kx) {
+#pragma unroll
+            for (int o = 0; o < XW; ++o) acc[o] = fmaf(rowv[o * S + kx], wk[ky * K + kx], acc[o]);
+          }
         }
-      }
-      float* op = a.out + (((size_t)b * a.Ho + oy) * a.Wo + ox0 + oxs) * a.Cmid + col;
+        float* op = a.out + (((size_t)b * a.Ho + oy) * a.Wo + ox0 + oxs) * a.Cmid + col;
 #pragma unroll
-      for (int o = 0; o < XW; ++o) {
-        if (ox0 + oxs + o < a.Wo) {
-          const float v = swishf_b(fmaf(acc[o], sc1, sh1)) * mk1;
-          op[(size_t)o * a.Cmid] = v;
-          ssum += v;
+        for (int o = 0; o < XW; ++o) {
+          if (ox0 + oxs + o < a.Wo) {
+            const float v = swish_folded(fmaf(acc[o], sc1, sh1), mk1);
+            op[(size_t)o * a.Cmid] = v;
+            ssum += v;
+          }
         }
       }
     }
@@ -718,6 +737,11 @@ __global__ __launch_bounds__(256, (KSF >= 3 ? 2 : 3)) void mbxb_kernel(MbxArgs a
     }
     cur = nxt;
   }
+}
+
+int mbxb_tiles(int Ho, int Wo, int k, int stride) {
+  const MbxCfgB c = mbxb_cfg(k, stride);
+  return ((Ho + c.th - 1) / c.th) * ((Wo + c.tw - 1) / c.tw);
 }
 
 bool mbxb_supported(int Cin, int Cmid, int k, int stride) {
@@ -793,10 +817,10 @@ __global__ __launch_bounds__(512, 2) void mbxd_kernel(MbxArgs a) {
     const int row = f >> 5, col = chn * 32 + (f & 31);
     if (col >= a.Cmid) return 0.f;
     if (row < K * K) return a.wd[(size_t)row * a.Cmid + col];
-    if (row == K * K) return a.sc1[col];
-    if (row == K * K + 1) return a.sh1[col];
-    if (row == K * K + 2) return a.mask1 ? a.mask1[(size_t)b * a.Cmid + col] : 1.f;
-    return a.mask0 ? a.mask0[(size_t)b * a.Cmid + col] : 1.f;
+    if (row == K * K) return a.sc1[col] * UDA_NEG_LOG2E;
+    if (row == K * K + 1) return a.sh1[col] * UDA_NEG_LOG2E;
+    if (row == K * K + 2) return (a.mask1 ? a.mask1[(size_t)b * a.Cmid + col] : 1.f) * UDA_NEG_LN2;
+    return (a.mask0 ? a.mask0[(size_t)b * a.Cmid + col] : 1.f) * UDA_NEG_LN2;
   };
 
   // ---- slab 0 operands -> LDS buffers 0
@@ -859,7 +883,7 @@ __global__ __launch_bounds__(512, 2) void mbxd_kernel(MbxArgs a) {
       }
       float* ep = E + (size_t)(wave * 32 + 4 * lh) * ES + li;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swishf_b(acc[r]) * mk0;
+      for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swish_folded(acc[r], mk0);
     }
     // next slab's packed weights: in flight during the depthwise phase
     uint4 nb[B_PER];
@@ -910,7 +934,7 @@ __global__ __launch_bounds__(512, 2) void mbxd_kernel(MbxArgs a) {
 #pragma unroll
         for (int o = 0; o < XW; ++o) {
           if (ox0 + oxs + o < a.Wo) {
-            const float v = swishf_b(fmaf(acc[o], sc1, sh1)) * mk1;
+            const float v = swish_folded(fmaf(acc[o], sc1, sh1), mk1);
             op[(size_t)o * a.Cmid] = v;
             ssum += v;
           }
@@ -991,9 +1015,11 @@ void launch_mbxd(const MbxArgs& a, int rows, int k, hipStream_t s) {
 size_t mbxb_packed_elems(int Cin, int Cmid) { return pwb_packed_elems(Cin + 1, Cmid, 2); }
 void mbxb_pack_weights(const float* we, const float* sc0, const float* sh0, int Cin, int Cmid, uint16_t* out) {
   float* w = (float*)malloc((size_t)(Cin + 1) * Cmid * sizeof(float));
+  // the GEMM delivers y = -log2(e) * BN(x W): see swish_folded
+  const float L = -1.4426950408889634f;
   for (int k = 0; k < Cin; ++k)
-    for (int n = 0; n < Cmid; ++n) w[(size_t)k * Cmid + n] = we[(size_t)k * Cmid + n] * sc0[n];
-  for (int n = 0; n < Cmid; ++n) w[(size_t)Cin * Cmid + n] = sh0[n];
+    for (int n = 0; n < Cmid; ++n) w[(size_t)k * Cmid + n] = we[(size_t)k * Cmid + n] * sc0[n] * L;
+  for (int n = 0; n < Cmid; ++n) w[(size_t)Cin * Cmid + n] = sh0[n] * L;
   pwb_pack_weights(w, Cin + 1, Cmid, 2, out);
   free(w);
 }

@@ -701,7 +701,8 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       a.pad_t = same_pad_before(ib.H, ob.H, o.k, o.stride);
       a.pad_l = same_pad_before(ib.W, ob.W, o.k, o.stride);
       a.in_div = v.div(ib, ob);
-      a.n_tiles = deep ? mbxd_tiles(ob.H, ob.W, o.k) : mbx_tiles(ob.H, ob.W, o.k, o.stride);
+      a.n_tiles = deep ? mbxd_tiles(ob.H, ob.W, o.k)
+                       : (c->wsplit_off[oi] >= 0 ? mbxb_tiles(ob.H, ob.W, o.k, o.stride) : mbx_tiles(ob.H, ob.W, o.k, o.stride));
       if (o.se_partial >= 0) {
         const uda_buf_desc_t& pb = c->bufs[o.se_partial];
         if ((int64_t)pb.H * pb.W != (int64_t)a.n_tiles || pb.C != ob.C || pb.per_sample != ob.per_sample)

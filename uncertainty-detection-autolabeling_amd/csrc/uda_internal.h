@@ -100,6 +100,7 @@ void launch_mbxd(const MbxArgs& a, int rows, int k, hipStream_t s);     // deep 
 bool mbxd_supported(int Cin, int Cmid, int k, int stride);
 int mbxd_tiles(int Ho, int Wo, int k);
 bool mbxb_supported(int Cin, int Cmid, int k, int stride);
+int mbxb_tiles(int Ho, int Wo, int k, int stride);
 size_t mbxb_packed_elems(int Cin, int Cmid);
 void mbxb_pack_weights(const float* we, const float* sc0, const float* sh0, int Cin, int Cmid, uint16_t* out);
 void launch_mbx(const MbxArgs& a, int rows, int k, int stride, hipStream_t s);

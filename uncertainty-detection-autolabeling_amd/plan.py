@@ -58,7 +58,10 @@ def mbx_tile(k, stride, cin=16):
     """(TH, TW) output tile of the fused expand+depthwise kernels (mirror of mbx_cfg / mbxd_kernel in csrc)."""
     if mbx_deep(cin):
         return (12, 16) if k == 3 else (8, 16)
-    return (8, 16) if stride == 1 else ((4, 16) if k == 3 else (4, 8))
+    import os
+    if int(os.environ.get("UDA_PW_TERMS", "3")) == 0 or not int(os.environ.get("UDA_MBX_BF16", "1")):
+        return (8, 16) if stride == 1 else ((4, 16) if k == 3 else (4, 8))      # f32-MFMA fallback kernel (mbx_cfg)
+    return ((12, 16) if k == 3 else (8, 16)) if stride == 1 else ((4, 12) if k == 3 else (4, 10))
 
 
 def mbx_tiles(Ho, Wo, k, stride, cin=16):
