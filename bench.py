@@ -29,8 +29,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-KIND_NAMES = {1: "stem_kernel", 2: "pw_kernel", 3: "dw_kernel", 4: "se_kernel", 5: "fuse_kernel",
-              6: "fuse_kernel(pool)", 7: "mbx_kernel", 8: "sep_kernel", 16: "aggregate_kernel", 17: "nms_*", 18: "preprocess_kernel"}
+KIND_NAMES = {1: "stem", 2: "pw", 3: "dw", 4: "se", 5: "fuse", 6: "pool", 7: "mbx", 8: "sep", 16: "aggregate", 17: "nms",
+              18: "preprocess"}
+# kernels behind each op kind (tools/traffic_from_pmc.py groups rocprofv3 kernel names with the same table)
+KIND_KERNELS = {"stem": "stem_kernel", "pw": "pwb_kernel", "dw": "dw_kernel", "se": "se_kernel", "fuse": "fuse_kernel",
+                "pool": "fuse_kernel", "mbx": "mbxb_kernel+mbxd_kernel", "sep": "sep_kernel", "aggregate": "aggregate_kernel",
+                "nms": "nms_*", "preprocess": "preprocess_kernel"}
+LAYERWISE_MB_PER_UNIT = {("efficientdet-d0", "1280x768", 7): 1798.7}   # SURVEY 8d, full MC
 
 
 def parse():
@@ -44,7 +49,7 @@ def parse():
     ap.add_argument("--classes", type=int, default=7)
     ap.add_argument("--variant", default="full", choices=["full", "head"],
                     help="full: mc_dropoutrate=0.05 everywhere; head: class/box head dropout only")
-    ap.add_argument("--chunk", type=int, default=16, help="images per pass of the op list")
+    ap.add_argument("--chunk", type=int, default=32, help="images per pass of the op list")
     ap.add_argument("--model", default="efficientdet-d0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="use the process group (RCCL) path even at world size 1")
@@ -185,7 +190,8 @@ def main():
             per_launch_bytes = cst["bytes"] / cst["launches"]
             avg_ms = dom_ms / dom_launches
             achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": KIND_NAMES.get(dominant, str(dominant)),
+            roof = {"bound": "hbm", "kernel": KIND_KERNELS.get(KIND_NAMES.get(dominant, ""), str(dominant)),
+                    "op_kind": KIND_NAMES.get(dominant, str(dominant)),
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                     "avg_launch_ms": round(avg_ms, 4), "launches": int(dom_launches),
@@ -198,6 +204,12 @@ def main():
                     roof["traffic"] = json.load(open(tf)).get(KIND_NAMES.get(dominant, ""), None)
                 except Exception:
                     pass
+        lw = LAYERWISE_MB_PER_UNIT.get((a.model, a.image_size, a.classes)) if a.variant == "full" else None
+        pipeline = None
+        if lw:      # whole conv stack against the layer-wise byte count SURVEY 8d prices the path with (fusion may beat it)
+            pipeline = {"layerwise_MB_per_unit": lw, "layerwise_GBps": round(lw * value / 1e3, 1),
+                        "frac_of_hbm_peak": round(lw * value / 1e3 / HBM_PEAK_GBS, 4),
+                        "gflop_per_unit": 16.97, "tflops": round(16.97 * value / 1e3, 2)}
         line = {
             "metric": "images*MC-samples/sec, EfficientDet-D0 MC-dropout serve (preprocess+net xT+decode+NMS)",
             "value": round(value, 2), "unit": "images*MC-samples/s", "n_gpus": world, "steps": a.steps,
@@ -213,6 +225,7 @@ def main():
             "kernel_ms_per_step": {KIND_NAMES.get(k, str(k)): round(v[0], 2) for k, v in calib.items()},
             "h2d_upload_ms": round(upload_s * 1e3, 1),
             "roofline": roof,
+            "pipeline": pipeline,
         }
         if world == 1 and not a.no_cpu_baseline:
             log("GPU part done (%.2f units/s); timing the CPU oracle on a bounded sample ..." % value)

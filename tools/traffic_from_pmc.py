@@ -11,13 +11,20 @@ import json
 import sys
 
 
+# op kind of each kernel (bench.py KIND_KERNELS): traffic is reported per kind, like bench.py's roofline
+KIND_OF = {"pwb_kernel": "pw", "pw_kernel": "pw", "mbxb_kernel": "mbx", "mbxd_kernel": "mbx", "mbx_kernel": "mbx",
+           "sep_kernel": "sep", "dw_kernel": "dw", "se_kernel": "se", "fuse_kernel": "fuse", "stem_kernel": "stem",
+           "aggregate_kernel": "aggregate", "preprocess_kernel": "preprocess", "nms_eval_kernel": "nms",
+           "nms_commit_kernel": "nms", "nms_bound_kernel": "nms", "nms_init_kernel": "nms"}
+
+
 def per_kernel(path, counter):
     tot, n = collections.defaultdict(float), collections.Counter()
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
         k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("uda::", "")
-        k = k.split("<")[0]
+        k = KIND_OF.get(k.split("<")[0], k.split("<")[0])
         tot[k] += float(r["Counter_Value"])
         n[k] += 1
     return tot, n
