@@ -168,6 +168,10 @@ int uda_synchronize(uda_ctx_t* ctx);
 int uda_get_detections(uda_ctx_t* ctx, float* boxes, float* scores, float* classes,
                        int32_t* valid, float* logits);
 int uda_detection_cols(const uda_ctx_t* ctx, int32_t post_mode, int32_t* box_cols, int32_t* cls_cols);
+/* What every caller of serve() computes next from `logits` (validate_model.py:159-166,
+ * infer_model.py:585-600, utils_class.py:36-41), on the device: probs [n, M, num_classes] = stable softmax of the
+ * selected rows' mean logits, entropy [n, M] = -sum p * log2(max(p, 1e-7)).  Global post-process only. */
+int uda_get_class_probs(uda_ctx_t* ctx, float* probs, float* entropy);
 
 /* serve = set_images_u8 + run + get_detections */
 int uda_serve(uda_ctx_t* ctx, const uint8_t* images, int32_t n, int32_t h, int32_t w,

@@ -410,3 +410,40 @@ def test_d2_per_class_topk_config5_shape():
     for g, r in zip(det, want):
         np.testing.assert_array_equal(g, r)
     d.close()
+
+
+def test_class_probs_entropy_and_unpacking():
+    """SURVEY 8f.1 on the device: softmax / entropy of the selected rows against the callers' numpy code."""
+    from oracle import unpack_ref as U
+    p = make_params(**FULL_MC)
+    w = make_weights(p, cls_spread=20.0)
+    d = _driver(p, w, 2)
+    d.set_dropout_seed(11)
+    out = d.serve_unpacked(make_images(2, 128, 192))
+    det = d._collect(2)
+    for n in range(2):
+        want_p, want_h = U.probab_entropy(det[4][n])
+        np.testing.assert_allclose(out["probab"][n], want_p, rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(out["entropy"][n], want_h, rtol=1e-5, atol=2e-6)
+    b4, cid, al, mc, mcc = U.unpack(p, det[0], det[2])
+    for k, v in (("boxes", b4), ("classes", cid), ("albox", al), ("mcbox", mc), ("mcclass", mcc)):
+        np.testing.assert_array_equal(out[k], v, err_msg=k)
+    d.close()
+
+
+@pytest.mark.parametrize("env", [dict(UDA_PW_TERMS="0"), dict(UDA_PW_TERMS="6"),
+                                 dict(UDA_FUSE_MBXD="0", UDA_FUSE_SEP="0", UDA_DEFER_DROPOUT="0"),
+                                 dict(UDA_FUSE_MBX="0", UDA_POST_OVERLAP="0")],
+                         ids=["f32-mfma", "six-terms", "no-deep-fusion", "unfused-serial-post"])
+def test_fallback_paths_stay_parity_green(env):
+    """Every switchable path (exact-f32 MFMA kernels, 6-term split, each fusion off) passes the smoke parity check.
+    The switches are read once per process, so each configuration runs in its own interpreter."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=root, env=e,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "smoke ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

@@ -247,3 +247,23 @@ def test_postprocess_output_layout():
     b2, s2, c2, v2 = P.postprocess_per_class(p, cls, box, np.array([1.5, 2.0], np.float32))
     assert b2.shape == (2, 100, 4) and c2.shape == (2, 100) and np.all(v2 <= 100)
     assert np.all(np.diff(s2[0]) <= 0)
+
+
+def test_softmax_entropy_unpack_kats():
+    """stable softmax / entropy in bits / column unpacking (validate_model.py:159-202)."""
+    from oracle import unpack_ref as U
+    p, h = U.probab_entropy(np.array([[0.0, 0.0], [100.0, 0.0], [1.0, 2.0, 3.0][:2]], np.float32))
+    np.testing.assert_allclose(p[0], [0.5, 0.5])
+    np.testing.assert_allclose(h[0], 1.0, rtol=1e-6)               # one bit
+    assert p[1][0] == 1.0 and abs(h[1]) < 1e-30 and np.isfinite(h[1])   # clamp at 1e-7 keeps 0 * log2 finite
+    np.testing.assert_allclose(p[2], np.exp([1.0, 2.0]) / np.exp([1.0, 2.0]).sum(), rtol=1e-6)
+    params = dict(mc_boxheadrate=0.0, mc_dropoutrate=0.05, mc_classheadrate=0.0, loss_attenuation=True)
+    boxes = np.arange(2 * 3 * 12, dtype=np.float32).reshape(2, 3, 12)
+    boxes[0, 0, 5] = np.nan
+    classes = np.arange(2 * 3 * 8, dtype=np.float32).reshape(2, 3, 8)
+    b4, cid, al, mc, mcc = U.unpack(params, boxes, classes)
+    assert b4.shape == (2, 3, 4) and al.shape == (2, 3, 4) and mc.shape == (2, 3, 4) and mcc.shape == (2, 3, 7)
+    assert al[0, 0, 1] == 0.0 and cid.shape == (2, 3)
+    params["loss_attenuation"] = False
+    b4, cid, al, mc, mcc = U.unpack(params, boxes[:, :, :8], classes)
+    assert al is None and mc.shape == (2, 3, 4)

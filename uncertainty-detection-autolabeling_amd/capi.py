@@ -79,6 +79,7 @@ _SIGNATURES = {
     "uda_synchronize": (C.c_int, [_P]),
     "uda_get_detections": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "uda_detection_cols": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "uda_get_class_probs": (C.c_int, [_P, _P, _P]),
     "uda_serve": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "uda_get_head_outputs": (C.c_int, [_P, C.c_int32, _P, _P]),
     "uda_set_head_outputs": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),

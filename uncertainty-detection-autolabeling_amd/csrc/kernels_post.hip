@@ -842,4 +842,29 @@ void launch_gather(const GatherArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(gather_kernel, dim3((total + 127) / 128), dim3(128), 0, s, a);
 }
 
+// ------------------------------------------------------------------------------------ class probabilities
+// What every caller does right after serve() (validate_model.py:159-166, infer_model.py:585-600,
+// utils_class.py:36-41): p = stable_softmax(logits) and the entropy -sum p * log2(max(p, 1e-7)), float32.
+__global__ __launch_bounds__(128) void probs_kernel(const float* logits, float* probs, float* entropy, int rows, int C) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float* x = logits + (size_t)r * C;
+  float mx = x[0];
+  for (int c = 1; c < C; ++c) mx = fmaxf(mx, x[c]);
+  float sum = 0.f;
+  for (int c = 0; c < C; ++c) sum += expf(x[c] - mx);
+  float h = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float pc = expf(x[c] - mx) / sum;
+    probs[(size_t)r * C + c] = pc;
+    h += pc * log2f(fmaxf(pc, 1e-7f));
+  }
+  entropy[r] = -h;
+}
+
+void launch_probs(const float* logits, float* probs, float* entropy, int rows, int C, hipStream_t s) {
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(probs_kernel, dim3((rows + 127) / 128), dim3(128), 0, s, logits, probs, entropy, rows, C);
+}
+
 }  // namespace uda

@@ -101,6 +101,7 @@ struct uda_ctx {
   unsigned long long* d_merge_keys = nullptr;
   // outputs
   float *d_oboxes = nullptr, *d_oscores = nullptr, *d_oclasses = nullptr, *d_ologits = nullptr;
+  float *d_oprobs = nullptr, *d_oentropy = nullptr;   // stable softmax / entropy of the selected rows (lazy)
   int32_t* d_ovalid = nullptr;
   int last_post_mode = 0;
   int last_n = 0;
@@ -189,7 +190,7 @@ extern "C" void uda_destroy(uda_ctx_t* c) {
   void* ptrs[] = {c->d_weights, c->d_wsplit, c->d_arena, c->d_anchors, c->d_u8, c->d_images, c->d_scales, c->d_masks,
                   c->d_site_off, c->d_site_ch, c->d_site_rate, c->d_cboxes, c->d_cscores, c->d_clogits,
                   c->d_cclasses, c->d_ucls, c->d_ual, c->d_uep, c->d_clsmean, c->d_cand_flat, c->d_merge_keys,
-                  c->d_oboxes, c->d_oscores, c->d_oclasses, c->d_ologits, c->d_ovalid};
+                  c->d_oboxes, c->d_oscores, c->d_oclasses, c->d_ologits, c->d_ovalid, c->d_oprobs, c->d_oentropy};
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (auto& w : c->ws) {
@@ -1056,6 +1057,24 @@ extern "C" int uda_get_detections(uda_ctx_t* c, float* boxes, float* scores, flo
   if (valid) HIPC(c, hipMemcpy(valid, c->d_ovalid, n * sizeof(int32_t), hipMemcpyDeviceToHost));
   if (logits && c->last_post_mode == UDA_POST_GLOBAL)
     HIPC(c, hipMemcpy(logits, c->d_ologits, n * M * C * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int uda_get_class_probs(uda_ctx_t* c, float* probs, float* entropy) {
+  if (!c || !probs || !entropy) return c ? fail(c, "get_class_probs: NULL argument") : 1;
+  if (c->last_post_mode != UDA_POST_GLOBAL) return fail(c, "get_class_probs: logits exist only after the global post-process");
+  HIPC(c, hipSetDevice(c->device));
+  const size_t n = c->last_n, M = c->model.max_output_size, C = c->model.num_classes;
+  if (!c->d_oprobs) {
+    const size_t N = (size_t)c->model.max_images;
+    HIPC(c, dalloc(&c->d_oprobs, N * M * C));
+    HIPC(c, dalloc(&c->d_oentropy, N * M));
+  }
+  launch_probs(c->d_ologits, c->d_oprobs, c->d_oentropy, (int)(n * M), (int)C, c->stream);
+  HIPC(c, hipStreamSynchronize(c->stream));
+  HIPC(c, hipGetLastError());
+  HIPC(c, hipMemcpy(probs, c->d_oprobs, n * M * C * sizeof(float), hipMemcpyDeviceToHost));
+  HIPC(c, hipMemcpy(entropy, c->d_oentropy, n * M * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
 }
 

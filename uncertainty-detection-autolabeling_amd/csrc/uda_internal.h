@@ -251,5 +251,6 @@ struct MergeArgs {         // per-class mode: concat per-class selections, pad, 
   int n_img, K, M, C;
 };
 void launch_merge_per_class(const MergeArgs& a, hipStream_t s);
+void launch_probs(const float* logits, float* probs, float* entropy, int rows, int C, hipStream_t s);
 
 }  // namespace uda

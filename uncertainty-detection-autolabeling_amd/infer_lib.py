@@ -200,6 +200,27 @@ class ServingDriver:
         self._ck(self._lib.uda_run(self._h, mode, 1), "uda_run")
         return self._collect(n, mode)
 
+    def class_probs(self, n):
+        """(probab [n, M, C], entropy [n, M]) of the last global post-process, computed on the device:
+        `stable_softmax(logits)` and `-sum p * log2(max(p, 1e-7))` exactly as every caller of `serve` does next
+        (validate_model.py:159-166, infer_model.py:585-600, utils_class.py:36-41)."""
+        probs = np.empty((n, self.M, self.num_classes), np.float32)
+        ent = np.empty((n, self.M), np.float32)
+        self._ck(self._lib.uda_get_class_probs(self._h, _ptr(probs), _ptr(ent)), "uda_get_class_probs")
+        return probs, ent
+
+    def serve_unpacked(self, image_arrays):
+        """serve + the unpacking `Validate._process_val_image` / `Infer` do on the host (validate_model.py:159-202):
+        dict(boxes [N,M,4], scores, classes [N,M], valid_len, logits, probab, entropy, albox, mcbox, mcclass);
+        entries a configuration does not produce are None."""
+        from . import postprocess as pp
+        det = self.serve(image_arrays)
+        n = det[0].shape[0]
+        probs = ent = None
+        if self.params["enable_softmax"]:
+            probs, ent = self.class_probs(n)
+        return pp.unpack_detections(self.params, det, probs, ent)
+
     def predict(self, image_arrays):
         """only_network: float32 [N,H,W,3] -> (cls_outputs[levels], box_outputs[levels]) with the
         reference's shapes ([N,h,w,ch], or [T,N,h,w,ch] for a head that is MC-stacked);

@@ -49,3 +49,27 @@ def transform_detections(detections):
     d = np.asarray(detections)
     return np.stack([d[:, :, 0], d[:, :, 1], d[:, :, 2], d[:, :, 3] - d[:, :, 1], d[:, :, 4] - d[:, :, 2],
                      d[:, :, 5], d[:, :, 6]], axis=-1)
+
+
+def unpack_detections(params, detections, probab=None, entropy=None):
+    """Split the serve() tuple the way the reference's callers do (validate_model.py:159-202, infer_model.py:585-636):
+    box columns 4: are the aleatoric and / or MC (epistemic) box std, class columns 1: the MC std of the logits;
+    NaNs in the uncertainty columns become 0 (`np.nan_to_num`)."""
+    boxes, scores, classes, valid = detections[:4]
+    logits = detections[4] if len(detections) > 4 else None
+    mc_box = bool(params.get("mc_boxheadrate") or params.get("mc_dropoutrate")) and bool(params.get("mc_dropout"))
+    mc_cls = bool(params.get("mc_classheadrate") or params.get("mc_dropoutrate")) and bool(params.get("mc_dropout"))
+    la = bool(params.get("loss_attenuation"))
+    albox = mcbox = mcclass = None
+    if mc_box and not la:
+        mcbox = np.nan_to_num(boxes[:, :, 4:])
+    elif mc_box and la:
+        albox = np.nan_to_num(boxes[:, :, 4:8])
+        mcbox = np.nan_to_num(boxes[:, :, 8:])
+    elif la:
+        albox = np.nan_to_num(boxes[:, :, 4:])
+    if mc_cls and classes.ndim == 3:
+        mcclass = np.nan_to_num(classes[:, :, 1:])
+        classes = classes[:, :, 0]
+    return dict(boxes=boxes[:, :, :4], scores=scores, classes=classes, valid_len=valid, logits=logits,
+                probab=probab, entropy=entropy, albox=albox, mcbox=mcbox, mcclass=mcclass)
