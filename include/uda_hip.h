@@ -177,6 +177,17 @@ int uda_get_class_probs(uda_ctx_t* ctx, float* probs, float* entropy);
 int uda_serve(uda_ctx_t* ctx, const uint8_t* images, int32_t n, int32_t h, int32_t w,
               float* boxes, float* scores, float* classes, int32_t* valid, float* logits);
 
+/* Calibrated box uncertainty of the last global post-process (CalibrateBoxUncert.calibrate_boxuncert,
+ * utils_box.py:404-524), on the device.  col0 = first of the four uncertainty columns inside the boxes output (4:
+ * aleatoric or the only one, 8: epistemic when both exist).  Isotonic tables are the fitted thresholds of the
+ * reference's sklearn IsotonicRegression models: table t = xs/ys[tab_off[t] .. tab_off[t+1]); 1 table (ISO_ALL), 4
+ * (ISO_PERCOO: ymin, xmin, ymax, xmax) or 4 * num_classes (ISO_PERCLSCOO, class-major, class ids 1..C);
+ * relative != 0 = the rel_iso_perclscoo variant.  temps: 1 or 4 divisors for the TS modes.  out [n, M, 4]. */
+enum uda_calib_mode { UDA_CALIB_TS_ALL = 0, UDA_CALIB_TS_PERCOO = 1, UDA_CALIB_ISO_ALL = 2, UDA_CALIB_ISO_PERCOO = 3,
+                      UDA_CALIB_ISO_PERCLSCOO = 4 };
+int uda_calibrate_box(uda_ctx_t* ctx, int32_t col0, int32_t mode, int32_t relative, int32_t n_tables,
+                      const int32_t* tab_off, const double* xs, const double* ys, const float* temps, float* out);
+
 /* Raw head outputs of the last run, level `level`: class [T_c, n, h, w, A*C] and
  * box [T_b, n, h, w, 4A or 8A] in the reference's stacking order (T axis first; T_x = 1
  * and the axis is dropped by the caller when that head is not stacked). */

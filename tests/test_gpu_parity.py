@@ -447,3 +447,37 @@ def test_fallback_paths_stay_parity_green(env):
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=root, env=e,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "smoke ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_box_uncertainty_calibration_matches_reference_restatement():
+    """SURVEY 8f.2 on the device: every calibrate_boxuncert method on the selected rows against the numpy restatement."""
+    from oracle import calib_ref as CR
+    from uda_amd.calibration import BoxCalibrator, IsoTable
+    p = make_params(**FULL_MC)
+    w = make_weights(p, cls_spread=20.0)
+    d = _driver(p, w, 2)
+    d.set_dropout_seed(5)
+    det = d.serve(make_images(2, 128, 192))
+    rng = np.random.default_rng(9)
+
+    def table():
+        xs = np.sort(rng.uniform(0, 40, 12))
+        xs += np.arange(12) * 1e-3
+        return xs, np.sort(rng.uniform(0, 60, 12))
+    C = p["num_classes"]
+    models = dict(ts_all=1.7, ts_percoo=[1.1, 2.3, 0.7, 3.1], iso_all=table(), iso_percoo=[table() for _ in range(4)],
+                  iso_perclscoo=[table() for _ in range(4 * C)],
+                  rel_iso_perclscoo=[(np.sort(rng.uniform(0, 2, 9)) + np.arange(9) * 1e-3, np.sort(rng.uniform(0, 3, 9)))
+                                     for _ in range(4 * C)])
+    dev_models = {k: (v if k.startswith("ts") else ([IsoTable(*t) for t in v] if isinstance(v, list) else IsoTable(*v)))
+                  for k, v in models.items()}
+    cal = BoxCalibrator(d, dev_models)
+    for which, cols in (("albox", slice(4, 8)), ("mcbox", slice(8, 12))):
+        for method in models:
+            got = cal.calibrate_boxuncert(2, which, method)
+            for n in range(2):
+                want = CR.calibrate_boxuncert(method, models, C, det[0][n][:, cols], det[2][n][:, 0], det[0][n][:, :4])
+                np.testing.assert_allclose(got[n], want, rtol=2e-6, atol=1e-6, err_msg="%s %s" % (which, method))
+    with pytest.raises(ValueError):
+        cal.calibrate_boxuncert(2, "albox", "nonsense")
+    d.close()

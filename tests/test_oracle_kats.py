@@ -267,3 +267,18 @@ def test_softmax_entropy_unpack_kats():
     params["loss_attenuation"] = False
     b4, cid, al, mc, mcc = U.unpack(params, boxes[:, :, :8], classes)
     assert al is None and mc.shape == (2, 3, 4)
+
+
+def test_isotonic_table_matches_sklearn():
+    """the thresholds-table restatement of IsotonicRegression(out_of_bounds='clip').predict against the
+    real sklearn class (what the reference pickles in calibrate_regression.py:370-434)."""
+    sk = pytest.importorskip("sklearn.isotonic")
+    from oracle import calib_ref as CR
+    rng = np.random.default_rng(3)
+    x = rng.uniform(0, 5, 400)
+    y = np.sqrt(x) + rng.normal(0, 0.2, 400)
+    iso = sk.IsotonicRegression(increasing=True, out_of_bounds="clip").fit(x, y)
+    q = np.concatenate([rng.uniform(-1, 7, 500), x[:20], [iso.X_thresholds_[0], iso.X_thresholds_[-1]]]).astype(np.float32)
+    got = CR.iso_predict((iso.X_thresholds_, iso.y_thresholds_), q)
+    np.testing.assert_allclose(got, iso.predict(q), rtol=1e-6, atol=1e-7)
+    assert got.dtype == np.float32

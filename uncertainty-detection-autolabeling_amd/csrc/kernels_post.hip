@@ -17,6 +17,8 @@
 // Pinned-down numerics shared with the oracle (oracle/post_ref.py header):
 //   exp32(x) = float(exp(double(x))), sigmoid(x) = float(1/(1+exp(-double(x)))),
 //   MC reductions are sequential float32 sums over t = 0..T-1.
+#include <hip/hip_fp16.h>
+
 #include "uda_internal.h"
 
 namespace uda {
@@ -865,6 +867,70 @@ __global__ __launch_bounds__(128) void probs_kernel(const float* logits, float* 
 void launch_probs(const float* logits, float* probs, float* entropy, int rows, int C, hipStream_t s) {
   if (rows <= 0) return;
   hipLaunchKernelGGL(probs_kernel, dim3((rows + 127) / 128), dim3(128), 0, s, logits, probs, entropy, rows, C);
+}
+
+// ------------------------------------------------------------------------------------ box-uncertainty calibration
+// CalibrateBoxUncert.calibrate_boxuncert (utils_box.py:404-524) on the selected rows: temperature scaling
+// (uncert / T) or isotonic regression tables (sklearn IsotonicRegression(out_of_bounds="clip").predict = linear
+// interpolation between the fitted thresholds in float64, clipped to their range), one table for all values,
+// one per box coordinate, or one per (class, coordinate); the relative variant divides by the box height /
+// width in float16 first (the reference passes dtype=np.float16) and multiplies back afterwards.
+__device__ __forceinline__ float iso_predict(const double* xs, const double* ys, int m, float v) {
+  if (m <= 0) return 0.f;
+  double x = (double)v;
+  if (x <= xs[0]) return (float)ys[0];
+  if (x >= xs[m - 1]) return (float)ys[m - 1];
+  int lo = 0, hi = m - 1;                  // xs[lo] <= x < xs[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (xs[mid] <= x) lo = mid; else hi = mid;
+  }
+  const double slope = (ys[hi] - ys[lo]) / (xs[hi] - xs[lo]);
+  return (float)(ys[lo] + slope * (x - xs[lo]));
+}
+
+__global__ __launch_bounds__(128) void calib_kernel(CalibArgs a) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= a.rows) return;
+  const float* row = a.boxes + (size_t)r * a.box_cols;
+  const int cls = (int)a.classes[(size_t)r * a.cls_cols];
+  const float hgt = row[2] - row[0], wid = row[3] - row[1];
+  for (int j = 0; j < 4; ++j) {
+    float u = row[a.col0 + j];
+    if (isnan(u)) u = 0.f;                 // np.nan_to_num
+    else if (isinf(u)) u = u > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+    float o;
+    if (a.mode == UDA_CALIB_TS_ALL) {
+      o = u / a.temps[0];
+    } else if (a.mode == UDA_CALIB_TS_PERCOO) {
+      o = u / a.temps[j];
+    } else {
+      int t = 0;
+      if (a.mode == UDA_CALIB_ISO_PERCOO) t = j;
+      else if (a.mode == UDA_CALIB_ISO_PERCLSCOO) t = (cls - 1) * 4 + j;
+      if (a.mode == UDA_CALIB_ISO_PERCLSCOO && (cls < 1 || cls > a.n_tables / 4)) {
+        o = 0.f;                           // rows of no calibrated class stay zero (np.zeros_like)
+      } else {
+        const double* xs = a.xs + a.tab_off[t];
+        const double* ys = a.ys + a.tab_off[t];
+        const int m = a.tab_off[t + 1] - a.tab_off[t];
+        if (a.relative) {
+          const float norm = (j & 1) ? wid : hgt;
+          float rel = 0.f;
+          if (norm != 0.f) rel = __half2float(__float2half(__half2float(__float2half(u)) / __half2float(__float2half(norm))));
+          o = iso_predict(xs, ys, m, rel) * norm;
+        } else {
+          o = iso_predict(xs, ys, m, u);
+        }
+      }
+    }
+    a.out[(size_t)r * 4 + j] = o;
+  }
+}
+
+void launch_calib(const CalibArgs& a, hipStream_t s) {
+  if (a.rows <= 0) return;
+  hipLaunchKernelGGL(calib_kernel, dim3((a.rows + 127) / 128), dim3(128), 0, s, a);
 }
 
 }  // namespace uda

@@ -1078,6 +1078,52 @@ extern "C" int uda_get_class_probs(uda_ctx_t* c, float* probs, float* entropy) {
   return 0;
 }
 
+extern "C" int uda_calibrate_box(uda_ctx_t* c, int32_t col0, int32_t mode, int32_t relative, int32_t n_tables,
+                                 const int32_t* tab_off, const double* xs, const double* ys, const float* temps, float* out) {
+  if (!c || !out) return c ? fail(c, "calibrate_box: NULL out") : 1;
+  if (c->last_post_mode != UDA_POST_GLOBAL) return fail(c, "calibrate_box: needs the global post-process (uncertainty columns)");
+  const int bc = box_cols_of(c->model, UDA_POST_GLOBAL), cc = cls_cols_of(c->model, UDA_POST_GLOBAL);
+  if (col0 < 4 || col0 + 4 > bc || (col0 & 3)) return fail(c, "calibrate_box: columns %d..%d outside the %d box columns", col0, col0 + 3, bc);
+  const bool iso = mode >= UDA_CALIB_ISO_ALL;
+  if (mode < 0 || mode > UDA_CALIB_ISO_PERCLSCOO) return fail(c, "calibrate_box: unknown mode %d", mode);
+  if (!iso && !temps) return fail(c, "calibrate_box: temperature scaling needs temps");
+  if (relative && mode != UDA_CALIB_ISO_PERCLSCOO) return fail(c, "calibrate_box: the relative variant exists per class and coordinate only");
+  const int want = mode == UDA_CALIB_ISO_ALL ? 1 : (mode == UDA_CALIB_ISO_PERCOO ? 4 : 4 * c->model.num_classes);
+  if (iso && (n_tables != want || !tab_off || !xs || !ys))
+    return fail(c, "calibrate_box: mode %d needs %d tables, got %d", mode, want, n_tables);
+  HIPC(c, hipSetDevice(c->device));
+  CalibArgs a{};
+  double *d_xs = nullptr, *d_ys = nullptr;
+  int32_t* d_off = nullptr;
+  float* d_out = nullptr;
+  const size_t rows = (size_t)c->last_n * c->model.max_output_size;
+  if (iso) {
+    const size_t tot = (size_t)tab_off[n_tables];
+    for (int t = 0; t < n_tables; ++t)
+      if (tab_off[t + 1] < tab_off[t]) return fail(c, "calibrate_box: table offsets must be non-decreasing");
+    HIPC(c, dalloc(&d_xs, tot)); HIPC(c, dalloc(&d_ys, tot)); HIPC(c, dalloc(&d_off, (size_t)n_tables + 1));
+    HIPC(c, hipMemcpyAsync(d_xs, xs, tot * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(d_ys, ys, tot * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(d_off, tab_off, ((size_t)n_tables + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  }
+  HIPC(c, dalloc(&d_out, rows * 4));
+  a.boxes = c->d_oboxes; a.classes = c->d_oclasses; a.out = d_out;
+  a.xs = d_xs; a.ys = d_ys; a.tab_off = d_off;
+  for (int j = 0; j < 4; ++j) a.temps[j] = temps ? temps[mode == UDA_CALIB_TS_ALL ? 0 : j] : 1.f;
+  a.rows = (int)rows; a.box_cols = bc; a.cls_cols = cc; a.col0 = col0;
+  a.mode = mode; a.relative = relative; a.n_tables = n_tables;
+  launch_calib(a, c->stream);
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpy(out, d_out, rows * 4 * sizeof(float), hipMemcpyDeviceToHost);
+  if (d_xs) hipFree(d_xs);
+  if (d_ys) hipFree(d_ys);
+  if (d_off) hipFree(d_off);
+  hipFree(d_out);
+  if (e != hipSuccess) return fail(c, "calibrate_box: %s", hipGetErrorString(e));
+  return 0;
+}
+
 extern "C" int uda_serve(uda_ctx_t* c, const uint8_t* images, int32_t n, int32_t h, int32_t w,
                          float* boxes, float* scores, float* classes, int32_t* valid, float* logits) {
   int rc = uda_set_images_u8(c, images, n, h, w);

@@ -251,6 +251,18 @@ struct MergeArgs {         // per-class mode: concat per-class selections, pad, 
   int n_img, K, M, C;
 };
 void launch_merge_per_class(const MergeArgs& a, hipStream_t s);
+struct CalibArgs {
+  const float* boxes;     // [rows, box_cols] output boxes (+ uncertainty columns)
+  const float* classes;   // [rows, cls_cols] class id in column 0
+  float* out;             // [rows, 4]
+  const double* xs;       // concatenated table thresholds
+  const double* ys;
+  const int32_t* tab_off; // [n_tables + 1]
+  float temps[4];
+  int rows, box_cols, cls_cols, col0;
+  int mode, relative, n_tables;
+};
+void launch_calib(const CalibArgs& a, hipStream_t s);
 void launch_probs(const float* logits, float* probs, float* entropy, int rows, int C, hipStream_t s);
 
 }  // namespace uda
