@@ -210,3 +210,29 @@ def test_cost_accounting_close_to_survey_figures():
     sep = costs.get(capi.OP_SEP, dict(launches=0))["launches"] // 16
     assert costs[capi.OP_PW]["launches"] == (101 - fused - sep) * 16
     assert costs[capi.OP_DW]["launches"] == (80 - fused - sep) * 16
+
+
+def test_prediction_data_records_round_trip(tmp_path):
+    """the prediction_data.txt line format parses back the way the reference's readers parse it."""
+    import ast
+    from uda_amd import writers
+    rng = np.random.default_rng(0)
+    M, C = 6, 3
+    un = dict(boxes=rng.uniform(0, 100, (2, M, 4)).astype(np.float32), scores=np.linspace(0.9, 0.1, 2 * M).reshape(2, M).astype(np.float32),
+              classes=rng.integers(1, C + 1, (2, M)).astype(np.float32), valid_len=np.array([M, M], np.int32),
+              logits=rng.normal(0, 1, (2, M, C)).astype(np.float32), probab=rng.uniform(0, 1, (2, M, C)).astype(np.float32),
+              entropy=rng.uniform(0, 1, (2, M)).astype(np.float32), albox=rng.uniform(0, 5, (2, M, 4)).astype(np.float32),
+              mcbox=None, mcclass=rng.uniform(0, 1, (2, M, C)).astype(np.float32))
+    un["albox"][0, 0, 1] = np.nan
+    cal = {"iso_all_albox": un["albox"] * 2}
+    recs = writers.prediction_records(un, ["000001", "000002"], 0.45, calibrated=cal)
+    assert len(recs) == int((un["scores"] > 0.45).sum())
+    path = tmp_path / "prediction_data.txt"
+    writers.write_prediction_data(str(path), recs)
+    back = [ast.literal_eval(l.replace("inf", "2e308")) for l in open(path)]
+    assert back == recs
+    r0 = back[0]
+    assert list(r0)[:6] == ["image_name", "score_thresh", "top_5scores", "det_score", "bbox", "class"]
+    assert r0["image_name"] == "000001.jpg" and r0["uncalib_albox"][1] == 0.0 and "uncalib_mcbox" not in r0
+    assert r0["logits"] == [float(v) for v in np.around(un["logits"][0, 0], 4)] and len(r0["iso_all_albox"]) == 4
+    assert isinstance(r0["entropy"], float) and len(r0["probab"]) == C and len(r0["uncalib_mcclass"]) == C
