@@ -94,3 +94,55 @@ def test_all_gather_detections_world2_even_shards():
 def test_all_gather_detections_world2_ragged_and_empty_shards():
     _run_world(5)      # shards of 3 and 2 images
     _run_world(1)      # rank 1 owns no image
+
+
+RESHARD_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch.distributed as dist
+from uda_amd import dist as udist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+n_total, n_members = int(sys.argv[1]), int(sys.argv[2])
+shapes_c = [(4, 5, 6), (2, 3, 6)]
+shapes_b = [(4, 5, 8), (2, 3, 8)]
+def heads(m):
+    r = np.random.default_rng(100 + m)
+    return ([r.normal(size=(n_total,) + s).astype(np.float32) for s in shapes_c],
+            [r.normal(size=(n_total,) + s).astype(np.float32) for s in shapes_b])
+owned = {m: heads(m) for m in range(n_members) if udist.member_owner(m, world) == rank}
+cls, box = udist.reshard_member_heads(owned, n_members, n_total, rank, world)
+a, b = udist.shard_range(n_total, rank, world)
+ok = True
+for m in range(n_members):
+    c, bx = heads(m)
+    for l in range(2):
+        ok &= np.array_equal(cls[l][m], c[l][a:b]) and np.array_equal(box[l][m], bx[l][a:b])
+ok &= cls[0].shape == (n_members, b - a, 4, 5, 6)
+dist.barrier()
+dist.destroy_process_group()
+print("RANK", rank, "OK" if ok else "MISMATCH")
+sys.exit(0 if ok else 1)
+'''
+
+
+def _run_reshard(n_total, n_members, world=2):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, "-c", RESHARD_WORKER % {"root": ROOT}, str(n_total), str(n_members)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert "OK" in o
+
+
+def test_ensemble_reshard_world2():
+    """Members striped over the ranks, heads re-sharded by image (all-to-all-v of point-to-point transfers)."""
+    _run_reshard(5, 3)      # rank 0 owns members 0 and 2, rank 1 member 1; shards of 3 and 2 images
+    _run_reshard(4, 1)      # rank 1 owns no member
+    _run_reshard(1, 2)      # rank 1 owns no image

@@ -370,6 +370,61 @@ def test_deep_ensemble_matches_oracle_aggregation():
     ens.close()
 
 
+STRIPE_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import torch.distributed as dist
+from common import LOSS_ATT, make_images, make_params, make_weights
+from uda_amd import dist as udist
+from uda_amd.infer_lib import ServingDriver
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+p = make_params(**LOSS_ATT)
+M = 3
+imgs = make_images(3, 100, 180, seed=44)
+mine = {m: ServingDriver("_", False, p["name"], batch_size=3, model_params=p, weights=make_weights(p, seed=40 + m, cls_spread=20.0))
+        for m in range(M) if udist.member_owner(m, world) == rank}
+pm = dict(p, mc_dropout=True, mc_dropoutrate=1e-9, mc_dropoutsamp=M)
+post = ServingDriver("_", False, p["name"], batch_size=3, model_params=pm, weights=make_weights(p, seed=40, cls_spread=20.0), chunk_images=1)
+got = udist.serve_ensemble_striped(mine, post, imgs, M, rank, world)
+np.savez(sys.argv[1] + ".rank%%d.npz" %% rank, *got)
+dist.barrier(); dist.destroy_process_group()
+for d in list(mine.values()) + [post]:
+    d.close()
+'''
+
+
+def test_ensemble_striped_over_ranks_equals_single_process(tmp_path):
+    """BASELINE configs[3] across ranks: members striped over two ranks (gloo, both on GPU 0), heads re-sharded by
+    image, aggregate + NMS per shard, all-gather: bit-identical to the single-process EnsembleDriver."""
+    import os, socket, subprocess, sys
+    from common import ROOT
+    from uda_amd.infer_lib import EnsembleDriver
+    p = make_params(**LOSS_ATT)
+    ws = [make_weights(p, seed=40 + m, cls_spread=20.0) for m in range(3)]
+    imgs = make_images(3, 100, 180, seed=44)
+    ens = EnsembleDriver(ws, p["name"], batch_size=3, model_params=p)
+    want = ens.serve(imgs)
+    ens.close()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "ens")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, "-c", STRIPE_WORKER % {"root": ROOT}, out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for pr in procs:
+        o = pr.communicate(timeout=300)[0]
+        assert pr.returncode == 0, o
+    for rank in range(2):
+        z = np.load(out + ".rank%d.npz" % rank)
+        got = [z["arr_%d" % i] for i in range(len(want))]
+        for g, r in zip(got, want):
+            np.testing.assert_array_equal(g, r)
+
+
 def test_bdd_like_padding_and_ten_classes():
     """BASELINE configs[2]-shaped input: 10 classes, raw height below the network height (scale 1, zero rows padded)."""
     from oracle import post_ref as P, preprocess_ref as PP

@@ -79,3 +79,104 @@ def serve_sharded(driver, images, rank, world, device=None, group=None):
     else:  # more ranks than images: this rank contributes an empty shard
         det = driver.empty_detections()
     return all_gather_detections(det, device=device, group=group)
+
+
+# ---------------------------------------------------------------------------------------------- ensemble striping
+def member_owner(member, world):
+    """Rank that runs ensemble member `member` (members striped round-robin over the ranks)."""
+    return member % world
+
+
+def reshard_member_heads(owned, n_members, n_total, rank, world, device=None, group=None):
+    """Deep-ensemble exchange (BASELINE configs[3], SURVEY §8e): every member ran on ONE rank for ALL images;
+    afterwards every rank needs ALL members for ITS contiguous image shard.  One all-to-all-v built from batched
+    point-to-point transfers (each GPU pair uses its own xGMI link; no ring): rank r sends to rank j the head
+    outputs of the members it owns restricted to shard j.
+
+    owned: {member: (cls_levels, box_levels)} with per-level float32 arrays [n_total, ...] (any trailing shape).
+    Returns (cls_levels, box_levels) with arrays [n_members, n_local, ...] for this rank's shard."""
+    import torch
+    import torch.distributed as dist
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    a, b = shard_range(n_total, rank, world)
+    mine = sorted(owned)
+    assert mine == [m for m in range(n_members) if member_owner(m, world) == rank], "member ownership must be round-robin"
+    template = None
+    if mine:
+        c0, b0 = owned[mine[0]]
+        template = [tuple(x.shape[1:]) for x in c0] + [tuple(x.shape[1:]) for x in b0]
+        n_cls = len(c0)
+    # every rank needs the per-image payload layout; ranks that own no member learn it from rank 0 (which owns member 0)
+    meta = [template, n_cls if mine else None]
+    dist.broadcast_object_list(meta, src=0, group=group)
+    template, n_cls = meta
+    per_image = int(sum(int(np.prod(s)) for s in template))
+
+    def flat(m, s, e):
+        c, bx = owned[m]
+        return np.concatenate([x[s:e].reshape(e - s, -1) for x in list(c) + list(bx)], axis=1)
+
+    ops, recv = [], {}
+    send_keep = []
+    for j in range(world):                                   # what I send to rank j
+        s, e = shard_range(n_total, j, world)
+        if e == s or not mine:
+            continue
+        payload = np.ascontiguousarray(np.stack([flat(m, s, e) for m in mine]), np.float32)   # [owned, n_j, per_image]
+        if j == rank:
+            recv[rank] = torch.from_numpy(payload)
+            continue
+        t = torch.from_numpy(payload).to(dev)
+        send_keep.append(t)
+        ops.append(dist.P2POp(dist.isend, t, j, group=group))
+    for r in range(world):                                   # what I receive from rank r
+        theirs = [m for m in range(n_members) if member_owner(m, world) == r]
+        if r == rank or not theirs or b == a:
+            continue
+        t = torch.empty((len(theirs), b - a, per_image), dtype=torch.float32, device=dev)
+        recv[r] = t
+        ops.append(dist.P2POp(dist.irecv, t, r, group=group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    full = np.zeros((n_members, b - a, per_image), np.float32)
+    for r, t in recv.items():
+        theirs = [m for m in range(n_members) if member_owner(m, world) == r]
+        full[theirs] = t.cpu().numpy()
+    outs, off = [], 0
+    for shp in template:
+        k = int(np.prod(shp))
+        outs.append(full[:, :, off:off + k].reshape((n_members, b - a) + tuple(shp)))
+        off += k
+    return outs[:n_cls], outs[n_cls:]
+
+
+def serve_ensemble_striped(member_drivers, post_driver, images, n_members, rank, world, device=None, group=None,
+                           post_mode=None):
+    """Deep ensemble with the members striped over the ranks: member m runs on rank m % world for the whole batch,
+    the head outputs are re-sharded by image (`reshard_member_heads`), every rank aggregates / decodes / NMSes its
+    image shard with all members as the sample axis, one all-gather returns the batch's detections everywhere.
+
+    member_drivers: {member: ServingDriver} for the members this rank owns (deterministic networks, batch = all
+    images); post_driver: an aggregating ServingDriver planned with mc_dropoutsamp = n_members (see EnsembleDriver)."""
+    n = len(images)
+    owned = {}
+    scales = None
+    for m, drv in sorted(member_drivers.items()):
+        a8 = drv._as_u8_batch(images)
+        drv._ck(drv._lib.uda_set_images_u8(drv._h, a8.ctypes.data, n, a8.shape[1], a8.shape[2]), "uda_set_images_u8")
+        drv._ck(drv._lib.uda_run(drv._h, -1, 0), "uda_run")
+        owned[m] = drv.head_outputs(n)
+        _, scales = drv.preprocessed_scales(n)
+    cls_lv, box_lv = reshard_member_heads(owned, n_members, n, rank, world, device=device, group=group)
+    a, b = shard_range(n, rank, world)
+    if scales is None:      # a rank without a member: the image scale depends only on the raw size (dataloader.py:123-135)
+        h, w = np.asarray(images).shape[1:3]
+        H, W = post_driver.image_size
+        s = min(np.float32(H) / np.float32(h), np.float32(W) / np.float32(w))
+        scales = np.full((n,), np.float32(1.0) / np.float32(s), np.float32)
+    if b > a:
+        det = post_driver.postprocess(cls_lv, box_lv, np.asarray(scales, np.float32)[a:b], post_mode=post_mode)
+    else:
+        det = post_driver.empty_detections()
+    return all_gather_detections(det, device=device, group=group)
