@@ -474,6 +474,7 @@ __device__ __forceinline__ float nms_iou(const float* a, const float* b) {
 struct NmsLds {
   float sel[4 * 128];        // up to 128 selected boxes (max_output_size <= 128 on this path)
   int list[NMS_CHUNK];       // candidates of this chunk whose pending chain must be evaluated
+  float wgt[4][128];         // per wave: the chain's weights, computed 64 links at a time by the wave's lanes
   int count;
 };
 
@@ -507,9 +508,53 @@ __device__ __forceinline__ float nms_chain_eval(const NmsArgs& a, const NmsLds& 
   return score;
 }
 
+// The same chain for ONE candidate evaluated by a whole wave (the per-chunk bound candidate, which used to be a
+// serial chain on one thread at the end of every block): the expensive part of a link (IoU + the float64 exp of
+// the soft weight) does not depend on the running score, so the 64 lanes compute 64 links at a time; lane 0 then
+// multiplies them into the score in exactly the reference's order with its early exits (bit-identical).
+// All lanes of the wave must call it with the same arguments; every lane returns the score.
+__device__ __forceinline__ float nms_chain_eval_wave(const NmsArgs& a, NmsLds& L, size_t base, int i, int k) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* wg = L.wgt[wave];
+  const int begin = a.begin[base + i];
+  const size_t bbase = (size_t)(blockIdx.y / a.segs) * a.K;   // boxes are per image, state per problem
+  const float4 b4 = *(const float4*)(a.boxes + (bbase + i) * 4);
+  const float bx[4] = {b4.x, b4.y, b4.z, b4.w};
+  const int n = k - begin;                   // links j = k-1 .. begin -> slot s = k-1-j
+  for (int s0 = 0; s0 < n; s0 += 64) {
+    const int sl = s0 + lane;
+    if (sl < n) {
+      const int j = k - 1 - sl;
+      const float sim = nms_iou(bx, L.sel + 4 * j);
+      float w;
+      if (a.soft || sim <= a.iou_thr) {
+        const float e = a.scale * sim * sim;
+        w = (e == 0.0f) ? 1.0f : (float)exp((double)e);
+      } else {
+        w = 0.0f;
+      }
+      if (!a.soft && sim > a.iou_thr) w = -2.0f;      // hard suppression marker (a weight is never negative)
+      wg[sl] = w;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  float score = a.stale[base + i];
+  if (lane == 0) {
+    for (int sl = 0; sl < n; ++sl) {
+      const float w = wg[sl];
+      if (w == -2.0f) { score = -INFINITY; break; }   // reference: score *= 0, then the hard-suppression return
+      score *= w;
+      if (score <= a.score_thr) { score = -INFINITY; break; }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  return __shfl(score, 0, 64);
+}
+
 // Evaluate the block's work list, one candidate per thread round-robin (the flagged candidates
 // of a chunk are spatial neighbours, so without the compaction a few waves would carry all the
-// chains).  Records tent / ub / ev; returns the best key among the entries this thread evaluated.
+// chains; lists are long and chains short, so a thread per candidate beats a wave per candidate: measured 5x).
+// Records tent / ub / ev; returns the best key among the entries this thread evaluated.
 __device__ __forceinline__ unsigned long long nms_run_list(const NmsArgs& a, NmsLds& L, size_t base, int k) {
   __syncthreads();
   unsigned long long best = 0ull;
@@ -592,13 +637,15 @@ __global__ __launch_bounds__(256) void nms_bound_kernel(NmsArgs a, int k) {
     }
   }
   best = block_max_key(best);
-  if (threadIdx.x == 0 && best != 0ull) {
+  if (threadIdx.x < 64 && best != 0ull) {       // wave 0, cooperatively
     const int idx = (int)(0xFFFFFFFFu - (uint32_t)best);
-    const float s = nms_chain_eval(a, L, base, idx, k);
-    a.tent[base + idx] = s;
-    a.ub[base + idx] = s;
-    a.ev[base + idx] = k;
-    if (s != -INFINITY) atomicMax(&a.bound_key[(size_t)n * a.M + k], nms_key(s, idx));
+    const float s = nms_chain_eval_wave(a, L, base, idx, k);
+    if (threadIdx.x == 0) {
+      a.tent[base + idx] = s;
+      a.ub[base + idx] = s;
+      a.ev[base + idx] = k;
+      if (s != -INFINITY) atomicMax(&a.bound_key[(size_t)n * a.M + k], nms_key(s, idx));
+    }
   }
 }
 
@@ -701,13 +748,15 @@ __global__ __launch_bounds__(256) void nms_commit_kernel(NmsArgs a, int k) {
   // sel_box row may be written by another block of this launch)
   if (threadIdx.x < 4) L.sel[4 * k + threadIdx.x] = a.boxes[((size_t)(n / a.segs) * a.K + widx) * 4 + threadIdx.x];
   __syncthreads();
-  if (threadIdx.x == 0 && best != 0ull) {
+  if (threadIdx.x < 64 && best != 0ull) {       // wave 0, cooperatively
     const int idx = (int)(0xFFFFFFFFu - (uint32_t)best);
-    const float s = nms_chain_eval(a, L, base, idx, k + 1);
-    a.tent[base + idx] = s;
-    a.ub[base + idx] = s;
-    a.ev[base + idx] = k + 1;
-    if (s != -INFINITY) atomicMax(&a.bound_key[(size_t)n * a.M + k + 1], nms_key(s, idx));
+    const float s = nms_chain_eval_wave(a, L, base, idx, k + 1);
+    if (threadIdx.x == 0) {
+      a.tent[base + idx] = s;
+      a.ub[base + idx] = s;
+      a.ev[base + idx] = k + 1;
+      if (s != -INFINITY) atomicMax(&a.bound_key[(size_t)n * a.M + k + 1], nms_key(s, idx));
+    }
   }
 }
 
