@@ -68,6 +68,8 @@ CASES = [
     (3, 1, 31, 88, 528, "bn,act"),
     (1, 1, 40, 208, 1248, "bn,act,mask"),
     (1, 1, 1, 8, 4, ""),
+    (2, 5, 300, 32, 16, "bn,se"),            # shared-input kernel: one tile load for the 5 sample rows of an image
+    (1, 4, 131, 16, 24, "bn,res,mask"),
 ]
 
 

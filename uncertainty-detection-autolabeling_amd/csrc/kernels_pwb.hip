@@ -266,6 +266,113 @@ __global__ __launch_bounds__(256, OCC) void pwb_kernel(PwArgs a) {
   }
 }
 
+// 1x1 conv whose INPUT is shared by the `in_div` sample rows of an image (block 0's projection under full MC
+// dropout: the depthwise output exists once per image, the per-sample SE gate x dropout scale multiplies it on the
+// way in).  A block keeps its 128 x K (K <= 32) input tile in registers and loops over the samples: gate, split,
+// MFMA, epilogue per sample -> the shared tensor is read once instead of in_div times.  Everything is wave-private
+// (each wave owns 32 pixel rows: its slice of the A image and its staging tile), so there is no block barrier.
+__global__ __launch_bounds__(256, 3) void pwb_shared_kernel(PwArgs a) {
+  constexpr int WAVE_BYTES = 32 * PWB_STG * 4;          // staging tile (8.5 KB) >= 2 x 32 x 80 B of the A image
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * WAVE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  unsigned char* Aw = lds + wave * WAVE_BYTES;           // [2 parts][32 rows][80 B]
+  float* stg = (float*)Aw;
+  const int b_in = blockIdx.z;
+  const int m0 = blockIdx.x * 128 + wave * 32;
+  const float* A = a.in + (size_t)b_in * a.HW * a.Cin;
+  const uint4* Wp = (const uint4*)a.wsplit;
+  const int NTL = (a.Cout + 31) >> 5;                    // == 1 (Cout <= 32)
+  // raw input rows of this wave: lane -> (row = lane / 8 + 8 i, k quad = lane % 8)
+  float4 ra[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = (lane >> 3) + 8 * i, k = 4 * (lane & 7);
+    ra[i] = (m0 + m < a.HW && k < a.Cin) ? *(const float4*)(A + (size_t)(m0 + m) * a.Cin + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // weight fragments of both k-steps, both pieces: straight from the packed image into registers
+  bf16x8 bf[2][2];
+  const int KS = (a.Cin + 15) >> 4;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+      bf[ks][p] = __builtin_bit_cast(bf16x8, ks < KS ? Wp[(((size_t)ks * NTL) * 2 + p) * 64 + lane] : make_uint4(0u, 0u, 0u, 0u));
+  const int rrow = lane >> 4, c4 = lane & 15;
+  const int col = 4 * c4;
+  const bool colok = col < a.Cout;
+  float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (colok && (a.Cout & 3) == 0) {
+    if (a.bias) bias = *(const float4*)(a.bias + col);
+    if (a.bn_scale) { sc = *(const float4*)(a.bn_scale + col); sh = *(const float4*)(a.bn_shift + col); }
+  }
+
+  for (int t = 0; t < a.in_div; ++t) {
+    const int b = b_in * a.in_div + t;
+    float4 rg = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (a.se) {
+      const int k = 4 * (lane & 7);
+      if (k < a.Cin) rg = *(const float4*)(a.se + (size_t)(b / a.se_div) * a.Cin + k);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = (lane >> 3) + 8 * i, kq = lane & 7;
+      float r0 = ra[i].x * rg.x, r1 = ra[i].y * rg.y, r2 = ra[i].z * rg.z, r3 = ra[i].w * rg.w;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const unsigned u0 = pack_bf16(r0, r1), u1 = pack_bf16(r2, r3);
+        *(uint2*)(Aw + (size_t)(p * 32 + m) * PWB_AROW + kq * 8) = make_uint2(u0, u1);
+        if (p == 0) {
+          r0 -= bf16_lo_f32(u0); r1 -= bf16_hi_f32(u0);
+          r2 -= bf16_lo_f32(u1); r3 -= bf16_hi_f32(u1);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 a0 = *(const bf16x8*)(Aw + (size_t)(0 * 32 + li) * PWB_AROW + ks * 32 + lh * 16);
+      const bf16x8 a1 = *(const bf16x8*)(Aw + (size_t)(1 * 32 + li) * PWB_AROW + ks * 32 + lh * 16);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bf[ks][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bf[ks][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bf[ks][0], acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();     // the A image of this wave has been read: the staging tile may overwrite it
+#pragma unroll
+    for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * PWB_STG + li] = acc[r];
+    __builtin_amdgcn_wave_barrier();
+    float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (colok && a.mask) mk = *(const float4*)(a.mask + (size_t)b * a.Cout + col);
+    const size_t out_base = (size_t)b * a.HW;
+    const size_t res_base = a.res ? (size_t)(b / a.res_div) * a.HW : 0;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 4 + rrow;
+      const int m = m0 + row;
+      if (colok && m < a.HW) {
+        float4 v = *(const float4*)(stg + row * PWB_STG + col);
+        v.x = fmaf(v.x + bias.x, sc.x, sh.x);
+        v.y = fmaf(v.y + bias.y, sc.y, sh.y);
+        v.z = fmaf(v.z + bias.z, sc.z, sh.z);
+        v.w = fmaf(v.w + bias.w, sc.w, sh.w);
+        if (a.act == UDA_ACT_SWISH) {
+          v.x = swishf_b(v.x); v.y = swishf_b(v.y); v.z = swishf_b(v.z); v.w = swishf_b(v.w);
+        }
+        v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
+        if (a.res) {
+          const float4 rr = *(const float4*)(a.res + (res_base + m) * a.Cout + col);
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        *(float4*)(a.out + (out_base + m) * a.Cout + col) = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();     // the staging tile has been read: the next sample's A image may overwrite it
+  }
+}
+
 template <int MT, int NT, int WM, int WN>
 static void launch_pwb_cfg(const PwArgs& a, int rows, hipStream_t s) {
   constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
@@ -278,6 +385,13 @@ static void launch_pwb_cfg(const PwArgs& a, int rows, hipStream_t s) {
 // tile = 128 pixels x {32, 64, 96, 128} channels (four waves stacked along the pixels for narrow outputs,
 // 2 x 2 waves of 64 x 64 for wide ones)
 void launch_pwb(const PwArgs& a, int rows, hipStream_t s) {
+  static int shared = -1;
+  if (shared < 0) { const char* e = getenv("UDA_PW_SHARED"); shared = e ? atoi(e) : 1; }
+  if (shared && a.in_div > 1 && a.Cin <= 32 && a.Cout <= 32 && (a.Cout & 3) == 0 && a.wparts == 2 && rows % a.in_div == 0) {
+    const dim3 grid((a.HW + 127) / 128, 1, rows / a.in_div);
+    hipLaunchKernelGGL(pwb_shared_kernel, grid, dim3(256), 0, s, a);
+    return;
+  }
   static int force = -1;
   if (force < 0) { const char* e = getenv("UDA_PWB_CFG"); force = e ? atoi(e) : 0; }
   int cfg = force;
