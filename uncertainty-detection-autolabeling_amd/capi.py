@@ -11,7 +11,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libuda_hip.so")
+LIB_PATH = os.environ.get("UDA_LIB") or os.path.join(CSRC, "libuda_hip.so")   # UDA_LIB: an alternative build for A/B runs
 HEADER = os.path.join(os.path.dirname(HERE), "include", "uda_hip.h")
 
 UDA_ABI_VERSION = 1

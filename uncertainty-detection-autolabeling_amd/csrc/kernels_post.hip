@@ -447,7 +447,10 @@ void launch_topk(const float* vals, int n_img, int L, int k, int32_t* out_idx, h
 //   A bound : each 2048-candidate chunk evaluates its stale-best candidate -> lower bound on the winner
 //   B eval  : evaluate every candidate whose stale priority >= bound; global max -> winner
 //   C commit: apply the commit rule, record the winner.
-constexpr int NMS_ITEMS = 8;
+#ifndef UDA_NMS_ITEMS
+#define UDA_NMS_ITEMS 8
+#endif
+constexpr int NMS_ITEMS = UDA_NMS_ITEMS;
 constexpr int NMS_CHUNK = 256 * NMS_ITEMS;
 
 __device__ __forceinline__ unsigned long long nms_key(float s, int idx) {

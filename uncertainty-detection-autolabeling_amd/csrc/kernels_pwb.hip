@@ -38,7 +38,6 @@ __device__ __forceinline__ float swishf_b(float x) { return x * sigmoidf_b(x); }
 // swish with the exponent scale folded into the producer: y = -log2(e) * x comes out of the GEMM / BN (weights,
 // shift and BN scale are pre-multiplied on the host or when they are staged), k = -keep_scale / log2(e):
 //   x * sigmoid(x) * keep_scale = y * k / (1 + 2^y)        (v_exp, v_add, v_rcp, 2 v_mul: 5 VALU instead of 7)
-constexpr float UDA_NEG_LOG2E = -1.4426950408889634f;
 constexpr float UDA_NEG_LN2 = -0.6931471805599453f;
 __device__ __forceinline__ float swish_folded(float y, float k) {
   return (y * k) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y));
@@ -690,7 +689,7 @@ __global__ __launch_bounds__(256, ((K == 3 && S == 2 && KSF <= 3) ? 3 : 2)) void
   extern __shared__ float mlds[];
   float* E = mlds;                            // [NPP][ES]
   float* red = E + (size_t)NPP * ES;          // [NG][32]
-  constexpr int NPAR = (K * K + 3) * 32;      // per slab: depthwise taps [K*K][32] | BN scale | BN shift | mask1
+  constexpr int NPAR = (K * K + 2) * 32;      // per slab: depthwise taps [K*K][32] | BN scale | BN shift (host-packed, a.wpar)
   float* par = red + NG * 32;                 // [2][NPAR]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -747,22 +746,19 @@ __global__ __launch_bounds__(256, ((K == 3 && S == 2 && KSF <= 3) ? 3 : 2)) void
       q.bl[ks] = Wp[(((size_t)ks * NCH + ch) * 2 + 1) * 64 + lane];
     }
     const int ecol = ch * 32 + li;
-    q.mk0 = ((ecol < a.Cmid && a.mask0) ? a.mask0[(size_t)b * a.Cmid + ecol] : 1.f) * UDA_NEG_LN2;
+    const float* m0 = a.mask0 ? a.mask0 + (size_t)b * a.Cmid + (ecol < a.Cmid ? ecol : 0) : (const float*)Wp;
+    const float v0 = *m0;
+    q.mk0 = (a.mask0 ? v0 : 1.f) * UDA_NEG_LN2;
   };
-  // the depthwise-side operands of a slab go through LDS, requested (like the B fragments) before the previous
-  // slab's output stores are issued: vmcnt retires loads and stores in order
-  auto par_value = [&](int chn, int f) -> float {
-    const int row = f >> 5, pcol = chn * 32 + (f & 31);
-    if (pcol >= a.Cmid) return 0.f;
-    if (row < K * K) return a.wd[(size_t)row * a.Cmid + pcol];
-    if (row == K * K) return a.sc1[pcol] * UDA_NEG_LOG2E;
-    if (row == K * K + 1) return a.sh1[pcol] * UDA_NEG_LOG2E;
-    return (a.mask1 ? a.mask1[(size_t)b * a.Cmid + pcol] : 1.f) * UDA_NEG_LN2;
-  };
+  // The depthwise-side operands of a slab (taps, BN scale / shift: one contiguous host-packed block per slab) go
+  // through LDS and, like the B fragments and the dropout scales, are requested while the PREVIOUS slab's expand
+  // phase ends - before that slab's output stores are issued (vmcnt retires loads and stores in order) - by plain
+  // branch-free loads, so that no wait is placed right behind them.
   constexpr int P_PER = (NPAR + 255) / 256;
   SlabB cur, nxt;
   load_b(0, cur);
-  for (int f = tid; f < NPAR; f += 256) par[f] = par_value(0, f);
+  for (int f = tid; f < NPAR; f += 256) par[f] = a.wpar[f];
+  float mk1 = ((c < a.Cmid && a.mask1) ? a.mask1[(size_t)b * a.Cmid + c] : 1.f) * UDA_NEG_LN2, mk1n = mk1;
   __syncthreads();
 
   for (int ch = 0; ch < NCH; ++ch) {
@@ -792,17 +788,24 @@ __global__ __launch_bounds__(256, ((K == 3 && S == 2 && KSF <= 3) ? 3 : 2)) void
     const bool more = ch + 1 < NCH;
     if (more) load_b(ch + 1, nxt);   // in flight during the depthwise phase
     float np_[P_PER];
+    const float* wnext = a.wpar + (size_t)(more ? ch + 1 : ch) * NPAR;
 #pragma unroll
     for (int i = 0; i < P_PER; ++i) {
       const int f = tid + 256 * i;
-      np_[i] = (more && f < NPAR) ? par_value(ch + 1, f) : 0.f;
+      np_[i] = wnext[f < NPAR ? f : 0];
+    }
+    {
+      const int ncol = (more ? ch + 1 : ch) * 32 + c;
+      const float* m1 = a.mask1 ? a.mask1 + (size_t)b * a.Cmid + (ncol < a.Cmid ? ncol : 0) : a.wpar;
+      const float v1 = *m1;          // unconditional (dummy address when the site is inactive): no wait at a branch merge
+      mk1n = (a.mask1 ? v1 : 1.f) * UDA_NEG_LN2;
     }
     __syncthreads();
     // ---- depthwise on E for channel 32 ch + c
     float wk[K * K];
 #pragma unroll
     for (int t = 0; t < K * K; ++t) wk[t] = pcur[t * 32 + c];
-    const float sc1 = pcur[K * K * 32 + c], sh1 = pcur[(K * K + 1) * 32 + c], mk1 = pcur[(K * K + 2) * 32 + c];
+    const float sc1 = pcur[K * K * 32 + c], sh1 = pcur[(K * K + 1) * 32 + c];
     float ssum = 0.f;
     if (dcol) {
 #pragma unroll
@@ -854,6 +857,7 @@ __global__ __launch_bounds__(256, ((K == 3 && S == 2 && KSF <= 3) ? 3 : 2)) void
       a.se_partial[((size_t)b * a.n_tiles + tile) * a.Cmid + col] = t;
     }
     cur = nxt;
+    mk1 = mk1n;
   }
 }
 
@@ -871,7 +875,7 @@ static void launch_mbxb_t(const MbxArgs& a, int rows, hipStream_t s) {
   constexpr int TH = mbxb_cfg(K, S).th, TW = mbxb_cfg(K, S).tw;
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
   constexpr int NPP = (IH * IW + 31) / 32 * 32;
-  const size_t lds = ((size_t)NPP * 33 + 8 * 32 + 2 * (K * K + 3) * 32) * sizeof(float);
+  const size_t lds = ((size_t)NPP * 33 + 8 * 32 + 2 * (K * K + 2) * 32) * sizeof(float);
   const dim3 grid((a.Wo + TW - 1) / TW, (a.Ho + TH - 1) / TH, rows);
   hipLaunchKernelGGL((mbxb_kernel<K, S, KSF>), grid, dim3(256), lds, s, a);
 }
@@ -916,7 +920,7 @@ __global__ __launch_bounds__(512, 2) void mbxd_kernel(MbxArgs a) {
   extern __shared__ __attribute__((aligned(16))) float dlds[];
   float* E = dlds;                            // [NPP][ES]
   float* red = E + (size_t)NPP * ES;          // [NG][32]
-  constexpr int NPAR = (K * K + 4) * 32;      // per slab: depthwise taps [K*K][32] | BN scale | BN shift | mask1 | mask0
+  constexpr int NPAR = (K * K + 2) * 32;      // per slab: depthwise taps [K*K][32] | BN scale | BN shift (host-packed, a.wpar)
   float* par = red + NG * 32;                 // [2][NPAR]
   uint4* Bs = (uint4*)(par + 2 * NPAR);       // [2][KSF][2 parts][64 lanes]
 
@@ -928,25 +932,16 @@ __global__ __launch_bounds__(512, 2) void mbxd_kernel(MbxArgs a) {
   const float* xin = a.in + (size_t)b_in * a.H * a.W * a.Cin;
   const int NCH = (a.Cmid + 31) >> 5;
   const uint4* Wp = (const uint4*)a.wsplit;
-  // Every per-slab operand (packed expand weights, depthwise taps, BN / dropout scalars) is requested while the
-  // PREVIOUS slab's expand phase ends, i.e. before that slab's output stores are issued: vmcnt retires loads and
-  // stores in order, so a load issued after the stores would make its consumer wait for the stores' HBM round trip.
-  auto par_value = [&](int chn, int f) -> float {
-    const int row = f >> 5, col = chn * 32 + (f & 31);
-    if (col >= a.Cmid) return 0.f;
-    if (row < K * K) return a.wd[(size_t)row * a.Cmid + col];
-    if (row == K * K) return a.sc1[col] * UDA_NEG_LOG2E;
-    if (row == K * K + 1) return a.sh1[col] * UDA_NEG_LOG2E;
-    if (row == K * K + 2) return (a.mask1 ? a.mask1[(size_t)b * a.Cmid + col] : 1.f) * UDA_NEG_LN2;
-    return (a.mask0 ? a.mask0[(size_t)b * a.Cmid + col] : 1.f) * UDA_NEG_LN2;
-  };
-
+  // Every per-slab operand (packed expand weights, host-packed depthwise taps + BN scale / shift, dropout scales) is
+  // requested while the PREVIOUS slab's expand phase ends, i.e. before that slab's output stores are issued: vmcnt
+  // retires loads and stores in order, so a load issued after the stores would make its consumer wait for the stores'
+  // HBM round trip.  The loads are plain and branch-free so that no wait is placed right behind them.
   // ---- slab 0 operands -> LDS buffers 0
   for (int f = tid; f < BSLAB; f += 512) {
     const int ks = f >> 7, rest = f & 127;     // [ks][part][lane]
     Bs[f] = Wp[(((size_t)ks * NCH + 0) * 2 + (rest >> 6)) * 64 + (rest & 63)];
   }
-  for (int f = tid; f < NPAR; f += 512) par[f] = par_value(0, f);
+  for (int f = tid; f < NPAR; f += 512) par[f] = a.wpar[f];
 
   // ---- this wave's operand fragments: pixel = wave * 32 + li, channels 16 ks + 8 lh .. + 7
   bf16x8 ah[KSF], al[KSF];
@@ -979,13 +974,14 @@ __global__ __launch_bounds__(512, 2) void mbxd_kernel(MbxArgs a) {
   const int c = tid & 31, g = tid >> 5;       // depthwise stage: channel within the slab, thread group
   const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
   constexpr int B_PER = (BSLAB + 511) / 512;  // uint4 of the next slab per thread
+  float mk1 = ((c < a.Cmid && a.mask1) ? a.mask1[(size_t)b * a.Cmid + c] : 1.f) * UDA_NEG_LN2, mk1n = mk1;
+  float mk0 = ((li < a.Cmid && a.mask0) ? a.mask0[(size_t)b * a.Cmid + li] : 1.f) * UDA_NEG_LN2, mk0n = mk0;
 
   for (int ch = 0; ch < NCH; ++ch) {
     const int col = ch * 32 + c;
     const bool dcol = col < a.Cmid;
     const uint4* bcur = Bs + (size_t)(ch & 1) * BSLAB;
     const float* pcur = par + (ch & 1) * NPAR;
-    const float mk0 = pcur[(K * K + 3) * 32 + li];
     // ---- expand: E[p][j] = swish(sum_k X[p][k] We'[k][32 ch + j]) * mask0 for this wave's 32 pixels
     {
       f32x16 acc;
@@ -1003,9 +999,21 @@ __global__ __launch_bounds__(512, 2) void mbxd_kernel(MbxArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swish_folded(acc[r], mk0);
     }
-    // next slab's packed weights: in flight during the depthwise phase
-    uint4 nb[B_PER];
+    // next slab's operands: in flight during the depthwise phase (dropout scales first: they are the oldest requests,
+    // so the counted wait that retires the weight loads at the end of the slab retires them too)
     const bool more = ch + 1 < NCH;
+    {
+      const int nch = more ? ch + 1 : ch;
+      const int ncol = nch * 32 + c, necol = nch * 32 + li;
+      // unconditional loads (a dummy address when a site is inactive): a load behind a branch gets its wait placed
+      // right at the merge point, which would drain the whole memory queue here
+      const float* m1 = a.mask1 ? a.mask1 + (size_t)b * a.Cmid + (ncol < a.Cmid ? ncol : 0) : a.wpar;
+      const float* m0 = a.mask0 ? a.mask0 + (size_t)b * a.Cmid + (necol < a.Cmid ? necol : 0) : a.wpar;
+      const float v1 = *m1, v0 = *m0;
+      mk1n = (a.mask1 ? v1 : 1.f) * UDA_NEG_LN2;
+      mk0n = (a.mask0 ? v0 : 1.f) * UDA_NEG_LN2;
+    }
+    uint4 nb[B_PER];
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
       const int f = tid + 512 * i;
@@ -1016,17 +1024,18 @@ __global__ __launch_bounds__(512, 2) void mbxd_kernel(MbxArgs a) {
     }
     constexpr int P_PER = (NPAR + 511) / 512;
     float np_[P_PER];
+    const float* wnext = a.wpar + (size_t)(more ? ch + 1 : ch) * NPAR;
 #pragma unroll
     for (int i = 0; i < P_PER; ++i) {
       const int f = tid + 512 * i;
-      np_[i] = (more && f < NPAR) ? par_value(ch + 1, f) : 0.f;
+      np_[i] = wnext[f < NPAR ? f : 0];
     }
     __syncthreads();
     // ---- depthwise on E for channel 32 ch + c
     float wk[K * K];
 #pragma unroll
     for (int t = 0; t < K * K; ++t) wk[t] = pcur[t * 32 + c];
-    const float sc1 = pcur[K * K * 32 + c], sh1 = pcur[(K * K + 1) * 32 + c], mk1 = pcur[(K * K + 2) * 32 + c];
+    const float sc1 = pcur[K * K * 32 + c], sh1 = pcur[(K * K + 1) * 32 + c];
     float ssum = 0.f;
     if (dcol) {
       for (int u = g; u < NUNIT; u += NG) {
@@ -1081,6 +1090,9 @@ __global__ __launch_bounds__(512, 2) void mbxd_kernel(MbxArgs a) {
       for (int gg = 1; gg < NG; ++gg) t += red[gg * 32 + c];
       a.se_partial[((size_t)b * a.n_tiles + tile) * a.Cmid + col] = t;
     }
+    mk1 = mk1n;
+    mk0 = mk0n;
+    asm volatile("" : "+v"(mk1), "+v"(mk0));     // complete before the back-edge (the loop-carried wait would be vmcnt(0))
   }
 }
 
@@ -1100,7 +1112,7 @@ int mbxd_tiles(int Ho, int Wo, int k) {
 template <int K, int KSF>
 static void launch_mbxd_t(const MbxArgs& a, int rows, hipStream_t s) {
   constexpr int TH = (K == 3) ? 12 : 8;
-  const size_t lds = ((size_t)256 * 33 + 16 * 32 + 2 * (K * K + 4) * 32) * sizeof(float) + (size_t)2 * KSF * 2 * 64 * sizeof(uint4);
+  const size_t lds = ((size_t)256 * 33 + 16 * 32 + 2 * (K * K + 2) * 32) * sizeof(float) + (size_t)2 * KSF * 2 * 64 * sizeof(uint4);
   static bool set = false;
   if (!set && lds > 64 * 1024) {
     hipFuncSetAttribute((const void*)mbxd_kernel<K, KSF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1127,6 +1139,22 @@ void launch_mbxd(const MbxArgs& a, int rows, int k, hipStream_t s) {
       default: launch_mbxd_t<5, 14>(a, rows, s); break;
     }
   }
+}
+
+// depthwise-side operands of the fused kernels, one contiguous block per 32-channel slab:
+// [slab][K*K taps | BN scale * -log2(e) | BN shift * -log2(e)][32 channels], zero beyond Cmid
+size_t mbx_par_floats(int Cmid, int k) { return (size_t)((Cmid + 31) / 32) * (k * k + 2) * 32; }
+void mbx_pack_params(const float* wd, const float* sc1, const float* sh1, int Cmid, int k, float* out) {
+  const int nch = (Cmid + 31) / 32, rows = k * k + 2;
+  const float L = -1.4426950408889634f;
+  for (int ch = 0; ch < nch; ++ch)
+    for (int r = 0; r < rows; ++r)
+      for (int j = 0; j < 32; ++j) {
+        const int col = ch * 32 + j;
+        float v = 0.f;
+        if (col < Cmid) v = r < k * k ? wd[(size_t)r * Cmid + col] : (r == k * k ? sc1[col] * L : sh1[col] * L);
+        out[((size_t)ch * rows + r) * 32 + j] = v;
+      }
 }
 
 // expand kernel [Cin][Cmid] times the BN scale, plus the BN shift as row Cin -> packed split-bf16 fragments

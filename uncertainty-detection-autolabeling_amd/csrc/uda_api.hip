@@ -35,6 +35,7 @@ struct uda_ctx {
   // split-bf16 copies of the 1x1 kernels in MFMA fragment order (kernels_pwb.hip); -1 = op keeps the f32 path
   uint16_t* d_wsplit = nullptr;
   std::vector<int64_t> wsplit_off;
+  std::vector<int64_t> wpar_off;   // MBX: offset (uint16 units) of the per-slab depthwise operand block inside d_wsplit
   int pw_parts = 2;            // UDA_PW_TERMS: 3 -> 2 pieces (default), 6 -> 3 pieces, 0 -> f32 MFMA everywhere
   float* d_arena = nullptr;
   // chunk lanes: consecutive chunks alternate between independent (stream, arena) pairs so that the
@@ -348,6 +349,7 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
     const int terms = e ? atoi(e) : 3;
     c->pw_parts = terms == 0 ? 0 : (terms == 6 ? 3 : 2);
     c->wsplit_off.assign(n_ops, -1);
+    c->wpar_off.assign(n_ops, -1);
     const char* em = getenv("UDA_MBX_BF16");
     const bool mbx_bf16 = em ? atoi(em) != 0 : true;
     if (c->pw_parts) {
@@ -362,8 +364,16 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
           pwb_pack_weights(weights + o.w_off, K, Nn, c->pw_parts, packed.data() + at);
         } else if (o.kind == UDA_OP_MBX && mbx_bf16 && o.bn_scale_off >= 0 && o.bn_shift_off >= 0 &&
                    (mbxb_supported(K, Nn, o.k, o.stride) || mbxd_supported(K, Nn, o.k, o.stride))) {
-          packed.resize(at + mbxb_packed_elems(K, Nn));
+          if (o.w2_off < 0 || o.bn2_scale_off < 0 || o.bn2_shift_off < 0) continue;
+          // [split expand weights | 16-byte aligned float block of the depthwise-side operands]
+          const size_t we_elems = (mbxb_packed_elems(K, Nn) + 7) / 8 * 8;
+          const size_t par_fl = mbx_par_floats(Nn, o.k);
+          packed.resize(at + we_elems + 2 * par_fl);
           mbxb_pack_weights(weights + o.w_off, weights + o.bn_scale_off, weights + o.bn_shift_off, K, Nn, packed.data() + at);
+          std::vector<float> par(par_fl);
+          mbx_pack_params(weights + o.w2_off, weights + o.bn2_scale_off, weights + o.bn2_shift_off, Nn, o.k, par.data());
+          memcpy(packed.data() + at + we_elems, par.data(), par_fl * sizeof(float));
+          c->wpar_off[i] = (int64_t)(at + we_elems);
         } else {
           continue;
         }
@@ -712,6 +722,7 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       }
       if (c->wsplit_off[oi] >= 0) {
         a.wsplit = c->d_wsplit + c->wsplit_off[oi];
+        a.wpar = (const float*)(c->d_wsplit + c->wpar_off[oi]);
         if (deep) launch_mbxd(a, rows, o.k, v.stream());
         else launch_mbxb(a, rows, o.k, o.stride, v.stream());
       } else {

@@ -94,7 +94,10 @@ struct MbxArgs {
   int n_tiles;
   unsigned long long* stamps;  // diagnostic phase stamps (UDA_MBX_STAMPS); null in production
   const void* wsplit;     // expand kernel * BN scale (+ BN shift row) as split-bf16 fragments (kernels_pwb.hip) or null
+  const float* wpar;      // per-slab depthwise taps + BN scale / shift block (mbx_pack_params) or null
 };
+size_t mbx_par_floats(int Cmid, int k);
+void mbx_pack_params(const float* wd, const float* sc1, const float* sh1, int Cmid, int k, float* out);
 void launch_mbxb(const MbxArgs& a, int rows, int k, int stride, hipStream_t s);
 void launch_mbxd(const MbxArgs& a, int rows, int k, hipStream_t s);     // deep stride-1 blocks (Cin > 48)
 bool mbxd_supported(int Cin, int Cmid, int k, int stride);
