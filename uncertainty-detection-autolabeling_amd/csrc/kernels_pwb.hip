@@ -765,6 +765,23 @@ __global__ __launch_bounds__(256, ((K == 3 && S == 2 && KSF <= 3) ? 3 : 2)) void
     const int col = ch * 32 + c;
     const bool dcol = col < a.Cmid;
     const float* pcur = par + (ch & 1) * NPAR;
+    // ---- the NEXT slab's operands are requested first (B fragments + expand dropout scale into registers, the
+    // depthwise block and its dropout scale for LDS): unconditional, branch-free loads with a whole phase to arrive
+    const bool more = ch + 1 < NCH;
+    load_b(more ? ch + 1 : ch, nxt);
+    float np_[P_PER];
+    const float* wnext = a.wpar + (size_t)(more ? ch + 1 : ch) * NPAR;
+#pragma unroll
+    for (int i = 0; i < P_PER; ++i) {
+      const int f = tid + 256 * i;
+      np_[i] = wnext[f < NPAR ? f : 0];
+    }
+    {
+      const int ncol = (more ? ch + 1 : ch) * 32 + c;
+      const float* m1 = a.mask1 ? a.mask1 + (size_t)b * a.Cmid + (ncol < a.Cmid ? ncol : 0) : a.wpar;
+      const float v1 = *m1;
+      mk1n = (a.mask1 ? v1 : 1.f) * UDA_NEG_LN2;
+    }
     // ---- expand: E[p][j] = swish(sum_k X[p][k] We'[k][32 ch + j]) * mask0
 #pragma unroll
     for (int t = 0; t < MTW; ++t) {
@@ -785,22 +802,22 @@ __global__ __launch_bounds__(256, ((K == 3 && S == 2 && KSF <= 3) ? 3 : 2)) void
         for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swish_folded(acc[r], cur.mk0);
       }
     }
-    const bool more = ch + 1 < NCH;
-    if (more) load_b(ch + 1, nxt);   // in flight during the depthwise phase
-    float np_[P_PER];
-    const float* wnext = a.wpar + (size_t)(more ? ch + 1 : ch) * NPAR;
-#pragma unroll
-    for (int i = 0; i < P_PER; ++i) {
-      const int f = tid + 256 * i;
-      np_[i] = wnext[f < NPAR ? f : 0];
-    }
-    {
-      const int ncol = (more ? ch + 1 : ch) * 32 + c;
-      const float* m1 = a.mask1 ? a.mask1 + (size_t)b * a.Cmid + (ncol < a.Cmid ? ncol : 0) : a.wpar;
-      const float v1 = *m1;          // unconditional (dummy address when the site is inactive): no wait at a branch merge
-      mk1n = (a.mask1 ? v1 : 1.f) * UDA_NEG_LN2;
-    }
     __syncthreads();
+    // the next slab's operands have had the whole expand phase to arrive; they are consumed HERE, ahead of this
+    // slab's output stores, so that no later wait has to retire those stores (vmcnt retires in order)
+    {
+      float* pnext = par + ((ch + 1) & 1) * NPAR;
+#pragma unroll
+      for (int i = 0; i < P_PER; ++i) {
+        const int f = tid + 256 * i;
+        if (more && f < NPAR) pnext[f] = np_[i];
+      }
+#pragma unroll
+      for (int ks = 0; ks < KSF; ++ks)
+        asm volatile("" : "+v"(nxt.bh[ks].x), "+v"(nxt.bh[ks].y), "+v"(nxt.bh[ks].z), "+v"(nxt.bh[ks].w),
+                          "+v"(nxt.bl[ks].x), "+v"(nxt.bl[ks].y), "+v"(nxt.bl[ks].z), "+v"(nxt.bl[ks].w));
+      asm volatile("" : "+v"(nxt.mk0), "+v"(mk1n));
+    }
     // ---- depthwise on E for channel 32 ch + c
     float wk[K * K];
 #pragma unroll
@@ -841,15 +858,7 @@ __global__ __launch_bounds__(256, ((K == 3 && S == 2 && KSF <= 3) ? 3 : 2)) void
       }
     }
     if (a.se_partial) red[g * 32 + c] = ssum;
-    {
-      float* pnext = par + ((ch + 1) & 1) * NPAR;
-#pragma unroll
-      for (int i = 0; i < P_PER; ++i) {
-        const int f = tid + 256 * i;
-        if (more && f < NPAR) pnext[f] = np_[i];
-      }
-    }
-    __syncthreads();   // E may be rewritten; red[] of this slab and the next slab's operands are complete
+    __syncthreads();   // E may be rewritten; red[] of this slab and the next slab's operands (written after the first barrier) are complete
     if (a.se_partial && g == 0 && dcol) {
       float t = red[c];
 #pragma unroll
@@ -922,7 +931,8 @@ __global__ __launch_bounds__(512, 2) void mbxd_kernel(MbxArgs a) {
   float* red = E + (size_t)NPP * ES;          // [NG][32]
   constexpr int NPAR = (K * K + 2) * 32;      // per slab: depthwise taps [K*K][32] | BN scale | BN shift (host-packed, a.wpar)
   float* par = red + NG * 32;                 // [2][NPAR]
-  uint4* Bs = (uint4*)(par + 2 * NPAR);       // [2][KSF][2 parts][64 lanes]
+  uint4* Bs = (uint4*)(par + 2 * NPAR);       // [KSF][2 parts][64 lanes]: rewritten between the two barriers of a slab
+  float* mks = (float*)(Bs + BSLAB);          // [2][32 * NCH]: dropout keep-scales * -ln2 of this sample row (expand, depthwise)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -942,6 +952,11 @@ __global__ __launch_bounds__(512, 2) void mbxd_kernel(MbxArgs a) {
     Bs[f] = Wp[(((size_t)ks * NCH + 0) * 2 + (rest >> 6)) * 64 + (rest & 63)];
   }
   for (int f = tid; f < NPAR; f += 512) par[f] = a.wpar[f];
+  for (int f = tid; f < 2 * 32 * NCH; f += 512) {
+    const int which = f / (32 * NCH), col = f - which * 32 * NCH;
+    const float* m = which ? a.mask1 : a.mask0;
+    mks[f] = ((m && col < a.Cmid) ? m[(size_t)b * a.Cmid + col] : 1.f) * UDA_NEG_LN2;
+  }
 
   // ---- this wave's operand fragments: pixel = wave * 32 + li, channels 16 ks + 8 lh .. + 7
   bf16x8 ah[KSF], al[KSF];
@@ -974,14 +989,32 @@ __global__ __launch_bounds__(512, 2) void mbxd_kernel(MbxArgs a) {
   const int c = tid & 31, g = tid >> 5;       // depthwise stage: channel within the slab, thread group
   const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
   constexpr int B_PER = (BSLAB + 511) / 512;  // uint4 of the next slab per thread
-  float mk1 = ((c < a.Cmid && a.mask1) ? a.mask1[(size_t)b * a.Cmid + c] : 1.f) * UDA_NEG_LN2, mk1n = mk1;
-  float mk0 = ((li < a.Cmid && a.mask0) ? a.mask0[(size_t)b * a.Cmid + li] : 1.f) * UDA_NEG_LN2, mk0n = mk0;
 
   for (int ch = 0; ch < NCH; ++ch) {
     const int col = ch * 32 + c;
     const bool dcol = col < a.Cmid;
-    const uint4* bcur = Bs + (size_t)(ch & 1) * BSLAB;
+    const uint4* bcur = Bs;
+    const float mk0 = mks[ch * 32 + li], mk1 = mks[32 * NCH + ch * 32 + c];
     const float* pcur = par + (ch & 1) * NPAR;
+    // ---- the NEXT slab's operands are requested first: they have the whole expand phase to arrive
+    const bool more = ch + 1 < NCH;
+    uint4 nb[B_PER];
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {      // (guarded loads measured 6 % faster than clamped unconditional ones here)
+      const int f = tid + 512 * i;
+      const int ks = f >> 7, rest = f & 127;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (more && f < BSLAB) v = Wp[(((size_t)ks * NCH + (ch + 1)) * 2 + (rest >> 6)) * 64 + (rest & 63)];
+      nb[i] = v;
+    }
+    constexpr int P_PER = (NPAR + 511) / 512;
+    float np_[P_PER];
+    const float* wnext = a.wpar + (size_t)(more ? ch + 1 : ch) * NPAR;
+#pragma unroll
+    for (int i = 0; i < P_PER; ++i) {
+      const int f = tid + 512 * i;
+      np_[i] = wnext[f < NPAR ? f : 0];
+    }
     // ---- expand: E[p][j] = swish(sum_k X[p][k] We'[k][32 ch + j]) * mask0 for this wave's 32 pixels
     {
       f32x16 acc;
@@ -999,38 +1032,23 @@ __global__ __launch_bounds__(512, 2) void mbxd_kernel(MbxArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swish_folded(acc[r], mk0);
     }
-    // next slab's operands: in flight during the depthwise phase (dropout scales first: they are the oldest requests,
-    // so the counted wait that retires the weight loads at the end of the slab retires them too)
-    const bool more = ch + 1 < NCH;
-    {
-      const int nch = more ? ch + 1 : ch;
-      const int ncol = nch * 32 + c, necol = nch * 32 + li;
-      // unconditional loads (a dummy address when a site is inactive): a load behind a branch gets its wait placed
-      // right at the merge point, which would drain the whole memory queue here
-      const float* m1 = a.mask1 ? a.mask1 + (size_t)b * a.Cmid + (ncol < a.Cmid ? ncol : 0) : a.wpar;
-      const float* m0 = a.mask0 ? a.mask0 + (size_t)b * a.Cmid + (necol < a.Cmid ? necol : 0) : a.wpar;
-      const float v1 = *m1, v0 = *m0;
-      mk1n = (a.mask1 ? v1 : 1.f) * UDA_NEG_LN2;
-      mk0n = (a.mask0 ? v0 : 1.f) * UDA_NEG_LN2;
-    }
-    uint4 nb[B_PER];
-#pragma unroll
-    for (int i = 0; i < B_PER; ++i) {
-      const int f = tid + 512 * i;
-      const int ks = f >> 7, rest = f & 127;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (more && f < BSLAB) v = Wp[(((size_t)ks * NCH + (ch + 1)) * 2 + (rest >> 6)) * 64 + (rest & 63)];
-      nb[i] = v;
-    }
-    constexpr int P_PER = (NPAR + 511) / 512;
-    float np_[P_PER];
-    const float* wnext = a.wpar + (size_t)(more ? ch + 1 : ch) * NPAR;
-#pragma unroll
-    for (int i = 0; i < P_PER; ++i) {
-      const int f = tid + 512 * i;
-      np_[i] = wnext[f < NPAR ? f : 0];
-    }
     __syncthreads();
+    // the next slab's operands are written to their LDS buffers HERE, ahead of this slab's output stores, so that no
+    // later wait has to retire those stores (vmcnt retires in order)
+    {
+      // (the single weight buffer is free: every wave finished its expand phase before the barrier above)
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i) {
+        const int f = tid + 512 * i;
+        if (more && f < BSLAB) Bs[f] = nb[i];
+      }
+      float* pnext = par + ((ch + 1) & 1) * NPAR;
+#pragma unroll
+      for (int i = 0; i < P_PER; ++i) {
+        const int f = tid + 512 * i;
+        if (more && f < NPAR) pnext[f] = np_[i];
+      }
+    }
     // ---- depthwise on E for channel 32 ch + c
     float wk[K * K];
 #pragma unroll
@@ -1069,30 +1087,13 @@ __global__ __launch_bounds__(512, 2) void mbxd_kernel(MbxArgs a) {
       }
     }
     if (a.se_partial) red[g * 32 + c] = ssum;
-    {
-      uint4* bnext = Bs + (size_t)((ch + 1) & 1) * BSLAB;
-#pragma unroll
-      for (int i = 0; i < B_PER; ++i) {
-        const int f = tid + 512 * i;
-        if (more && f < BSLAB) bnext[f] = nb[i];
-      }
-      float* pnext = par + ((ch + 1) & 1) * NPAR;
-#pragma unroll
-      for (int i = 0; i < P_PER; ++i) {
-        const int f = tid + 512 * i;
-        if (more && f < NPAR) pnext[f] = np_[i];
-      }
-    }
-    __syncthreads();   // E may be rewritten; red[] and the next slab's operands are complete
+    __syncthreads();   // E may be rewritten; red[] and the next slab's operands (written after the first barrier) are complete
     if (a.se_partial && g == 0 && dcol) {
       float t = red[c];
 #pragma unroll
       for (int gg = 1; gg < NG; ++gg) t += red[gg * 32 + c];
       a.se_partial[((size_t)b * a.n_tiles + tile) * a.Cmid + col] = t;
     }
-    mk1 = mk1n;
-    mk0 = mk0n;
-    asm volatile("" : "+v"(mk1), "+v"(mk0));     // complete before the back-edge (the loop-carried wait would be vmcnt(0))
   }
 }
 
@@ -1112,11 +1113,12 @@ int mbxd_tiles(int Ho, int Wo, int k) {
 template <int K, int KSF>
 static void launch_mbxd_t(const MbxArgs& a, int rows, hipStream_t s) {
   constexpr int TH = (K == 3) ? 12 : 8;
-  const size_t lds = ((size_t)256 * 33 + 16 * 32 + 2 * (K * K + 2) * 32) * sizeof(float) + (size_t)2 * KSF * 2 * 64 * sizeof(uint4);
-  static bool set = false;
-  if (!set && lds > 64 * 1024) {
+  const size_t lds = ((size_t)256 * 33 + 16 * 32 + 2 * (K * K + 2) * 32 + 2 * 32 * ((a.Cmid + 31) / 32)) * sizeof(float) +
+                     (size_t)KSF * 2 * 64 * sizeof(uint4);
+  static size_t attr_lds = 64 * 1024;      // above the default limit the kernel needs an explicit opt-in
+  if (lds > attr_lds) {
     hipFuncSetAttribute((const void*)mbxd_kernel<K, KSF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    set = true;
+    attr_lds = lds;
   }
   const dim3 grid((a.Wo + 15) / 16, (a.Ho + TH - 1) / TH, rows);
   hipLaunchKernelGGL((mbxd_kernel<K, KSF>), grid, dim3(512), lds, s, a);
