@@ -229,6 +229,18 @@ int uda_debug_pw(int32_t device, const float* in, const float* w, const float* b
                  int32_t rows, int32_t in_div, int32_t hw, int32_t cin, int32_t cout, int32_t act,
                  int32_t terms, int32_t reps, float* out, float* avg_ms);
 
+/* The numpy NMS family of the reference (row a18, src/nms_np.py:30-278): x1,y1,x2,y2 boxes with the +1 pixel
+ * convention.  method: 0 hard_nms, 1 diou_nms, 2 soft_nms gaussian, 3 soft_nms linear (thresholds as the caller
+ * resolved them: `iou_thresh or 0.5` ...).  uda_nms_np: float64 dets [n,5] -> kept rows out [<= n, 5] in selection
+ * order, *n_out rows.  uda_per_class_nms_np = nms_np.per_class_nms on float32 inputs (boxes y1,x1,y2,x2; classes
+ * 0-based): out [max_boxes, 7] rows [image_id, x1, y1, x2, y2, score, class + 1], dummy rows score -1e5, boxes
+ * multiplied by image_scale. */
+int uda_nms_np(int32_t device, const double* dets, int32_t n, int32_t method, double iou_thresh, double sigma,
+               double score_thresh, double* out, int32_t* n_out);
+int uda_per_class_nms_np(int32_t device, const float* boxes, const float* scores, const int32_t* classes, int32_t k,
+                         float image_id, float image_scale, int32_t num_classes, int32_t max_boxes, int32_t method,
+                         float iou_thresh, float sigma, float score_thresh, float* out);
+
 /* Per-op-kind device timing with HIP events recorded on the handle's stream.
  * kind_mask: bit (1 << uda_op_kind) selects op kinds; bit 16 post-process aggregate, bit 17 NMS. */
 int uda_profile_enable(uda_ctx_t* ctx, uint32_t kind_mask);

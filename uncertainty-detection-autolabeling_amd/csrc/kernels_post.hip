@@ -985,4 +985,118 @@ void launch_calib(const CalibArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(calib_kernel, dim3((a.rows + 127) / 128), dim3(128), 0, s, a);
 }
 
+// ------------------------------------------------------------------------------------ numpy NMS family (row a18)
+// nms_np.hard_nms / diou_nms / soft_nms (reference src/nms_np.py:30-192): boxes x1,y1,x2,y2 with the +1 pixel
+// convention.  One block per problem (a class of an image); T = double for the float64 arrays the family functions
+// are called with directly, float for per_class_nms (float32 boxes / scores make every intermediate float32).
+// hard / diou: the dets arrive sorted by score (descending, host side = argsort()[::-1]); box i is kept iff no kept
+// box before it suppresses it - n greedy steps, the suppression test of a step spread over the block.
+// soft (gaussian / linear): every step takes the arg-max of the current scores, emits it, rescales the others
+// (exp(-iou^2 / sigma) or 1 - iou above the threshold) and drops those that fall below score_thresh.
+template <typename T>
+__device__ __forceinline__ T np_iou(const T* a, T area_a, const T* b, T area_b) {
+  const T w = max((T)0, min(a[2], b[2]) - max(a[0], b[0]) + (T)1);
+  const T h = max((T)0, min(a[3], b[3]) - max(a[1], b[1]) + (T)1);
+  const T inter = w * h;
+  return inter / (area_a + area_b - inter);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nmsnp_kernel(NmsNpArgs<T> a) {
+  __shared__ T red_v[256];
+  __shared__ int red_i[256];
+  __shared__ int s_cur, s_nout;
+  const int pb = blockIdx.x;
+  const int off = a.off[pb], n = a.off[pb + 1] - off;
+  const T* d = a.dets + (size_t)off * 5;
+  T* sc = a.score + off;          // working scores (soft) 
+  int* st = a.state + off;        // 0 alive, 1 removed / emitted
+  T* out = a.out + (size_t)off * 5;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n; i += 256) { sc[i] = d[i * 5 + 4]; st[i] = 0; }
+  if (tid == 0) s_nout = 0;
+  __syncthreads();
+  if (a.method <= 1) {            // hard (0) / diou (1): input sorted by score, descending
+    for (int i = 0; i < n; ++i) {
+      if (st[i]) continue;        // uniform: st[] is only written before a barrier
+      const T* bi = d + i * 5;
+      const T ai = (bi[2] - bi[0] + (T)1) * (bi[3] - bi[1] + (T)1);
+      for (int j = i + 1 + tid; j < n; j += 256) {
+        if (st[j]) continue;
+        const T* bj = d + j * 5;
+        const T aj = (bj[2] - bj[0] + (T)1) * (bj[3] - bj[1] + (T)1);
+        T v = np_iou(bi, ai, bj, aj);
+        if (a.method == 1) {
+          const T ex1 = min(bi[0], bj[0]), ex2 = max(bi[2], bj[2]), ey1 = min(bi[1], bj[1]), ey2 = max(bi[3], bj[3]);
+          const T diag = (ex2 - ex1) * (ex2 - ex1) + (ey2 - ey1) * (ey2 - ey1);
+          const T cxi = (bi[0] + bi[2]) / (T)2, cyi = (bi[1] + bi[3]) / (T)2;
+          const T cxj = (bj[0] + bj[2]) / (T)2, cyj = (bj[1] + bj[3]) / (T)2;
+          const T dist = (cxi - cxj) * (cxi - cxj) + (cyi - cyj) * (cyi - cyj);
+          v = v - dist / (diag + (T)1e-10);
+        }
+        if (!(v <= a.iou_thr)) st[j] = 1;
+      }
+      if (tid == 0) {
+        T* o = out + (size_t)s_nout * 5;
+        for (int k = 0; k < 5; ++k) o[k] = bi[k];
+        s_nout = s_nout + 1;
+      }
+      __syncthreads();
+    }
+  } else {                         // soft: gaussian (2) / linear (3)
+    for (int step = 0; step < n; ++step) {
+      T bv = -INFINITY;
+      int bidx = -1;
+      for (int i = tid; i < n; i += 256)
+        if (!st[i] && (sc[i] > bv || bidx < 0)) { bv = sc[i]; bidx = i; }     // first maximum of this thread's stride
+      red_v[tid] = bv; red_i[tid] = bidx;
+      __syncthreads();
+      for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (tid < s2) {
+          const int oi = red_i[tid + s2];
+          const T ov = red_v[tid + s2];
+          const int mi = red_i[tid];
+          if (oi >= 0 && (mi < 0 || ov > red_v[tid] || (ov == red_v[tid] && oi < mi))) { red_v[tid] = ov; red_i[tid] = oi; }
+        }
+        __syncthreads();
+      }
+      if (tid == 0) s_cur = red_i[0];
+      __syncthreads();
+      const int m = s_cur;
+      if (m < 0) break;
+      const T* bm = d + m * 5;
+      const T am = (bm[2] - bm[0] + (T)1) * (bm[3] - bm[1] + (T)1);
+      if (tid == 0) {
+        T* o = out + (size_t)s_nout * 5;
+        for (int k = 0; k < 4; ++k) o[k] = bm[k];
+        o[4] = sc[m];
+        s_nout = s_nout + 1;
+        st[m] = 1;
+      }
+      __syncthreads();
+      for (int j = tid; j < n; j += 256) {
+        if (st[j]) continue;
+        const T* bj = d + j * 5;
+        const T aj = (bj[2] - bj[0] + (T)1) * (bj[3] - bj[1] + (T)1);
+        const T v = np_iou(bm, am, bj, aj);
+        T wgt;
+        if (a.method == 2) wgt = (T)exp(-(v * v) / a.sigma);
+        else wgt = (v > a.iou_thr) ? (T)1 - v : (T)1;
+        const T ns = sc[j] * wgt;
+        sc[j] = ns;
+        if (!(ns >= a.score_thr)) st[j] = 1;
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) a.n_out[pb] = s_nout;
+}
+
+template <typename T>
+void launch_nmsnp(const NmsNpArgs<T>& a, int n_problems, hipStream_t s) {
+  if (n_problems > 0) hipLaunchKernelGGL(nmsnp_kernel<T>, dim3(n_problems), dim3(256), 0, s, a);
+}
+template void launch_nmsnp<float>(const NmsNpArgs<float>&, int, hipStream_t);
+template void launch_nmsnp<double>(const NmsNpArgs<double>&, int, hipStream_t);
+
 }  // namespace uda

@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <numeric>
 #include <string>
 #include <vector>
 
@@ -1399,5 +1401,109 @@ extern "C" int uda_debug_pw(int32_t device, const float* in, const float* w, con
   hipStreamDestroy(st);
   for (void* p : owned) hipFree(p);
   if (err != hipSuccess) return fail(nullptr, "uda_debug_pw: %s", hipGetErrorString(err));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ numpy NMS family (a18)
+template <typename T>
+static int run_nmsnp(int device, const std::vector<T>& dets, const std::vector<int32_t>& off, int method, double iou_thr,
+                     double sigma, double score_thr, std::vector<T>& out, std::vector<int32_t>& n_out) {
+  const int problems = (int)off.size() - 1;
+  const size_t total = (size_t)off.back();
+  out.assign(total * 5, (T)0);
+  n_out.assign(problems > 0 ? problems : 0, 0);
+  if (problems <= 0 || total == 0) return 0;
+  HIPC(nullptr, hipSetDevice(device));
+  T *d_dets = nullptr, *d_score = nullptr, *d_out = nullptr;
+  int32_t *d_off = nullptr, *d_state = nullptr, *d_nout = nullptr;
+  HIPC(nullptr, dalloc(&d_dets, total * 5)); HIPC(nullptr, dalloc(&d_score, total)); HIPC(nullptr, dalloc(&d_out, total * 5));
+  HIPC(nullptr, dalloc(&d_off, off.size())); HIPC(nullptr, dalloc(&d_state, total)); HIPC(nullptr, dalloc(&d_nout, (size_t)problems));
+  HIPC(nullptr, hipMemcpy(d_dets, dets.data(), total * 5 * sizeof(T), hipMemcpyHostToDevice));
+  HIPC(nullptr, hipMemcpy(d_off, off.data(), off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  NmsNpArgs<T> a{};
+  a.dets = d_dets; a.off = d_off; a.score = d_score; a.state = d_state; a.out = d_out; a.n_out = d_nout;
+  a.method = method; a.iou_thr = (T)iou_thr; a.sigma = (T)sigma; a.score_thr = (T)score_thr;
+  launch_nmsnp<T>(a, problems, nullptr);
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpy(out.data(), d_out, total * 5 * sizeof(T), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(n_out.data(), d_nout, (size_t)problems * sizeof(int32_t), hipMemcpyDeviceToHost);
+  void* fr[] = {d_dets, d_score, d_out, d_off, d_state, d_nout};
+  for (void* p : fr) hipFree(p);
+  if (e != hipSuccess) return fail(nullptr, "nms_np: %s", hipGetErrorString(e));
+  return 0;
+}
+
+// rows sorted by score, descending (what `dets[:, 4].argsort()[::-1]` yields for distinct scores; ties: later index first)
+template <typename T>
+static void sort_desc(std::vector<T>& dets, int begin, int n) {
+  std::vector<int> idx(n);
+  std::iota(idx.begin(), idx.end(), 0);
+  std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) {
+    const T sx = dets[(size_t)(begin + x) * 5 + 4], sy = dets[(size_t)(begin + y) * 5 + 4];
+    return sx > sy || (sx == sy && x > y);
+  });
+  std::vector<T> tmp((size_t)n * 5);
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < 5; ++k) tmp[(size_t)i * 5 + k] = dets[(size_t)(begin + idx[i]) * 5 + k];
+  std::copy(tmp.begin(), tmp.end(), dets.begin() + (size_t)begin * 5);
+}
+
+extern "C" int uda_nms_np(int32_t device, const double* dets, int32_t n, int32_t method, double iou_thresh, double sigma,
+                          double score_thresh, double* out, int32_t* n_out) {
+  if (!dets || !out || !n_out || n < 0 || method < 0 || method > 3) return fail(nullptr, "uda_nms_np: bad argument");
+  std::vector<double> d(dets, dets + (size_t)n * 5), o;
+  std::vector<int32_t> off = {0, n}, no;
+  if (method <= 1) sort_desc(d, 0, n);
+  const int rc = run_nmsnp<double>(device, d, off, method, iou_thresh, sigma, score_thresh, o, no);
+  if (rc) return rc;
+  *n_out = n ? no[0] : 0;
+  std::copy(o.begin(), o.begin() + (size_t)*n_out * 5, out);
+  return 0;
+}
+
+extern "C" int uda_per_class_nms_np(int32_t device, const float* boxes, const float* scores, const int32_t* classes, int32_t k,
+                                    float image_id, float image_scale, int32_t num_classes, int32_t max_boxes, int32_t method,
+                                    float iou_thresh, float sigma, float score_thresh, float* out) {
+  if (!boxes || !scores || !classes || !out || k < 0 || num_classes < 1 || max_boxes < 1 || method < 0 || method > 3)
+    return fail(nullptr, "uda_per_class_nms_np: bad argument");
+  std::vector<float> d;
+  std::vector<int32_t> off = {0}, cls_of;
+  for (int c = 0; c < num_classes; ++c) {
+    const int begin = off.back();
+    int n = 0;
+    for (int i = 0; i < k; ++i)
+      if (classes[i] == c) {           // boxes arrive y1,x1,y2,x2 -> x1,y1,x2,y2 (nms_np.py:234)
+        d.insert(d.end(), {boxes[i * 4 + 1], boxes[i * 4 + 0], boxes[i * 4 + 3], boxes[i * 4 + 2], scores[i]});
+        ++n;
+      }
+    if (!n) continue;
+    if (method <= 1) sort_desc(d, begin, n);
+    off.push_back(begin + n);
+    cls_of.push_back(c);
+  }
+  std::vector<float> o;
+  std::vector<int32_t> no;
+  const int rc = run_nmsnp<float>(device, d, off, method, iou_thresh, sigma, score_thresh, o, no);
+  if (rc) return rc;
+  struct Row { float v[7]; };
+  std::vector<Row> rows;
+  for (size_t p = 0; p + 1 < off.size(); ++p)
+    for (int i = 0; i < no[p]; ++i) {
+      const float* r = o.data() + ((size_t)off[p] + i) * 5;
+      rows.push_back(Row{{image_id, r[0], r[1], r[2], r[3], r[4], (float)(cls_of[p] + 1)}});
+    }
+  std::stable_sort(rows.begin(), rows.end(), [](const Row& x, const Row& y) { return x.v[5] > y.v[5]; });
+  for (int i = 0; i < max_boxes; ++i) {
+    float* dst = out + (size_t)i * 7;
+    if (i < (int)rows.size()) {
+      for (int j = 0; j < 7; ++j) dst[j] = rows[i].v[j];
+    } else {                           // dummy rows: score -1e5 (nms_np.py:256-274)
+      for (int j = 0; j < 7; ++j) dst[j] = 0.f;
+      dst[0] = image_id;
+      dst[5] = -1e5f;
+    }
+    for (int j = 1; j < 5; ++j) dst[j] *= image_scale;
+  }
   return 0;
 }

@@ -254,6 +254,20 @@ struct MergeArgs {         // per-class mode: concat per-class selections, pad, 
   int n_img, K, M, C;
 };
 void launch_merge_per_class(const MergeArgs& a, hipStream_t s);
+template <typename T>
+struct NmsNpArgs {         // numpy NMS family (kernels_post.hip): problems = consecutive slices of dets
+  const T* dets;           // [total, 5] x1 y1 x2 y2 score (sorted by score, descending, for hard / diou)
+  const int32_t* off;      // [problems + 1]
+  T* score;                // [total] workspace
+  int32_t* state;          // [total] workspace
+  T* out;                  // [total, 5] kept rows of each problem at its offset
+  int32_t* n_out;          // [problems]
+  int method;              // 0 hard, 1 diou, 2 gaussian, 3 linear
+  T iou_thr, sigma, score_thr;
+};
+template <typename T>
+void launch_nmsnp(const NmsNpArgs<T>& a, int n_problems, hipStream_t s);
+
 struct CalibArgs {
   const float* boxes;     // [rows, box_cols] output boxes (+ uncertainty columns)
   const float* classes;   // [rows, cls_cols] class id in column 0
