@@ -267,6 +267,8 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
     return fail(nullptr, "uda_create: max_output_size %d outside [1, 128]", model->max_output_size);
   if (model->chunk_images < 1 || model->max_images < 1 || model->mc_samples < 1)
     return fail(nullptr, "uda_create: chunk_images/max_images/mc_samples must be >= 1");
+  if (model->mc_samples > 96)      // the aggregate kernel parks T logits + 4 T box corners per candidate in LDS
+    return fail(nullptr, "uda_create: mc_samples %d > 96 unsupported", model->mc_samples);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, "uda_create: no HIP device available (the HIP path has no CPU fallback)");
