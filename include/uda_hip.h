@@ -56,7 +56,10 @@ enum uda_op_kind {
   UDA_OP_POOL = 6,  /* max pool (stride+1) x (stride+1), stride s, SAME   efficientdet_keras.py:280-290 */
   UDA_OP_MBX = 7,   /* fused MBConv front half: 1x1 expand + BN + swish + dropout -> depthwise kxk/s + BN + swish
                        + dropout + SE tile sums, the 6x-expanded tensor never leaves the CU
-                       (efficientnet_model.py:446-464) */
+                       (efficientnet_model.py:446-464).  With se_scale >= 0 the op also absorbs the PREVIOUS block's
+                       projection (efficientnet_model.py:471-486): in[0] is that block's gated-depthwise tensor D
+                       [C0 <= 32 channels], se_scale its per-row gate [rows, C0], se_w1_off the projection kernel
+                       [C0][se_mid], se_b1_off / se_w2_off its BN scale / shift, se_mid = 16 projected channels */
   UDA_OP_SEP = 8    /* fused SeparableConv2D: depthwise 3x3 stride 1 SAME (kernel at w2_off) -> 1x1 (kernel at w_off)
                        (+bias)(+BN)(+swish)(+dropout); the depthwise result never leaves the CU
                        (efficientdet_keras.py:207-227,421-446,584-626) */

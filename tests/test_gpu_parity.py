@@ -488,8 +488,8 @@ def test_class_probs_entropy_and_unpacking():
 
 @pytest.mark.parametrize("env", [dict(UDA_PW_TERMS="0"), dict(UDA_PW_TERMS="6"),
                                  dict(UDA_FUSE_MBXD="0", UDA_FUSE_SEP="0", UDA_DEFER_DROPOUT="0"),
-                                 dict(UDA_FUSE_MBX="0", UDA_POST_OVERLAP="0")],
-                         ids=["f32-mfma", "six-terms", "no-deep-fusion", "unfused-serial-post"])
+                                 dict(UDA_FUSE_MBX="0", UDA_POST_OVERLAP="0"), dict(UDA_FUSE_PROJ="0", UDA_PW_SHARED="0")],
+                         ids=["f32-mfma", "six-terms", "no-deep-fusion", "unfused-serial-post", "no-absorbed-projection"])
 def test_fallback_paths_stay_parity_green(env):
     """Every switchable path (exact-f32 MFMA kernels, 6-term split, each fusion off) passes the smoke parity check.
     The switches are read once per process, so each configuration runs in its own interpreter."""

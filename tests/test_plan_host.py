@@ -105,10 +105,12 @@ def test_op_list_shape_d0():
     assert fused == shallow + deep
     sep = kinds.count(capi.OP_SEP)             # 24 BiFPN nodes + 2 heads x 5 levels x (3 + 1) separable convs
     assert sep == (64 if pl.fuse_sep else 0)
-    assert len(pl.ops) == 224 - fused - sep
+    proj = sum(1 for o in pl.ops if o["kind"] == capi.OP_MBX and o["se_scale"] >= 0)   # block 0's projection inside block 1's op
+    assert proj == (1 if pl.fuse_proj and shallow else 0)
+    assert len(pl.ops) == 224 - fused - sep - proj
     assert kinds.count(capi.OP_STEM) == 1 and kinds.count(capi.OP_SE) == 16 and kinds.count(capi.OP_FUSE) == 24
     assert kinds.count(capi.OP_POOL) == 2 and kinds.count(capi.OP_DW) == 16 + 24 + 40 - fused - sep
-    assert kinds.count(capi.OP_PW) == 31 + 1 + 5 + 24 + 40 - fused - sep
+    assert kinds.count(capi.OP_PW) == 31 + 1 + 5 + 24 + 40 - fused - sep - proj
     assert len(pl.sites) == 61 and pl.T == 3
 
 
@@ -119,7 +121,8 @@ def test_sample_axis_propagation():
     # block 0: the dropout after the shared depthwise is deferred into the SE gate (it commutes with the
     # squeeze and with the 1x1 projection), so the sample axis starts at the gate / the projection output
     assert not full.bufs[bn["blocks_0/dw"]].per_sample and full.bufs[bn["blocks_0/se"]].per_sample
-    assert full.bufs[bn["blocks_0/out"]].per_sample and full.bufs[bn["blocks_15/out"]].per_sample
+    assert ("blocks_0/out" not in bn) == bool(full.fuse_proj)      # absorbed by block 1's fused op: never materialised
+    assert full.bufs[bn["blocks_1/dw"]].per_sample and full.bufs[bn["blocks_15/out"]].per_sample
     se0 = [o for o in full.ops if full.bufs[o["out"]].name == "blocks_0/se"][0]
     assert se0["drop_site"] == full.site_index["blocks_0/dw"]
     assert all(o["drop_site"] == -1 for o in full.ops if full.bufs[o["out"]].name == "blocks_0/dw")
@@ -208,7 +211,8 @@ def test_cost_accounting_close_to_survey_figures():
     assert 7.9 < gmac_per_w < 8.5        # block 0's depthwise also runs once per image (deferred dropout)
     fused = costs.get(capi.OP_MBX, dict(launches=0))["launches"] // 16
     sep = costs.get(capi.OP_SEP, dict(launches=0))["launches"] // 16
-    assert costs[capi.OP_PW]["launches"] == (101 - fused - sep) * 16
+    proj = 1 if pl.fuse_proj else 0
+    assert costs[capi.OP_PW]["launches"] == (101 - fused - sep - proj) * 16
     assert costs[capi.OP_DW]["launches"] == (80 - fused - sep) * 16
 
 

@@ -669,7 +669,14 @@ __host__ __device__ constexpr MbxCfgB mbxb_cfg(int k, int s) {
 }
 }  // namespace
 
-template <int K, int S, int KSF>   // KSF = 16-deep MFMA k-steps covering Cin + 1
+// FUSE0: the block's 16-channel input does not exist in memory.  It is the previous block's 1x1 projection
+// (block 0: 32 -> 16, BN, no activation) of a tensor D that is shared by the samples of an image, gated per sample
+// (SE gate x deferred dropout scale).  The prologue computes it per 32-pixel slice on the matrix cores as
+// X^T = (W0^T * gate * BN scale) D^T: the 32 x 32 accumulator then has the PIXEL on the lane and 8 of the 16 channels
+// in registers 0..7 of each lane half - exactly an A-operand fragment of the expand MFMA with the k order
+// (j, h) -> channel (j & 3) + 8 (j >> 2) + 4 h, which the host applies to the rows of the packed expand weights.
+// No lane movement, no LDS, and the 16-channel tensor never goes to HBM.
+template <int K, int S, int KSF, bool FUSE0>   // KSF = 16-deep MFMA k-steps covering Cin + 1
 __global__ __launch_bounds__(256, ((K == 3 && S == 2 && KSF <= 3) ? 3 : 2)) void mbxb_kernel(MbxArgs a) {
   constexpr int NW = 4;
   constexpr int TH = mbxb_cfg(K, S).th, TW = mbxb_cfg(K, S).tw;
@@ -697,7 +704,36 @@ __global__ __launch_bounds__(256, ((K == 3 && S == 2 && KSF <= 3) ? 3 : 2)) void
   const int b = blockIdx.z, b_in = b / a.in_div;
   const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
   const int iy0 = oy0 * S - a.pad_t, ix0 = ox0 * S - a.pad_l;
-  const float* xin = a.in + (size_t)b_in * a.H * a.W * a.Cin;
+  const int cin_mem = FUSE0 ? a.c0 : a.Cin;   // channels of the tensor that is actually read
+  const float* xin = a.in + (size_t)b_in * a.H * a.W * cin_mem;
+
+  auto split8 = [](const float4& v0, const float4& v1, bf16x8& hi, bf16x8& lo) {
+    const unsigned h0 = pack_bf16(v0.x, v0.y), h1 = pack_bf16(v0.z, v0.w);
+    const unsigned h2 = pack_bf16(v1.x, v1.y), h3 = pack_bf16(v1.z, v1.w);
+    const unsigned l0 = pack_bf16(v0.x - bf16_lo_f32(h0), v0.y - bf16_hi_f32(h0));
+    const unsigned l1 = pack_bf16(v0.z - bf16_lo_f32(h1), v0.w - bf16_hi_f32(h1));
+    const unsigned l2 = pack_bf16(v1.x - bf16_lo_f32(h2), v1.y - bf16_hi_f32(h2));
+    const unsigned l3 = pack_bf16(v1.z - bf16_lo_f32(h3), v1.w - bf16_hi_f32(h3));
+    hi = __builtin_bit_cast(bf16x8, make_uint4(h0, h1, h2, h3));
+    lo = __builtin_bit_cast(bf16x8, make_uint4(l0, l1, l2, l3));
+  };
+  // FUSE0: A' = W0^T (row = projected channel li) x gate of this sample row, both k-steps of the 32 input channels
+  bf16x8 w0h[2], w0l[2];
+  float sh0v[8];
+  if constexpr (FUSE0) {
+    const float* gp = a.gate + (size_t)(b / a.g_div) * a.c0;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int k = ks * 16 + 8 * lh;
+      float4 w0 = *(const float4*)(a.w0t + li * 32 + k), w1 = *(const float4*)(a.w0t + li * 32 + k + 4);
+      const float4 g0 = *(const float4*)(gp + k), g1 = *(const float4*)(gp + k + 4);
+      w0.x *= g0.x; w0.y *= g0.y; w0.z *= g0.z; w0.w *= g0.w;
+      w1.x *= g1.x; w1.y *= g1.y; w1.z *= g1.z; w1.w *= g1.w;
+      split8(w0, w1, w0h[ks], w0l[ks]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sh0v[j] = a.sh0f[(j & 3) + 8 * (j >> 2) + 4 * lh];
+  }
 
   // ---- this wave's operand fragments: pixel = slice * 32 + li, channels 16 ks + 8 lh .. + 7
   bf16x8 ah[MTW][KSF], al[MTW][KSF];
@@ -707,7 +743,37 @@ __global__ __launch_bounds__(256, ((K == 3 && S == 2 && KSF <= 3) ? 3 : 2)) void
     const int p = mt * 32 + li;
     const int iy = iy0 + p / IW, ix = ix0 + p % IW;
     const bool in = (mt < NMT) && (p < NP) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-    const float* px = xin + ((size_t)(in ? iy : 0) * a.W + (in ? ix : 0)) * a.Cin;
+    const float* px = xin + ((size_t)(in ? iy : 0) * a.W + (in ? ix : 0)) * cin_mem;
+    if constexpr (FUSE0) {
+      static_assert(!FUSE0 || KSF == 2, "the fused projection feeds a 16-channel expand");
+      f32x16 xacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xacc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int k = ks * 16 + 8 * lh;
+        float4 d0 = make_float4(0.f, 0.f, 0.f, 0.f), d1 = d0;
+        if (in) {
+          d0 = *(const float4*)(px + k);
+          d1 = *(const float4*)(px + k + 4);
+        }
+        bf16x8 dh, dl;
+        split8(d0, d1, dh, dl);
+        xacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0l[ks], dh, xacc, 0, 0, 0);
+        xacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0h[ks], dl, xacc, 0, 0, 0);
+        xacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0h[ks], dh, xacc, 0, 0, 0);
+      }
+      // registers 0..7 = channels (j & 3) + 8 (j >> 2) + 4 lh of pixel li: BN shift, zero outside the image
+      float4 v0, v1;
+      v0.x = in ? xacc[0] + sh0v[0] : 0.f; v0.y = in ? xacc[1] + sh0v[1] : 0.f;
+      v0.z = in ? xacc[2] + sh0v[2] : 0.f; v0.w = in ? xacc[3] + sh0v[3] : 0.f;
+      v1.x = in ? xacc[4] + sh0v[4] : 0.f; v1.y = in ? xacc[5] + sh0v[5] : 0.f;
+      v1.z = in ? xacc[6] + sh0v[6] : 0.f; v1.w = in ? xacc[7] + sh0v[7] : 0.f;
+      split8(v0, v1, ah[t][0], al[t][0]);
+      float4 f0 = make_float4((lh == 0 && in) ? 1.f : 0.f, 0.f, 0.f, 0.f), f1 = make_float4(0.f, 0.f, 0.f, 0.f);
+      split8(f0, f1, ah[t][1], al[t][1]);       // k-step 1: only the "inside the image" channel
+      continue;
+    }
 #pragma unroll
     for (int ks = 0; ks < KSF; ++ks) {
       const int k = ks * 16 + 8 * lh;
@@ -886,7 +952,10 @@ static void launch_mbxb_t(const MbxArgs& a, int rows, hipStream_t s) {
   constexpr int NPP = (IH * IW + 31) / 32 * 32;
   const size_t lds = ((size_t)NPP * 33 + 8 * 32 + 2 * (K * K + 2) * 32) * sizeof(float);
   const dim3 grid((a.Wo + TW - 1) / TW, (a.Ho + TH - 1) / TH, rows);
-  hipLaunchKernelGGL((mbxb_kernel<K, S, KSF>), grid, dim3(256), lds, s, a);
+  if constexpr (KSF == 2) {
+    if (a.gate) { hipLaunchKernelGGL((mbxb_kernel<K, S, KSF, true>), grid, dim3(256), lds, s, a); return; }
+  }
+  hipLaunchKernelGGL((mbxb_kernel<K, S, KSF, false>), grid, dim3(256), lds, s, a);
 }
 
 template <int K, int S>
@@ -1161,15 +1230,32 @@ void mbx_pack_params(const float* wd, const float* sc1, const float* sh1, int Cm
 
 // expand kernel [Cin][Cmid] times the BN scale, plus the BN shift as row Cin -> packed split-bf16 fragments
 size_t mbxb_packed_elems(int Cin, int Cmid) { return pwb_packed_elems(Cin + 1, Cmid, 2); }
-void mbxb_pack_weights(const float* we, const float* sc0, const float* sh0, int Cin, int Cmid, uint16_t* out) {
+// perm16: rows 0..15 stored in the k order of an accumulator tile used as the A operand (FUSE0): slot 8 h + j holds
+// channel (j & 3) + 8 (j >> 2) + 4 h
+void mbxb_pack_weights(const float* we, const float* sc0, const float* sh0, int Cin, int Cmid, uint16_t* out, bool perm16) {
   float* w = (float*)malloc((size_t)(Cin + 1) * Cmid * sizeof(float));
   // the GEMM delivers y = -log2(e) * BN(x W): see swish_folded
   const float L = -1.4426950408889634f;
   for (int k = 0; k < Cin; ++k)
     for (int n = 0; n < Cmid; ++n) w[(size_t)k * Cmid + n] = we[(size_t)k * Cmid + n] * sc0[n] * L;
   for (int n = 0; n < Cmid; ++n) w[(size_t)Cin * Cmid + n] = sh0[n] * L;
+  if (perm16 && Cin == 16) {
+    float* t = (float*)malloc((size_t)16 * Cmid * sizeof(float));
+    memcpy(t, w, (size_t)16 * Cmid * sizeof(float));
+    for (int h = 0; h < 2; ++h)
+      for (int j = 0; j < 8; ++j)
+        memcpy(w + (size_t)(8 * h + j) * Cmid, t + (size_t)((j & 3) + 8 * (j >> 2) + 4 * h) * Cmid, (size_t)Cmid * sizeof(float));
+    free(t);
+  }
   pwb_pack_weights(w, Cin + 1, Cmid, 2, out);
   free(w);
+}
+
+// FUSE0 operands: W0^T [32 projected channels (16 real)][32 input channels] times the BN scale, then the BN shift [32]
+void mbxb_pack_proj(const float* w0 /*[c0][cout]*/, const float* sc, const float* sh, int c0, int cout, float* out /*[32*32 + 32]*/) {
+  for (int r = 0; r < 32; ++r)
+    for (int k = 0; k < 32; ++k) out[r * 32 + k] = (r < cout && k < c0) ? w0[(size_t)k * cout + r] * sc[r] : 0.f;
+  for (int r = 0; r < 32; ++r) out[32 * 32 + r] = r < cout ? sh[r] : 0.f;
 }
 
 // ---------------------------------------------------------------- host-side weight split / packing

@@ -313,6 +313,13 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
       uda_destroy(c);
       return 1;
     }
+    if (o.kind == UDA_OP_MBX && o.se_scale >= 0 &&
+        (!okbuf(o.se_scale) || o.se_mid != 16 || bufs[o.in[0]].C > 32 || bufs[o.in[0]].C % 8 || bufs[o.se_scale].C != bufs[o.in[0]].C ||
+         o.se_w1_off < 0 || o.se_b1_off < 0 || o.se_w2_off < 0)) {
+      fail(nullptr, "op %d: fused projection needs a [rows, C0 <= 32] gate, a 16-channel projection and its kernel / BN offsets", i);
+      uda_destroy(c);
+      return 1;
+    }
     if (o.kind == UDA_OP_SEP && (o.w_off < 0 || o.w2_off < 0 || !sep_supported(bufs[o.in[0]].C, bufs[o.out].C) ||
                                  bufs[o.in[0]].H != bufs[o.out].H || bufs[o.in[0]].W != bufs[o.out].W)) {
       fail(nullptr, "op %d: fused separable conv %d->%d unsupported (needs both kernels, C %% 8 == 0, 16 <= C <= 128, same size)",
@@ -367,16 +374,20 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
           packed.resize(at + pwb_packed_elems(K, Nn, c->pw_parts));
           pwb_pack_weights(weights + o.w_off, K, Nn, c->pw_parts, packed.data() + at);
         } else if (o.kind == UDA_OP_MBX && mbx_bf16 && o.bn_scale_off >= 0 && o.bn_shift_off >= 0 &&
-                   (mbxb_supported(K, Nn, o.k, o.stride) || mbxd_supported(K, Nn, o.k, o.stride))) {
+                   (mbxb_supported(o.se_scale >= 0 ? o.se_mid : K, Nn, o.k, o.stride) || mbxd_supported(K, Nn, o.k, o.stride))) {
           if (o.w2_off < 0 || o.bn2_scale_off < 0 || o.bn2_shift_off < 0) continue;
-          // [split expand weights | 16-byte aligned float block of the depthwise-side operands]
-          const size_t we_elems = (mbxb_packed_elems(K, Nn) + 7) / 8 * 8;
+          const bool fuse0 = o.se_scale >= 0;      // the previous block's projection is computed in this op's prologue
+          const int Ke = fuse0 ? o.se_mid : K;     // input channels of the expand
+          // [split expand weights | 16-byte aligned float block of the depthwise-side operands | (fuse0) projection block]
+          const size_t we_elems = (mbxb_packed_elems(Ke, Nn) + 7) / 8 * 8;
           const size_t par_fl = mbx_par_floats(Nn, o.k);
-          packed.resize(at + we_elems + 2 * par_fl);
-          mbxb_pack_weights(weights + o.w_off, weights + o.bn_scale_off, weights + o.bn_shift_off, K, Nn, packed.data() + at);
-          std::vector<float> par(par_fl);
+          const size_t proj_fl = fuse0 ? 32 * 32 + 32 : 0;
+          packed.resize(at + we_elems + 2 * (par_fl + proj_fl));
+          mbxb_pack_weights(weights + o.w_off, weights + o.bn_scale_off, weights + o.bn_shift_off, Ke, Nn, packed.data() + at, fuse0);
+          std::vector<float> par(par_fl + proj_fl);
           mbx_pack_params(weights + o.w2_off, weights + o.bn2_scale_off, weights + o.bn2_shift_off, Nn, o.k, par.data());
-          memcpy(packed.data() + at + we_elems, par.data(), par_fl * sizeof(float));
+          if (fuse0) mbxb_pack_proj(weights + o.se_w1_off, weights + o.se_b1_off, weights + o.se_w2_off, K, Ke, par.data() + par_fl);
+          memcpy(packed.data() + at + we_elems, par.data(), par.size() * sizeof(float));
           c->wpar_off[i] = (int64_t)(at + we_elems);
         } else {
           continue;
@@ -699,9 +710,12 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
     }
     case UDA_OP_MBX: {
       const uda_buf_desc_t& ib = c->bufs[o.in[0]];
-      const bool deep = ib.C > 48;
-      if (deep ? !(mbxd_supported(ib.C, ob.C, o.k, o.stride) && c->wsplit_off[oi] >= 0) : !mbx_supported(ib.C, ob.C, o.k, o.stride))
-        return fail(c, "op %d: fused MBConv %d->%d k%d s%d unsupported", oi, ib.C, ob.C, o.k, o.stride);
+      const bool fuse0 = o.se_scale >= 0;
+      const int cin = fuse0 ? o.se_mid : ib.C;     // input channels of the expand
+      const bool deep = cin > 48;
+      if (fuse0 && c->wsplit_off[oi] < 0) return fail(c, "op %d: the fused projection needs the split-bf16 path", oi);
+      if (deep ? !(mbxd_supported(cin, ob.C, o.k, o.stride) && c->wsplit_off[oi] >= 0) : !mbx_supported(cin, ob.C, o.k, o.stride))
+        return fail(c, "op %d: fused MBConv %d->%d k%d s%d unsupported", oi, cin, ob.C, o.k, o.stride);
       if (o.drop_site2 >= c->model.n_drop_sites || (o.drop_site2 >= 0 && c->sites[o.drop_site2].channels != ob.C))
         return fail(c, "op %d: bad second dropout site", oi);
       MbxArgs a{};
@@ -712,7 +726,7 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       if (!a.we || !a.sc0 || !a.wd || !a.sc1) return fail(c, "op %d: fused MBConv needs both kernels and both BNs", oi);
       a.mask0 = v.mask(o.drop_site);
       a.mask1 = v.mask(o.drop_site2);
-      a.H = ib.H; a.W = ib.W; a.Ho = ob.H; a.Wo = ob.W; a.Cin = ib.C; a.Cmid = ob.C;
+      a.H = ib.H; a.W = ib.W; a.Ho = ob.H; a.Wo = ob.W; a.Cin = cin; a.Cmid = ob.C;
       a.pad_t = same_pad_before(ib.H, ob.H, o.k, o.stride);
       a.pad_l = same_pad_before(ib.W, ob.W, o.k, o.stride);
       a.in_div = v.div(ib, ob);
@@ -727,6 +741,15 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       if (c->wsplit_off[oi] >= 0) {
         a.wsplit = c->d_wsplit + c->wsplit_off[oi];
         a.wpar = (const float*)(c->d_wsplit + c->wpar_off[oi]);
+        if (fuse0) {
+          const uda_buf_desc_t& gb = c->bufs[o.se_scale];
+          if (gb.per_sample && !ob.per_sample) return fail(c, "op %d: per-sample gate on a per-image output", oi);
+          a.gate = v.ptr(o.se_scale);
+          a.g_div = v.div(gb, ob);
+          a.c0 = ib.C;
+          a.w0t = a.wpar + mbx_par_floats(ob.C, o.k);
+          a.sh0f = a.w0t + 32 * 32;
+        }
         if (deep) launch_mbxd(a, rows, o.k, v.stream());
         else launch_mbxb(a, rows, o.k, o.stride, v.stream());
       } else {

@@ -95,7 +95,13 @@ struct MbxArgs {
   unsigned long long* stamps;  // diagnostic phase stamps (UDA_MBX_STAMPS); null in production
   const void* wsplit;     // expand kernel * BN scale (+ BN shift row) as split-bf16 fragments (kernels_pwb.hip) or null
   const float* wpar;      // per-slab depthwise taps + BN scale / shift block (mbx_pack_params) or null
+  // fused projection of the previous block (mbxb_kernel FUSE0): in = D [rows / in_div, H, W, c0]
+  const float* gate;      // [rows / g_div, c0] per-sample gate on D (SE gate x deferred dropout), null = not fused
+  const float* w0t;       // [32][32] projection kernel^T x BN scale (mbxb_pack_proj)
+  const float* sh0f;      // [32] projection BN shift
+  int c0, g_div;
 };
+void mbxb_pack_proj(const float* w0, const float* sc, const float* sh, int c0, int cout, float* out);
 size_t mbx_par_floats(int Cmid, int k);
 void mbx_pack_params(const float* wd, const float* sc1, const float* sh1, int Cmid, int k, float* out);
 void launch_mbxb(const MbxArgs& a, int rows, int k, int stride, hipStream_t s);
@@ -105,7 +111,7 @@ int mbxd_tiles(int Ho, int Wo, int k);
 bool mbxb_supported(int Cin, int Cmid, int k, int stride);
 int mbxb_tiles(int Ho, int Wo, int k, int stride);
 size_t mbxb_packed_elems(int Cin, int Cmid);
-void mbxb_pack_weights(const float* we, const float* sc0, const float* sh0, int Cin, int Cmid, uint16_t* out);
+void mbxb_pack_weights(const float* we, const float* sc0, const float* sh0, int Cin, int Cmid, uint16_t* out, bool perm16 = false);
 void launch_mbx(const MbxArgs& a, int rows, int k, int stride, hipStream_t s);
 int mbx_tiles(int Ho, int Wo, int k, int stride);
 bool mbx_supported(int Cin, int Cmid, int k, int stride);

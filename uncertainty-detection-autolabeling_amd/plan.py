@@ -109,6 +109,8 @@ class Plan:
         import os
         self.defer_dropout = bool(int(os.environ.get("UDA_DEFER_DROPOUT", "1")))
         self.fuse_sep = bool(int(os.environ.get("UDA_FUSE_SEP", "1"))) and int(os.environ.get("UDA_PW_TERMS", "3")) != 0
+        self.fuse_proj = (bool(int(os.environ.get("UDA_FUSE_PROJ", "1"))) and int(os.environ.get("UDA_PW_TERMS", "3")) != 0
+                          and bool(int(os.environ.get("UDA_MBX_BF16", "1"))) and bool(int(os.environ.get("UDA_FUSE_MBX", "1"))))
         self._build_sites()
         self._lower()
         self._plan_memory()
@@ -251,6 +253,7 @@ class Plan:
                      act=capi.ACT_SWISH, k=3, stride=2)
         reductions = []
         red_ids = set(arch.reduction_block_ids(blocks))
+        pending_proj = None      # (gate buffer, projection kernel, BN name) of a block whose 1x1 projection the next block absorbs
         for i, b in enumerate(blocks):
             p = "%s/blocks_%d/" % (bb, i)
             bn_names = [p + "tpu_batch_normalization" + ("" if j == 0 else "_%d" % j) for j in range(3)]
@@ -263,9 +266,16 @@ class Plan:
                 Ho, Wo = same_out(xb.H, b["stride"]), same_out(xb.W, b["stride"])
                 s0, s1 = self._site("blocks_%d/expand" % i), self._site("blocks_%d/dw" % i)
                 ps = xb.per_sample or s0 >= 0 or s1 >= 0
+                kw = {}
+                if pending_proj is not None:        # x is the previous block's gated-depthwise tensor, not its output
+                    gate_b, proj_k, proj_bn = pending_proj
+                    ps = ps or self.bufs[gate_b].per_sample
+                    kw.update(se_scale=gate_b, se_w1_off=self._pack(w[proj_k]), se_mid=b["cin"])
+                    kw["se_b1_off"], kw["se_w2_off"] = self._bn(proj_bn)
+                    pending_proj = None
                 out = self._buf(Ho, Wo, mid, ps, name="blocks_%d/dw" % i)
                 part = -1
-                kw = dict(k=b["kernel"], stride=b["stride"], w_off=self._pack(w[p + "conv2d/kernel"]),
+                kw.update(k=b["kernel"], stride=b["stride"], w_off=self._pack(w[p + "conv2d/kernel"]),
                           drop_site=s0, drop_site2=s1, act=capi.ACT_SWISH,
                           w2_off=self._pack(w[p + "depthwise_conv2d/depthwise_kernel"]))
                 kw["bn_scale_off"], kw["bn_shift_off"] = self._bn(bn_names[0])
@@ -304,6 +314,17 @@ class Plan:
                                 se_b1_off=self._pack(w[p + "se/conv2d/bias"]),
                                 se_w2_off=self._pack(w[p + "se/conv2d_1/kernel"]),
                                 se_b2_off=self._pack(w[p + "se/conv2d_1/bias"]))
+            nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+            absorb = (self.fuse_proj and nxt is not None and b["expand"] == 1 and gate >= 0 and not b["skip"] and b["cout"] == 16
+                      and nxt["cin"] == 16 and nxt["expand"] != 1 and not nxt["skip"] and self.bufs[x].C <= 32
+                      and mbx_supported(16, 16 * nxt["expand"], nxt["kernel"], nxt["stride"])
+                      and (i not in red_ids or len([r for r in red_ids if r <= i]) < cfg["min_level"]))
+            if absorb:
+                # the next block's fused kernel computes this projection in its prologue: the 16-channel tensor is never stored
+                pending_proj = (gate, proj, bn_names[nb])
+                if i in red_ids:
+                    reductions.append(-1)           # an endpoint below min_level: not an FPN input
+                continue
             x = self._pw(x, b["cout"], proj, "blocks_%d/out" % i, bn=bn_names[nb], se=gate,
                          residual=inp if b["skip"] else -1)
             if i in red_ids:
@@ -593,8 +614,12 @@ def op_costs(plan, n_images):
             fl = 2 * rows * ob.H * ob.W * 27 * ob.C
         elif k == capi.OP_MBX:
             ib = plan.bufs[o["ins"][0]]
-            by += ib.C * ob.C + o["k"] * o["k"] * ob.C
-            fl = 2 * rows * (ib.H * ib.W * ib.C * ob.C + ob.H * ob.W * ob.C * o["k"] * o["k"])
+            cin = o["se_mid"] if o["se_scale"] >= 0 else ib.C
+            by += cin * ob.C + o["k"] * o["k"] * ob.C
+            fl = 2 * rows * (ib.H * ib.W * cin * ob.C + ob.H * ob.W * ob.C * o["k"] * o["k"])
+            if o["se_scale"] >= 0:      # absorbed projection of the previous block
+                by += ib.C * cin
+                fl += 2 * rows * ib.H * ib.W * ib.C * cin
         elif k == capi.OP_SEP:
             ib = plan.bufs[o["ins"][0]]
             by += ib.C * ob.C + 9 * ib.C
