@@ -494,10 +494,12 @@ void launch_dw(DwArgs a, int rows, int k, int stride, hipStream_t s) {
 // ------------------------------------------------------------------------------------ squeeze-excite
 // One block per sample row: channel means from the depthwise kernel's tile sums (fixed
 // order), then the two tiny dense layers.
-__global__ __launch_bounds__(256) void se_kernel(SeArgs a) {
-  extern __shared__ float sm[];  // red[256 float4] | mean[C] | mid[mid]
+constexpr int SE_THREADS = 1024;   // the tile-sum reduction is a chain of dependent loads per thread: more threads = shorter chains
+
+__global__ __launch_bounds__(SE_THREADS) void se_kernel(SeArgs a) {
+  extern __shared__ float sm[];  // red[SE_THREADS float4] | mean[C] | mid[mid]
   float4* red = (float4*)sm;
-  float* mean = sm + 1024;
+  float* mean = sm + 4 * SE_THREADS;
   float* mid = mean + a.C;
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
@@ -507,17 +509,27 @@ __global__ __launch_bounds__(256) void se_kernel(SeArgs a) {
   const float* part = a.partial + (size_t)(b / a.in_div) * a.n_tiles * a.C;
   const float* dm = a.mask ? a.mask + (size_t)b * a.C : nullptr;
   const int C4 = a.C >> 2;
-  // channel sums: thread = (channel quad, tile group); groups are combined in a fixed order
-  for (int cbase = 0; cbase < C4; cbase += 256) {
-    const int cw = min(256, C4 - cbase);
-    const int G = 256 / cw;
+  // channel sums: thread = (channel quad, tile group); groups are combined in a fixed order (deterministic)
+  for (int cbase = 0; cbase < C4; cbase += SE_THREADS) {
+    const int cw = min(SE_THREADS, C4 - cbase);
+    const int G = SE_THREADS / cw;
     const int c4 = cbase + tid % cw, g = tid / cw;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g < G) {
-      for (int t = g; t < a.n_tiles; t += G) {
-        const float4 v = *(const float4*)(part + (size_t)t * a.C + c4 * 4);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      // two independent accumulation chains (tiles g, g + 2G, ... and g + G, g + 3G, ...), summed in a fixed order
+      float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f);
+      int t = g;
+      for (; t + G < a.n_tiles; t += 2 * G) {
+        const float4 v0 = *(const float4*)(part + (size_t)t * a.C + c4 * 4);
+        const float4 v1 = *(const float4*)(part + (size_t)(t + G) * a.C + c4 * 4);
+        s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+        s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
       }
+      if (t < a.n_tiles) {
+        const float4 v0 = *(const float4*)(part + (size_t)t * a.C + c4 * 4);
+        s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+      }
+      s.x += s1.x; s.y += s1.y; s.z += s1.z; s.w += s1.w;
     }
     red[tid] = s;
     __syncthreads();
@@ -535,10 +547,20 @@ __global__ __launch_bounds__(256) void se_kernel(SeArgs a) {
     }
     __syncthreads();
   }
-  for (int j = tid; j < a.mid; j += blockDim.x) {
+  // first dense layer: thread = (hidden unit j, slice of the channels); slices are combined in a fixed order
+  {
+    const int P = min(SE_THREADS / a.mid, a.C);          // channel slices per hidden unit (mid <= SE_THREADS)
+    const int j = tid % a.mid, part = tid / a.mid;
     float s = 0.f;
-    for (int c = 0; c < a.C; ++c) s = fmaf(mean[c], a.w1[(size_t)c * a.mid + j], s);
-    mid[j] = swishf(s + a.b1[j]);
+    if (part < P)
+      for (int c = part; c < a.C; c += P) s = fmaf(mean[c], a.w1[(size_t)c * a.mid + j], s);
+    float* redf = (float*)red;
+    redf[tid] = s;
+    __syncthreads();
+    if (part == 0) {
+      for (int q = 1; q < P; ++q) s += redf[q * a.mid + j];
+      mid[j] = swishf(s + a.b1[j]);
+    }
   }
   __syncthreads();
   for (int c = tid; c < a.C; c += blockDim.x) {
@@ -549,7 +571,7 @@ __global__ __launch_bounds__(256) void se_kernel(SeArgs a) {
 }
 
 void launch_se(const SeArgs& a, int rows, hipStream_t s) {
-  hipLaunchKernelGGL(se_kernel, dim3(rows), dim3(256), (1024 + a.C + a.mid) * sizeof(float), s, a);
+  hipLaunchKernelGGL(se_kernel, dim3(rows), dim3(SE_THREADS), (4 * SE_THREADS + a.C + a.mid) * sizeof(float), s, a);
 }
 
 // ------------------------------------------------------------------------------------ fusion / pooling

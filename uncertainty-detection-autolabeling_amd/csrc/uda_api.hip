@@ -787,6 +787,7 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       a.C = src.C; a.mid = o.se_mid; a.n_tiles = pb.H * pb.W;   // the producer (DW / MBX) validated this count
       a.inv_hw = 1.0f / (float)(src.H * src.W);
       if (pb.C != src.C || ob.C != src.C) return fail(c, "op %d: SE channel mismatch", oi);
+      if (a.mid < 1 || a.mid > 1024) return fail(c, "op %d: SE hidden width %d outside [1, 1024]", oi, a.mid);
       // deferred dropout site (plan.py): the squeezed tensor is per image, its keep-scale per sample row
       a.mask = v.mask(o.drop_site);
       a.in_div = v.div(pb, ob);
