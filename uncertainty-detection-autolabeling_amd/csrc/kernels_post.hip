@@ -779,6 +779,266 @@ void launch_nms_epoch(const NmsArgs& a, int epoch, hipStream_t s) {
 
 void launch_nms_finish(const NmsArgs&, int, hipStream_t) {}
 
+// ------------------------------------------------------------------------------------ NMS, one launch
+// The same epoch rule executed by ONE block per problem (image, or image x class) for all epochs: problems are
+// independent, so nothing but __syncthreads is needed and the 2 x max_output_size dependent launches of the grid
+// version become one.  The candidates are cut into chunks of 1024 (one per thread); the block keeps, per chunk,
+//   cub[ch] = max key over alive candidates of the cached upper bound ub (<= stale: drives the search for the winner)
+//   cst[ch] = max key over alive candidates of the stale score          (drives the pops)
+// in LDS, so an epoch only visits chunks that can matter:
+//   search: repeatedly take the unvisited chunk with the largest cub > L, evaluate the exact score of every
+//           candidate in it with key(ub) > L (one thread each), L = max(L, best exact key) - until no chunk beats L;
+//   pops  : every chunk with cst > key(winner) (and the winner's chunk): candidates whose STALE priority outranks
+//           the winner take their exact score (begin = k), the winner is recorded and removed; cub / cst of the
+//           chunk are recomputed.
+// Identical selections and scores to the grid version (and to the heap of the reference) bit for bit.
+constexpr int SOLO_T = 1024;
+constexpr int SOLO_MAXCH = 512;
+
+struct SoloLds {
+  float sel[4 * 128];
+  unsigned long long cub[SOLO_MAXCH], cst[SOLO_MAXCH];
+  unsigned long long r0[SOLO_T / 64], r1[SOLO_T / 64];
+  unsigned char visited[SOLO_MAXCH];
+  float wgt[128];            // link weights of the epoch's first bound candidate (computed by wave 0, 64 links at a time)
+  unsigned long long L;
+  int pick;
+};
+
+__device__ __forceinline__ float solo_chain(const NmsArgs& a, const SoloLds& S, size_t base, size_t bbase, int i, int k) {
+  float score = a.stale[base + i];
+  const int begin = a.begin[base + i];
+  const float4 b4 = *(const float4*)(a.boxes + (bbase + i) * 4);
+  const float bx[4] = {b4.x, b4.y, b4.z, b4.w};
+  for (int j = k - 1; j >= begin; --j) {
+    const float sim = nms_iou(bx, S.sel + 4 * j);
+    float w;
+    if (a.soft || sim <= a.iou_thr) {
+      const float e = a.scale * sim * sim;
+      w = (e == 0.0f) ? 1.0f : (float)exp((double)e);
+    } else {
+      w = 0.0f;
+    }
+    score *= w;
+    if (!a.soft && sim > a.iou_thr) return -INFINITY;
+    if (score <= a.score_thr) return -INFINITY;
+  }
+  return score;
+}
+
+// max of two keys over the block; results valid in every thread
+__device__ __forceinline__ void solo_max2(SoloLds& S, unsigned long long& v0, unsigned long long& v1) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o0 = __shfl_xor(v0, off, 64), o1 = __shfl_xor(v1, off, 64);
+    v0 = o0 > v0 ? o0 : v0;
+    v1 = o1 > v1 ? o1 : v1;
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { S.r0[threadIdx.x >> 6] = v0; S.r1[threadIdx.x >> 6] = v1; }
+  __syncthreads();
+  v0 = S.r0[0]; v1 = S.r1[0];
+#pragma unroll
+  for (int w = 1; w < SOLO_T / 64; ++w) {
+    v0 = S.r0[w] > v0 ? S.r0[w] : v0;
+    v1 = S.r1[w] > v1 ? S.r1[w] : v1;
+  }
+}
+
+__global__ __launch_bounds__(SOLO_T) void nms_solo_kernel(NmsArgs a, const float* scores) {
+  __shared__ SoloLds S;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const size_t base = (size_t)n * a.K;
+  const int img = n / a.segs;
+  const size_t bbase = (size_t)img * a.K;
+  const int NCH = (a.K + SOLO_T - 1) / SOLO_T;
+  // ---- initial state and chunk maxima
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int i = ch * SOLO_T + tid;
+    unsigned long long key = 0ull, dummy = 0ull;
+    if (i < a.K) {
+      const float s = scores[bbase + i];
+      const bool member = (a.segs == 1) || (a.classes[bbase + i] == n % a.segs);
+      const float v = (member && s > a.score_thr) ? s : -INFINITY;
+      a.stale[base + i] = v;
+      a.ub[base + i] = v;
+      a.ev[base + i] = -1;
+      a.begin[base + i] = 0;
+      if (v != -INFINITY) key = nms_key(v, i);
+    }
+    solo_max2(S, key, dummy);
+    if (tid == 0) { S.cub[ch] = key; S.cst[ch] = key; }
+  }
+  if (tid < a.M) {
+    a.sel_idx[(size_t)n * a.M + tid] = 0;
+    a.sel_score[(size_t)n * a.M + tid] = 0.f;
+  }
+  if (tid == 0) a.nsel[n] = 0;
+  __syncthreads();
+
+  for (int k = 0; k < a.M; ++k) {
+    // ---- search for the winner of epoch k
+    for (int ch = tid; ch < NCH; ch += SOLO_T) S.visited[ch] = 0;
+    if (tid == 0) S.L = 0ull;
+    __syncthreads();
+    // a first lower bound: the exact score of the candidate with the largest upper bound of all (its index is in the
+    // key), evaluated by wave 0 with the links spread over the lanes - otherwise the first visited chunk would have to
+    // evaluate every one of its candidates
+    if (tid < 64) {
+      unsigned long long bk = 0ull;
+      for (int ch = tid; ch < NCH; ch += 64) bk = S.cub[ch] > bk ? S.cub[ch] : bk;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long ok = __shfl_xor(bk, off, 64);
+        bk = ok > bk ? ok : bk;
+      }
+      if (bk != 0ull) {
+        const int i = (int)(0xFFFFFFFFu - (uint32_t)bk);
+        const int begin = a.begin[base + i];
+        const float4 b4 = *(const float4*)(a.boxes + (bbase + i) * 4);
+        const float bx[4] = {b4.x, b4.y, b4.z, b4.w};
+        const int nl = k - begin;
+        for (int s0 = 0; s0 < nl; s0 += 64) {
+          const int sl = s0 + tid;
+          if (sl < nl) {
+            const float sim = nms_iou(bx, S.sel + 4 * (k - 1 - sl));
+            float w;
+            if (a.soft || sim <= a.iou_thr) {
+              const float e = a.scale * sim * sim;
+              w = (e == 0.0f) ? 1.0f : (float)exp((double)e);
+            } else {
+              w = 0.0f;
+            }
+            if (!a.soft && sim > a.iou_thr) w = -2.0f;
+            S.wgt[sl] = w;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (tid == 0) {
+          float score = a.stale[base + i];
+          for (int sl = 0; sl < nl; ++sl) {
+            const float w = S.wgt[sl];
+            if (w == -2.0f) { score = -INFINITY; break; }
+            score *= w;
+            if (score <= a.score_thr) { score = -INFINITY; break; }
+          }
+          a.tent[base + i] = score;
+          a.ub[base + i] = score;
+          a.ev[base + i] = k;
+          if (score != -INFINITY) S.L = nms_key(score, i) - 1ull;   // "- 1": the candidate itself must still pass the > L tests below
+        }
+      }
+    }
+    __syncthreads();
+    while (true) {
+      if (tid < 64) {            // wave 0 picks the unvisited chunk with the largest upper bound above L
+        const unsigned long long L = S.L;
+        unsigned long long bk = 0ull;
+        int bc = -1;
+        for (int ch = tid; ch < NCH; ch += 64) {
+          const unsigned long long v = S.cub[ch];
+          if (!S.visited[ch] && v > L && v > bk) { bk = v; bc = ch; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          const unsigned long long ok = __shfl_xor(bk, off, 64);
+          const int oc = __shfl_xor(bc, off, 64);
+          if (ok > bk || (ok == bk && oc >= 0 && (bc < 0 || oc < bc))) { bk = ok; bc = oc; }
+        }
+        if (tid == 0) S.pick = bc;
+      }
+      __syncthreads();
+      const int ch = S.pick;
+      if (ch < 0) break;
+      const unsigned long long L = S.L;
+      const int i = ch * SOLO_T + tid;
+      unsigned long long ke = 0ull, ku = 0ull;
+      if (i < a.K) {
+        float u = a.ub[base + i];
+        if (u != -INFINITY && a.stale[base + i] != -INFINITY) {
+          if (nms_key(u, i) > L) {
+            float sc;
+            if (a.ev[base + i] == k) {
+              sc = a.tent[base + i];             // already exact in this epoch (the first bound candidate)
+            } else {
+              sc = solo_chain(a, S, base, bbase, i, k);
+              a.tent[base + i] = sc;
+              a.ub[base + i] = sc;
+              a.ev[base + i] = k;
+            }
+            u = sc;
+            if (sc != -INFINITY) ke = nms_key(sc, i);
+          }
+          if (u != -INFINITY) ku = nms_key(u, i);
+        }
+      }
+      solo_max2(S, ke, ku);
+      if (tid == 0) {
+        S.cub[ch] = ku;
+        S.visited[ch] = 1;
+        if (ke > S.L) S.L = ke;
+      }
+      __syncthreads();
+    }
+    const unsigned long long wk = S.L;
+    if (wk == 0ull) break;                       // no live candidate left: the remaining slots stay padded
+    const int widx = (int)(0xFFFFFFFFu - (uint32_t)wk);
+    const int wch = widx / SOLO_T;
+    // ---- pops and the winner
+    for (int ch = 0; ch < NCH; ++ch) {
+      if (!(S.cst[ch] > wk || ch == wch)) continue;     // uniform: LDS values written before the last barrier
+      const int i = ch * SOLO_T + tid;
+      unsigned long long ks = 0ull, ku = 0ull;
+      if (i < a.K) {
+        float st = a.stale[base + i];
+        if (st != -INFINITY) {
+          if (i == widx) {
+            const size_t o = (size_t)n * a.M + k;
+            const float ws = a.tent[base + i];
+            a.sel_idx[o] = i;
+            a.sel_score[o] = ws;
+            const float4 b4 = *(const float4*)(a.boxes + (bbase + i) * 4);
+            *(float4*)(a.sel_box + o * 4) = b4;
+            S.sel[4 * k + 0] = b4.x; S.sel[4 * k + 1] = b4.y; S.sel[4 * k + 2] = b4.z; S.sel[4 * k + 3] = b4.w;
+            a.stale[base + i] = -INFINITY;
+            a.nsel[n] = k + 1;
+            st = -INFINITY;
+          } else if (nms_key(st, i) > wk) {
+            float e;
+            if (a.ev[base + i] == k) {
+              e = a.tent[base + i];
+            } else {
+              e = solo_chain(a, S, base, bbase, i, k);
+              a.tent[base + i] = e;
+              a.ub[base + i] = e;
+              a.ev[base + i] = k;
+            }
+            a.stale[base + i] = e;
+            a.begin[base + i] = k;
+            st = e;
+          }
+          if (st != -INFINITY) {
+            ks = nms_key(st, i);
+            const float u = a.ub[base + i];
+            if (u != -INFINITY) ku = nms_key(u, i);
+          }
+        }
+      }
+      solo_max2(S, ks, ku);
+      if (tid == 0) { S.cst[ch] = ks; S.cub[ch] = ku; }
+      __syncthreads();
+    }
+    __syncthreads();
+  }
+}
+
+bool nms_solo_supported(const NmsArgs& a) { return a.K <= SOLO_T * SOLO_MAXCH && a.M <= 128; }
+
+void launch_nms_solo(const NmsArgs& a, const float* scores, hipStream_t s) {
+  if (a.n_img <= 0) return;
+  hipLaunchKernelGGL(nms_solo_kernel, dim3(a.n_img), dim3(SOLO_T), 0, s, a, scores);
+}
+
 // ------------------------------------------------------------------------------------ gather / pack
 __global__ __launch_bounds__(128) void gather_kernel(GatherArgs a) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;

@@ -222,6 +222,9 @@ struct NmsArgs {
 void launch_nms_init(const NmsArgs& a, const float* scores, hipStream_t s);
 void launch_nms_epoch(const NmsArgs& a, int epoch, hipStream_t s);
 void launch_nms_finish(const NmsArgs& a, int pad, hipStream_t s);
+// all epochs in one launch, one block per problem (kernels_post.hip "NMS, one launch")
+bool nms_solo_supported(const NmsArgs& a);
+void launch_nms_solo(const NmsArgs& a, const float* scores, hipStream_t s);
 
 struct GatherArgs {
   const int32_t* sel_idx;   // [n, M]
