@@ -221,6 +221,8 @@ def main():
                                    % (a.model, a.batch, a.image_size, a.samples, a.variant, a.classes),
                        "images_per_gpu": a.batch, "mc_samples": a.samples, "chunk_images": a.chunk,
                        "weights": "random init (reference initialisers), seed 0",
+                       "contraction": "float32 tensors and accumulators; 1x1 products as split-bf16 MFMA with %s cross terms "
+                                      "(UDA_PW_TERMS; 0 = exact f32-input MFMA)" % os.environ.get("UDA_PW_TERMS", "3"),
                        "sharding": "images across ranks, all-gather of detections"},
             "kernel_ms_per_step": {KIND_NAMES.get(k, str(k)): round(v[0], 2) for k, v in calib.items()},
             "h2d_upload_ms": round(upload_s * 1e3, 1),
