@@ -161,6 +161,10 @@ int uda_get_dropout_masks(uda_ctx_t* ctx, float* masks, int64_t n_floats);
  * handle's stream.  post_mode < 0 uses the model default; run_post == 0 stops after the heads. */
 int uda_run(uda_ctx_t* ctx, int32_t post_mode, int32_t run_post);
 int uda_synchronize(uda_ctx_t* ctx);
+/* Global NMS over the whole anchor set runs on the score prefix that can be selected at all, checked on the
+ * device; this counts the images / problems that failed the check and were redone on the full set (the results
+ * are identical either way). */
+int64_t uda_nms_prefix_fallbacks(const uda_ctx_t* ctx);
 
 /* Detections of the last uda_run (synchronises).  Shapes for n images, M = max_output_size:
  *   boxes   [n, M, box_cols]   box_cols = 4 (+4 aleatoric sigma)(+4 epistemic sigma)

@@ -165,6 +165,66 @@ def test_nms_kernel_bit_exact(n, tied, sigma, thr):
     d.close()
 
 
+@pytest.mark.parametrize("case", ["sparse", "dense", "all_tied", "identical_boxes", "threshold", "hard"])
+def test_nms_score_prefix_and_fallback(case):
+    """Candidate sets above 8192 run on their score prefix; when the device check rejects the prefix the problem is
+    redone on the full set.  Either way: bit-exact against the oracle's NonMaxSuppressionV5."""
+    from oracle import post_ref as P
+    p = make_params()
+    d = _driver(p, make_weights(p), 1)
+    rng = np.random.default_rng(len(case))
+    n_img, n = 3, 30000
+    sigma, thr = 0.25, 0.001
+    boxes = np.zeros((n_img, n, 4), np.float32)
+    scores = np.zeros((n_img, n), np.float32)
+    for i in range(n_img):
+        boxes[i], scores[i] = _rand_boxes(rng, n, span=40000.0 if case == "sparse" else 400.0, tied=(case == "dense"))
+    expect_fallback = None
+    if case == "sparse":
+        expect_fallback = 0                 # boxes hardly overlap: the 100 winners are the top scores
+    elif case == "all_tied":
+        scores[:] = 0.37                    # more exact ties than any prefix holds
+        expect_fallback = n_img
+    elif case == "identical_boxes":
+        boxes[:] = boxes[:, :1]             # every selection decays every other score: the winners fall below the cut
+        expect_fallback = n_img
+    elif case == "threshold":
+        sigma, thr = 0.0, 0.5               # hard NMS, half of the candidates above the threshold
+    elif case == "hard":
+        sigma, thr = 0.0, float("-inf")
+    before = d.nms_prefix_fallbacks()
+    idx, sc, valid = d.nms(boxes, scores, 100, 0.5, thr, sigma)
+    fell = d.nms_prefix_fallbacks() - before
+    for i in range(n_img):
+        ridx, rsc, rvalid = P.nms_v5(boxes[i], scores[i], 100, 0.5, thr, sigma, True)
+        assert valid[i] == rvalid
+        np.testing.assert_array_equal(idx[i], ridx)
+        np.testing.assert_array_equal(sc[i], rsc)
+    assert 0 <= fell <= n_img
+    if expect_fallback is not None:
+        assert fell == expect_fallback, (case, fell)
+    d.close()
+
+
+def test_postprocess_large_anchor_set_uses_prefix_and_matches_oracle():
+    """256x384 input: 18 414 candidates per image, so the global NMS takes the score-prefix path inside the serve
+    post-process; outputs must still equal the oracle's bit for bit."""
+    from oracle import post_ref as P, preprocess_ref as PP
+    p = make_params(image_size="384x256", **FULL_MC)
+    x, scales = PP.preprocess(make_images(2, 200, 360, seed=32), (256, 384), p["mean_rgb"], p["stddev_rgb"])
+    for seed, spread in ((31, 20.0), (33, 1.0)):     # spread-out scores / near-tied scores (plain random init)
+        w = make_weights(p, seed=seed, cls_spread=spread)
+        (rcls, rbox), _ = _oracle_net(p, w, x, 5)
+        want = P.postprocess_global(p, rcls, rbox, scales)
+        d = _driver(p, w, 2)
+        for rep in range(3):      # a rejected prefix pauses the prefix path for the following runs: same outputs
+            got = d.postprocess(rcls, rbox, scales)
+            for k, (g, r) in enumerate(zip(got, want)):
+                np.testing.assert_array_equal(g, r, err_msg="spread %g run %d output %d" % (spread, rep, k))
+        print("spread %g: %d image(s) redone on the full set" % (spread, d.nms_prefix_fallbacks()))
+        d.close()
+
+
 @pytest.mark.parametrize("name,over", [("plain", PLAIN), ("lossatt", LOSS_ATT), ("full_mc", FULL_MC),
                                        ("head_mc", HEAD_MC), ("mc_noatt", MC_NO_ATT), ("box_only", BOX_ONLY_MC)])
 def test_postprocess_bit_exact_on_oracle_heads(name, over):

@@ -1,0 +1,59 @@
+"""Side measurement for DESIGN.md section 5: global soft-NMS over the whole anchor set (K = 184 140 candidates per
+image) on a detector-like score distribution - a few objects with clusters of confident anchors, everything else
+background - where the score prefix is accepted by the device check.  Run twice, with UDA_NMS_PREFIX unset and
+UDA_NMS_PREFIX=0 (the environment is read once per process); prints the NMS time per batch (HIP events around the
+NMS launches, uploads excluded) and checks the first image against the CPU oracle."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def detector_like(rng, k, objects=20, per_object=40):
+    c = rng.uniform(0, 1, (k, 2)) * (768, 1280)
+    wh = rng.uniform(16, 400, (k, 2))
+    s = (10.0 ** rng.uniform(-4, -2, k)).astype(np.float32)
+    obj = rng.integers(0, k, objects)
+    for o in obj:
+        m = rng.integers(0, k, per_object)
+        c[m] = c[o] + rng.normal(0, 6, (per_object, 2))
+        wh[m] = wh[o] * rng.uniform(0.8, 1.25, (per_object, 2))
+        s[m] = rng.uniform(0.3, 0.95, per_object)
+    b = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+    return b, s
+
+
+def main():
+    from common import make_params, make_weights
+    from uda_amd.infer_lib import ServingDriver
+    from oracle import post_ref as P
+    n_img, k = 32, 184140
+    rng = np.random.default_rng(0)
+    boxes = np.zeros((n_img, k, 4), np.float32)
+    scores = np.zeros((n_img, k), np.float32)
+    for i in range(n_img):
+        boxes[i], scores[i] = detector_like(rng, k)
+    p = make_params()
+    d = ServingDriver("_", False, p["name"], batch_size=1, model_params=p, weights=make_weights(p))
+    d.profile_enable([17])
+    best = None
+    for rep in range(4):
+        idx, sc, valid = d.nms(boxes, scores, 100, 0.5, 0.001, 0.25)
+        ms, launches = d.profile_read(17)
+        if rep:
+            best = ms if best is None else min(best, ms)
+    ridx, rsc, rvalid = P.nms_v5(boxes[0], scores[0], 100, 0.5, 0.001, 0.25, True)
+    assert valid[0] == rvalid and (idx[0] == ridx).all() and (sc[0] == rsc).all()
+    print("UDA_NMS_PREFIX=%s: %d images x %d candidates, NMS %.3f ms per batch, %d problem(s) redone on the full set; "
+          "image 0 equals the oracle" % (os.environ.get("UDA_NMS_PREFIX", "(default 2048)"), n_img, k, best,
+                                         d.nms_prefix_fallbacks()))
+    d.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -78,6 +78,7 @@ _SIGNATURES = {
     "uda_get_dropout_masks": (C.c_int, [_P, _P, C.c_int64]),
     "uda_run": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "uda_synchronize": (C.c_int, [_P]),
+    "uda_nms_prefix_fallbacks": (C.c_int64, [_P]),
     "uda_get_detections": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "uda_detection_cols": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "uda_get_class_probs": (C.c_int, [_P, _P, _P]),

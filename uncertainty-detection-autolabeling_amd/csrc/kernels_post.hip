@@ -1039,6 +1039,433 @@ void launch_nms_solo(const NmsArgs& a, const float* scores, hipStream_t s) {
   hipLaunchKernelGGL(nms_solo_kernel, dim3(a.n_img), dim3(SOLO_T), 0, s, a, scores);
 }
 
+// ------------------------------------------------------------------------------------ NMS, one launch, state in registers
+// Problems of up to 8192 candidates (top-k / per-class paths, score prefixes): the same epoch rule with the whole
+// per-candidate state (stale score, cached exact score = upper bound, begin, epoch of the cached score, box) in the
+// registers of the thread that owns the candidate (candidate i = j * 1024 + tid), the selected boxes in LDS.  Nothing
+// is read from memory inside the epoch loop; an epoch costs three block reductions:
+//   1. the candidate with the largest upper bound takes its exact score (links spread over the lanes of wave 0)
+//      -> lower bound L on the winner;
+//   2. every candidate whose upper bound beats L takes its exact score (one thread each, in parallel); max -> winner;
+//   3. pops: every candidate whose STALE priority outranks the winner becomes exact (begin = k); the winner is recorded.
+// Bit-identical selections and scores to the grid version and to the reference's heap.
+struct RegLds {
+  float sel[4 * 128];
+  unsigned long long red[SOLO_T / 64];
+  float wgt[128];
+  unsigned long long L;
+  float pbox[4];
+  float pscore;
+  int pbegin;
+};
+
+__device__ __forceinline__ unsigned long long reg_max(RegLds& S, unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) S.red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  v = S.red[0];
+#pragma unroll
+  for (int w = 1; w < SOLO_T / 64; ++w) v = S.red[w] > v ? S.red[w] : v;
+  return v;
+}
+
+__device__ __forceinline__ float reg_chain(const NmsArgs& a, const RegLds& S, float score, int begin, const float* bx, int k) {
+  for (int j = k - 1; j >= begin; --j) {
+    const float sim = nms_iou(bx, S.sel + 4 * j);
+    float w;
+    if (a.soft || sim <= a.iou_thr) {
+      const float e = a.scale * sim * sim;
+      w = (e == 0.0f) ? 1.0f : (float)exp((double)e);
+    } else {
+      w = 0.0f;
+    }
+    score *= w;
+    if (!a.soft && sim > a.iou_thr) return -INFINITY;
+    if (score <= a.score_thr) return -INFINITY;
+  }
+  return score;
+}
+
+template <int IPT>
+__global__ __launch_bounds__(SOLO_T) void nms_reg_kernel(NmsArgs a, const float* scores) {
+  // more than four candidates per thread: the boxes live in (dynamic) LDS instead of registers, 16 B per candidate
+  constexpr bool BOXLDS = IPT > 4;
+  constexpr int NBX = BOXLDS ? 1 : IPT;
+  extern __shared__ float4 reg_boxes[];
+  __shared__ RegLds S;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int img = n / a.segs;
+  const size_t bbase = (size_t)img * a.K;
+  float st[IPT], ub[IPT], bx[NBX][4];
+  int be[IPT];                  // begin | (epoch of the cached exact score + 1) << 8
+#pragma unroll
+  for (int j = 0; j < IPT; ++j) {
+    const int i = j * SOLO_T + tid;
+    float v = -INFINITY;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < a.K) {
+      const float s = scores[bbase + i];
+      const bool member = (a.segs == 1) || (a.classes[bbase + i] == n % a.segs);
+      if (member && s > a.score_thr) v = s;
+      b4 = *(const float4*)(a.boxes + (bbase + i) * 4);
+    }
+    st[j] = v; ub[j] = v; be[j] = 0;
+    if constexpr (BOXLDS) {
+      reg_boxes[j * SOLO_T + tid] = b4;
+    } else {
+      bx[j][0] = b4.x; bx[j][1] = b4.y; bx[j][2] = b4.z; bx[j][3] = b4.w;
+    }
+  }
+  auto box_of = [&](int j, float* o) {
+    if constexpr (BOXLDS) {
+      const float4 b4 = reg_boxes[j * SOLO_T + tid];
+      o[0] = b4.x; o[1] = b4.y; o[2] = b4.z; o[3] = b4.w;
+    } else {
+      o[0] = bx[j][0]; o[1] = bx[j][1]; o[2] = bx[j][2]; o[3] = bx[j][3];
+    }
+  };
+  if (tid < a.M) {
+    a.sel_idx[(size_t)n * a.M + tid] = 0;
+    a.sel_score[(size_t)n * a.M + tid] = 0.f;
+  }
+  int nsel = 0;
+
+  for (int k = 0; k < a.M; ++k) {
+    // ---- 1. exact score of the candidate with the largest upper bound
+    unsigned long long bk = 0ull;
+#pragma unroll
+    for (int j = 0; j < IPT; ++j)
+      if (st[j] != -INFINITY && ub[j] != -INFINITY) {
+        const unsigned long long key = nms_key(ub[j], j * SOLO_T + tid);
+        bk = key > bk ? key : bk;
+      }
+    bk = reg_max(S, bk);
+    if (bk == 0ull) break;                 // nothing alive
+    const int bi = (int)(0xFFFFFFFFu - (uint32_t)bk);
+    const bool own = (bi % SOLO_T) == tid;
+    const int oj = bi / SOLO_T;
+#pragma unroll
+    for (int j = 0; j < IPT; ++j)
+      if (own && j == oj) {
+        float b[4];
+        box_of(j, b);
+        S.pbox[0] = b[0]; S.pbox[1] = b[1]; S.pbox[2] = b[2]; S.pbox[3] = b[3];
+        S.pscore = st[j];
+        S.pbegin = be[j] & 255;
+      }
+    __syncthreads();
+    if (tid < 64) {
+      const int begin = S.pbegin, nl = k - begin;
+      const float pb[4] = {S.pbox[0], S.pbox[1], S.pbox[2], S.pbox[3]};
+      for (int s0 = 0; s0 < nl; s0 += 64) {
+        const int sl = s0 + tid;
+        if (sl < nl) {
+          const float sim = nms_iou(pb, S.sel + 4 * (k - 1 - sl));
+          float w;
+          if (a.soft || sim <= a.iou_thr) {
+            const float e = a.scale * sim * sim;
+            w = (e == 0.0f) ? 1.0f : (float)exp((double)e);
+          } else {
+            w = 0.0f;
+          }
+          if (!a.soft && sim > a.iou_thr) w = -2.0f;
+          S.wgt[sl] = w;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (tid == 0) {
+        float score = S.pscore;
+        for (int sl = 0; sl < nl; ++sl) {
+          const float w = S.wgt[sl];
+          if (w == -2.0f) { score = -INFINITY; break; }
+          score *= w;
+          if (score <= a.score_thr) { score = -INFINITY; break; }
+        }
+        S.pscore = score;
+        S.L = (score != -INFINITY) ? nms_key(score, bi) - 1ull : 0ull;   // "- 1": the candidate itself passes the > L test
+      }
+    }
+    __syncthreads();
+    const unsigned long long L = S.L;
+    const float pscore = S.pscore;
+    // ---- 2. exact scores of everything that can still beat L
+    unsigned long long ke = 0ull;
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+      if (own && j == oj) { ub[j] = pscore; be[j] = (be[j] & 255) | ((k + 1) << 8); }
+      if (st[j] != -INFINITY && ub[j] != -INFINITY && nms_key(ub[j], j * SOLO_T + tid) > L) {
+        if ((be[j] >> 8) != k + 1) {
+          float b[4];
+          box_of(j, b);
+          ub[j] = reg_chain(a, S, st[j], be[j] & 255, b, k);
+          be[j] = (be[j] & 255) | ((k + 1) << 8);
+        }
+        if (ub[j] != -INFINITY) {
+          const unsigned long long key = nms_key(ub[j], j * SOLO_T + tid);
+          ke = key > ke ? key : ke;
+        }
+      }
+    }
+    const unsigned long long wk = reg_max(S, ke);
+    if (wk == 0ull) break;                 // no live candidate left: the remaining slots stay padded
+    const int widx = (int)(0xFFFFFFFFu - (uint32_t)wk);
+    // ---- 3. pops and the winner
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+      const int i = j * SOLO_T + tid;
+      if (st[j] == -INFINITY) continue;
+      if (i == widx) {
+        const size_t o = (size_t)n * a.M + k;
+        float b[4];
+        box_of(j, b);
+        a.sel_idx[o] = i;
+        a.sel_score[o] = ub[j];
+        *(float4*)(a.sel_box + o * 4) = make_float4(b[0], b[1], b[2], b[3]);
+        S.sel[4 * k + 0] = b[0]; S.sel[4 * k + 1] = b[1]; S.sel[4 * k + 2] = b[2]; S.sel[4 * k + 3] = b[3];
+        st[j] = -INFINITY;
+      } else if (nms_key(st[j], i) > wk) {
+        if ((be[j] >> 8) != k + 1) {
+          float b[4];
+          box_of(j, b);
+          ub[j] = reg_chain(a, S, st[j], be[j] & 255, b, k);
+        }
+        st[j] = ub[j];
+        be[j] = k | ((k + 1) << 8);
+      }
+    }
+    nsel = k + 1;
+    __syncthreads();
+  }
+  if (tid == 0) a.nsel[n] = nsel;
+}
+
+bool nms_reg_supported(const NmsArgs& a) { return a.K <= SOLO_T * 8 && a.M <= 128; }
+
+template <int IPT>
+static void launch_nms_reg_t(const NmsArgs& a, const float* scores, hipStream_t s) {
+  const size_t lds = IPT > 4 ? (size_t)IPT * SOLO_T * sizeof(float4) : 0;
+  if (lds > 48 * 1024) {
+    static bool opted = false;     // above the default limit the kernel needs an explicit opt-in
+    if (!opted) {
+      hipFuncSetAttribute((const void*)nms_reg_kernel<IPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      opted = true;
+    }
+  }
+  hipLaunchKernelGGL((nms_reg_kernel<IPT>), dim3(a.n_img), dim3(SOLO_T), lds, s, a, scores);
+}
+
+void launch_nms_reg(const NmsArgs& a, const float* scores, hipStream_t s) {
+  if (a.n_img <= 0) return;
+  if (a.K <= SOLO_T) launch_nms_reg_t<1>(a, scores, s);
+  else if (a.K <= 2 * SOLO_T) launch_nms_reg_t<2>(a, scores, s);
+  else if (a.K <= 3 * SOLO_T) launch_nms_reg_t<3>(a, scores, s);
+  else if (a.K <= 4 * SOLO_T) launch_nms_reg_t<4>(a, scores, s);
+  else if (a.K <= 6 * SOLO_T) launch_nms_reg_t<6>(a, scores, s);
+  else launch_nms_reg_t<8>(a, scores, s);
+}
+
+// ------------------------------------------------------------------------------------ NMS on a score prefix
+// With the whole anchor set as candidates (184 k per image) almost none can ever be selected: a candidate is popped
+// from the reference's heap only while its score is at least the score of the LAST box selected.  So the NMS is run
+// (single-launch kernel above) on the candidates whose score is >= tau, tau chosen so that 2048..4096 candidates pass,
+// kept in index order so that ties break exactly as in the full problem.  The result is the full problem's result iff
+// no excluded candidate could have been popped before the loop ended:
+//     max_out boxes selected : every excluded score <  the smallest selected (updated) score, or <= score_thresh
+//     fewer selected         : every excluded score <= score_thresh (excluded candidates never enter the heap)
+// prefix_check_kernel tests exactly that per image; images that fail are flagged and redone on the full set by the
+// host (uda_api.hip finish_post), so the output is bit-identical either way.
+constexpr int PFX_T = 1024;
+
+struct PfxLds {
+  unsigned hist[2048];
+  int wsum[17];
+  int bin, above, inbin;       // result of a digit selection
+  int wcnt[PFX_T / 64];
+  unsigned wex[PFX_T / 64];
+};
+
+// histogram of ((key >> shift) & (nb - 1)) over this block's candidates whose key matches `prefix` above hi_shift.
+// Scores cluster (random-init: every score ~ 0.01), so a bin shared by >= 16 lanes of a wave is added once.
+__device__ __forceinline__ void pfx_hist(const float* v, int K, uint32_t prefix, int hi_shift, int shift, int nb,
+                                         unsigned* hist) {
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < nb; i += PFX_T) hist[i] = 0;
+  __syncthreads();
+  const int Kr = (K + 63) & ~63;
+  for (int i = threadIdx.x; i < Kr; i += PFX_T) {
+    uint32_t bin = 0xFFFFFFFFu;
+    if (i < K) {
+      const uint32_t key = ord32(v[i]);
+      if (hi_shift >= 32 || (key >> hi_shift) == prefix) bin = (key >> shift) & (uint32_t)(nb - 1);
+    }
+    unsigned long long todo = __ballot(bin != 0xFFFFFFFFu);
+    if (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const uint32_t b = (uint32_t)__shfl((int)bin, leader, 64);
+      const unsigned long long same = __ballot(bin == b);
+      const int ns = __popcll(same);
+      if (ns >= 16) {
+        if (lane == leader) atomicAdd(&hist[b], (unsigned)ns);
+        if (bin == b) bin = 0xFFFFFFFFu;
+      }
+    }
+    if (bin != 0xFFFFFFFFu) atomicAdd(&hist[bin], 1u);
+  }
+  __syncthreads();
+}
+
+// the bin (from the top) in which the running count reaches `need`; S.above = count in the bins above it
+__device__ __forceinline__ void pfx_pick(PfxLds& S, int nb, int need) {
+  // thread t owns bins nb-1-2t and nb-2-2t (descending order)
+  const int hi = nb - 1 - 2 * (int)threadIdx.x, lo = hi - 1;
+  const int ch = hi >= 0 ? (int)S.hist[hi] : 0, cl = lo >= 0 ? (int)S.hist[lo] : 0;
+  int total;
+  const int excl = block_excl_scan(ch + cl, S.wsum, &total);
+  if (excl < need && need <= excl + ch + cl) {
+    if (excl + ch >= need) { S.bin = hi; S.above = excl; S.inbin = ch; }
+    else { S.bin = lo; S.above = excl + ch; S.inbin = cl; }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(PFX_T) void prefix_select_kernel(PrefixArgs a) {
+  __shared__ PfxLds S;
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* v = a.scores + (size_t)n * a.K;
+  const float* bx = a.boxes + (size_t)n * a.K * 4;
+  int32_t* sidx = a.sub_idx + (size_t)n * a.Lcap;
+  float* ssc = a.sub_scores + (size_t)n * a.Lcap;
+  float4* sbx = (float4*)(a.sub_boxes + (size_t)n * a.Lcap * 4);
+
+  // ---- tau: the coarsest key prefix with Lp <= #(key >= tau) <= Lcap
+  uint32_t tau;
+  bool ok = true;
+  pfx_hist(v, a.K, 0u, 32, 21, 2048, S.hist);
+  pfx_pick(S, 2048, a.Lp);
+  const int b1 = S.bin, above1 = S.above;
+  if (above1 + S.inbin <= a.Lcap) {
+    tau = (uint32_t)b1 << 21;
+  } else {
+    __syncthreads();
+    pfx_hist(v, a.K, (uint32_t)b1, 21, 10, 2048, S.hist);
+    pfx_pick(S, 2048, a.Lp - above1);
+    const int b2 = S.bin, above2 = above1 + S.above;
+    if (above2 + S.inbin <= a.Lcap) {
+      tau = ((uint32_t)b1 << 21) | ((uint32_t)b2 << 10);
+    } else {
+      __syncthreads();
+      pfx_hist(v, a.K, ((uint32_t)b1 << 11) | (uint32_t)b2, 10, 0, 1024, S.hist);
+      pfx_pick(S, 1024, a.Lp - above2);
+      tau = ((uint32_t)b1 << 21) | ((uint32_t)b2 << 10) | (uint32_t)S.bin;
+      ok = above2 + S.above + S.inbin <= a.Lcap;    // more exact ties than the prefix can hold: full problem
+    }
+  }
+  __syncthreads();
+
+  // ---- ordered compaction: wave w owns the contiguous slice [w * seg, (w + 1) * seg)
+  const int seg = ((a.K + (PFX_T / 64) - 1) / (PFX_T / 64) + 63) & ~63;
+  const int s0 = wave * seg, s1 = min(a.K, s0 + seg);
+  int cnt = 0;
+  uint32_t ex = 0u;                      // largest key among the excluded candidates (0 = none)
+  if (ok) {
+    for (int i = s0 + lane; i < s0 + seg; i += 64) {
+      uint32_t key = 0u;
+      if (i < s1) key = ord32(v[i]);
+      const bool take = (i < s1) && key >= tau;
+      cnt += __popcll(__ballot(take));
+      if (i < s1 && !take) ex = key > ex ? key : ex;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)ex, off, 64);
+    ex = o > ex ? o : ex;
+  }
+  if (lane == 0) { S.wcnt[wave] = cnt; S.wex[wave] = ex; }
+  __syncthreads();
+  int pos = 0, total = 0;
+  uint32_t exall = 0u;
+  for (int w = 0; w < PFX_T / 64; ++w) {
+    if (w < wave) pos += S.wcnt[w];
+    total += S.wcnt[w];
+    exall = S.wex[w] > exall ? S.wex[w] : exall;
+  }
+  if (ok && total > 0) {
+    for (int i = s0 + lane; i < s0 + seg; i += 64) {
+      float sc = 0.f;
+      bool take = false;
+      if (i < s1) {
+        sc = v[i];
+        take = ord32(sc) >= tau;
+      }
+      const unsigned long long m = __ballot(take);
+      if (m == 0ull) continue;
+      if (take) {
+        const int o = pos + __popcll(m & ((1ull << lane) - 1ull));
+        sidx[o] = i;
+        ssc[o] = sc;
+        sbx[o] = *(const float4*)(bx + (size_t)i * 4);
+      }
+      pos += __popcll(m);
+    }
+  }
+  if (!ok) total = 0;
+  for (int o = total + tid; o < a.Lcap; o += PFX_T) {     // padding: dead candidates
+    sidx[o] = 0;
+    ssc[o] = -INFINITY;
+    sbx[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (tid == 0) {
+    a.excl_key[n] = exall;
+    a.bad[n] = ok ? 0 : 1;
+  }
+}
+
+void launch_prefix_select(const PrefixArgs& a, hipStream_t s) {
+  if (a.n_img <= 0) return;
+  hipLaunchKernelGGL(prefix_select_kernel, dim3(a.n_img), dim3(PFX_T), 0, s, a);
+}
+
+// maps the prefix problem's selections back to candidate indices and checks that the prefix was sufficient
+__global__ __launch_bounds__(128) void prefix_check_kernel(PrefixCheckArgs a) {
+  __shared__ uint32_t wmin[128];
+  const int n = blockIdx.x, j = threadIdx.x;
+  const int ns = a.sub_nsel[n];
+  uint32_t key = 0xFFFFFFFFu;
+  if (j < a.M) {
+    const size_t o = (size_t)n * a.M + j;
+    const float sc = a.sub_sel_score[o];
+    a.sel_idx[o] = (j < ns) ? a.sub_idx[(size_t)n * a.Lcap + a.sub_sel_idx[o]] : 0;
+    a.sel_score[o] = sc;
+    if (j < ns) key = ord32(sc);
+  }
+  wmin[j] = key;
+  __syncthreads();
+  if (j == 0) {
+    uint32_t m = 0xFFFFFFFFu;
+    for (int t = 0; t < 128; ++t) m = wmin[t] < m ? wmin[t] : m;
+    const uint32_t ek = a.excl_key[n];
+    bool fine = true;
+    if (ek != 0u) {                      // something was excluded
+      const uint32_t eb = (ek & 0x80000000u) ? (ek ^ 0x80000000u) : ~ek;
+      const float es = __uint_as_float(eb);
+      fine = (es <= a.score_thr) || (ns == a.M && ek < m);
+    }
+    a.nsel[n] = ns;
+    if (!fine) a.bad[n] = 1;
+  }
+}
+
+void launch_prefix_check(const PrefixCheckArgs& a, hipStream_t s) {
+  if (a.n_img <= 0) return;
+  hipLaunchKernelGGL(prefix_check_kernel, dim3(a.n_img), dim3(128), 0, s, a);
+}
+
 // ------------------------------------------------------------------------------------ gather / pack
 __global__ __launch_bounds__(128) void gather_kernel(GatherArgs a) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;

@@ -101,6 +101,18 @@ struct uda_ctx {
     unsigned long long *bound = nullptr, *win = nullptr;
     bool ready = false;
   } ws[2];
+  // NMS on a score prefix (global mode with the whole anchor set as candidates): sub-problem arrays + workspace
+  struct PrefixWs {
+    int32_t *sub_idx = nullptr, *bad = nullptr;
+    float *sub_scores = nullptr, *sub_boxes = nullptr;
+    uint32_t* excl = nullptr;
+    NmsWs ws;
+    int Lcap = 0;
+  } pfx;
+  std::vector<std::pair<int, int>> pfx_pending;   // image ranges whose prefix flags the host has not looked at yet
+  bool pfx_off = false;                            // set while finish_post redoes rejected images
+  int64_t pfx_fallbacks = 0;                       // images redone on the full candidate set so far
+  int pfx_skip = 0, pfx_backoff = 0;               // runs left without the prefix / length of the last pause
   unsigned long long* d_merge_keys = nullptr;
   // outputs
   float *d_oboxes = nullptr, *d_oscores = nullptr, *d_oclasses = nullptr, *d_ologits = nullptr;
@@ -113,6 +125,8 @@ struct uda_ctx {
   uint32_t prof_mask = 0;
   ProfSlot prof[32];
 };
+
+static void free_prefix_ws(uda_ctx::PrefixWs& w);
 
 static int fail(uda_ctx* c, const char* fmt, ...) {
   char buf[1024];
@@ -196,6 +210,7 @@ extern "C" void uda_destroy(uda_ctx_t* c) {
                   c->d_oboxes, c->d_oscores, c->d_oclasses, c->d_ologits, c->d_ovalid, c->d_oprobs, c->d_oentropy};
   for (void* p : ptrs)
     if (p) hipFree(p);
+  free_prefix_ws(c->pfx);
   for (auto& w : c->ws) {
     void* wp[] = {w.stale, w.tent, w.ub, w.sel_score, w.sel_box, w.ev, w.begin, w.sel_idx, w.nsel, w.done, w.bound, w.win};
     for (void* p : wp)
@@ -242,6 +257,47 @@ static hipError_t alloc_nms_ws(uda_ctx::NmsWs& w, size_t problems, size_t K, siz
 #undef WS
   w.ready = true;
   return hipSuccess;
+}
+
+// UDA_NMS_SOLO = candidates per problem up to which the single-launch NMS kernel is used directly (0 = never)
+static int solo_limit() {
+  static int solo = -1;
+  if (solo < 0) { const char* e = getenv("UDA_NMS_SOLO"); solo = e ? atoi(e) : 8192; }
+  return solo;
+}
+
+// candidates passed on to the prefix NMS: at least UDA_NMS_PREFIX (default 2048, 0 = always the full set), at most twice that
+static int prefix_target() {
+  static int L = -1;
+  if (L < 0) {
+    const char* e = getenv("UDA_NMS_PREFIX");
+    L = e ? atoi(e) : 2048;
+    if (L < 0) L = 0;
+    if (L > 0 && L < 128) L = 128;
+    if (L > 4096) L = 4096;
+  }
+  return L;
+}
+
+static hipError_t alloc_prefix_ws(uda_ctx::PrefixWs& w, size_t problems, int Lcap, size_t M) {
+  if (w.Lcap) return hipSuccess;
+  hipError_t e;
+  if ((e = dalloc(&w.sub_idx, problems * Lcap)) != hipSuccess) return e;
+  if ((e = dalloc(&w.sub_scores, problems * Lcap)) != hipSuccess) return e;
+  if ((e = dalloc(&w.sub_boxes, problems * Lcap * 4)) != hipSuccess) return e;
+  if ((e = dalloc(&w.excl, problems)) != hipSuccess) return e;
+  if ((e = dalloc(&w.bad, problems)) != hipSuccess) return e;
+  if ((e = alloc_nms_ws(w.ws, problems, (size_t)Lcap, M)) != hipSuccess) return e;
+  w.Lcap = Lcap;
+  return hipSuccess;
+}
+
+static void free_prefix_ws(uda_ctx::PrefixWs& w) {
+  void* p[] = {w.sub_idx, w.sub_scores, w.sub_boxes, w.excl, w.bad, w.ws.stale, w.ws.tent, w.ws.ub, w.ws.sel_score, w.ws.sel_box,
+               w.ws.ev, w.ws.begin, w.ws.sel_idx, w.ws.nsel, w.ws.done, w.ws.bound, w.ws.win};
+  for (void* q : p)
+    if (q) hipFree(q);
+  w = uda_ctx::PrefixWs();
 }
 
 extern "C" int uda_detection_cols(const uda_ctx_t* c, int32_t post_mode, int32_t* box_cols, int32_t* cls_cols) {
@@ -493,6 +549,8 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
   if (m.has_uncert && m.loss_attenuation) CK(dalloc(&c->d_ual, N * K * 4));
   if (m.has_uncert && m.box_stacked) CK(dalloc(&c->d_uep, N * K * 4));
   CK(alloc_nms_ws(c->ws[0], N, K, M));
+  if (prefix_target() > 0 && (int)K > solo_limit() && K > (size_t)2 * prefix_target() && M <= 128)
+    CK(alloc_prefix_ws(c->pfx, N, 2 * prefix_target(), M));
   CK(dalloc(&c->d_oboxes, N * M * 12));
   CK(dalloc(&c->d_oscores, N * M));
   CK(dalloc(&c->d_oclasses, N * M * (1 + C)));
@@ -909,20 +967,52 @@ static int run_network(uda_ctx* c, int post_mode = 0, bool chunk_post = false) {
 }
 
 // ------------------------------------------------------------------------------------ post-process
-static void run_nms(const NmsArgs& na, const float* scores, int M, hipStream_t st) {
+static NmsArgs nms_args_at(uda_ctx::NmsWs& w, size_t p0, int problems, int K, int M, const float* boxes);
+
+// Returns true when the problems were solved on their score prefix (flags in pw->bad[p0 ..] say which ones have to be
+// redone on the full set, see finish_post); `pw` null = never.
+static bool run_nms(const NmsArgs& na, const float* scores, int M, hipStream_t st, uda_ctx::PrefixWs* pw = nullptr, size_t p0 = 0) {
   // One launch for all epochs (one block per problem) when a problem is small - the top-k / per-class paths with a
   // few thousand candidates each; with the whole anchor set as candidates (184 k near-tied scores under random-init
   // weights) an epoch revisits 10-20 chunks one after the other inside the block and the grid version, which scans
   // all chunks in parallel, is 4x faster (measured: 35 vs 7.9 ms for 32 images).  UDA_NMS_SOLO = candidates per
   // problem up to which the single-launch kernel is used (0 = never).
-  static int solo = -1;
-  if (solo < 0) { const char* e = getenv("UDA_NMS_SOLO"); solo = e ? atoi(e) : 8192; }
+  const int solo = solo_limit();
+  static int reg = -1;
+  if (reg < 0) { const char* e = getenv("UDA_NMS_REG"); reg = e ? atoi(e) : 1; }
+  if (na.K <= solo && reg && nms_reg_supported(na)) {
+    launch_nms_reg(na, scores, st);
+    return false;
+  }
   if (na.K <= solo && nms_solo_supported(na)) {
     launch_nms_solo(na, scores, st);
-    return;
+    return false;
+  }
+  // Large candidate sets: the single-launch kernel on the candidates that can be popped at all (score prefix), checked
+  // on the device, full set only for the problems the check rejects.
+  if (pw && pw->Lcap > 0 && na.segs == 1 && na.K > pw->Lcap && M <= 128) {
+    const size_t lc = (size_t)pw->Lcap;
+    PrefixArgs pa{};
+    pa.scores = scores; pa.boxes = na.boxes;
+    pa.sub_idx = pw->sub_idx + p0 * lc; pa.sub_scores = pw->sub_scores + p0 * lc; pa.sub_boxes = pw->sub_boxes + p0 * lc * 4;
+    pa.excl_key = pw->excl + p0; pa.bad = pw->bad + p0;
+    pa.n_img = na.n_img; pa.K = na.K; pa.Lp = pw->Lcap / 2; pa.Lcap = pw->Lcap;
+    launch_prefix_select(pa, st);
+    NmsArgs sub = nms_args_at(pw->ws, p0, na.n_img, pw->Lcap, M, pa.sub_boxes);
+    sub.iou_thr = na.iou_thr; sub.score_thr = na.score_thr; sub.soft = na.soft; sub.scale = na.scale;
+    if (reg && nms_reg_supported(sub)) launch_nms_reg(sub, pa.sub_scores, st);
+    else launch_nms_solo(sub, pa.sub_scores, st);
+    PrefixCheckArgs ca{};
+    ca.sub_sel_idx = sub.sel_idx; ca.sub_sel_score = sub.sel_score; ca.sub_nsel = sub.nsel;
+    ca.sub_idx = pa.sub_idx; ca.excl_key = pa.excl_key;
+    ca.sel_idx = na.sel_idx; ca.sel_score = na.sel_score; ca.nsel = na.nsel; ca.bad = pa.bad;
+    ca.n_img = na.n_img; ca.M = M; ca.Lcap = pw->Lcap; ca.score_thr = na.score_thr;
+    launch_prefix_check(ca, st);
+    return true;
   }
   launch_nms_init(na, scores, st);
   for (int e = 0; e < M; ++e) launch_nms_epoch(na, e, st);
+  return false;
 }
 
 static void nms_params(NmsArgs& a, float iou_thr, float score_thr, float soft_sigma) {
@@ -988,7 +1078,7 @@ static NmsArgs nms_args_at(uda_ctx::NmsWs& w, size_t p0, int problems, int K, in
 
 static int run_post_global(uda_ctx* c, int i0, int n, hipStream_t st) {
   const uda_model_t& m = c->model;
-  int rc = run_candidates(c, i0, n, st);
+  int rc = c->pfx_off ? 0 : run_candidates(c, i0, n, st);    // a redo (finish_post) finds the candidates in place
   if (rc) return rc;
   const int K = c->Kc, M = m.max_output_size;
   const size_t k = (size_t)K, mm = (size_t)M, C = (size_t)m.num_classes;
@@ -997,7 +1087,9 @@ static int run_post_global(uda_ctx* c, int i0, int n, hipStream_t st) {
     ProfScope ps(c, 17, st);
     NmsArgs na = nms_args_at(c->ws[0], (size_t)i0, n, K, M, c->d_cboxes + (size_t)i0 * k * 4);
     nms_params(na, m.nms_iou_thresh, m.nms_score_thresh, m.nms_soft_sigma);
-    run_nms(na, c->d_cscores + (size_t)i0 * k, M, st);
+    const bool try_prefix = !c->pfx_off && c->pfx_skip == 0;
+    if (run_nms(na, c->d_cscores + (size_t)i0 * k, M, st, try_prefix ? &c->pfx : nullptr, (size_t)i0))
+      c->pfx_pending.push_back({i0, n});
   }
   GatherArgs g{};
   g.box_cols = box_cols_of(m, UDA_POST_GLOBAL);
@@ -1066,23 +1158,64 @@ static int run_post(uda_ctx* c, int n, int post_mode) {
   const int pm = post_mode < 0 ? c->model.post_mode : post_mode;
   int rc = prepare_post(c, pm);
   if (rc) return rc;
+  c->pfx_pending.clear();
   rc = run_post_range(c, 0, n, pm, c->stream);
+  if (c->pfx_skip > 0 && c->pfx_pending.empty()) --c->pfx_skip;
   if (rc) return rc;
   c->last_post_mode = pm;
   c->last_n = n;
   return 0;
 }
 
+// Every reader of the post-process outputs comes through here: images whose score prefix turned out not to be
+// sufficient (flag written by prefix_check_kernel) are redone on the full candidate set before anything is read.
+static int finish_post(uda_ctx* c) {
+  if (c->pfx_pending.empty()) return 0;
+  HIPC(c, hipStreamSynchronize(c->stream));
+  std::vector<std::pair<int, int>> pend;
+  pend.swap(c->pfx_pending);
+  std::vector<int32_t> bad((size_t)c->model.max_images, 0);
+  for (const auto& r : pend)
+    HIPC(c, hipMemcpy(bad.data() + r.first, c->pfx.bad + r.first, (size_t)r.second * sizeof(int32_t), hipMemcpyDeviceToHost));
+  int rc = 0, n_bad = 0, n_all = 0;
+  c->pfx_off = true;
+  for (const auto& r : pend) {
+    n_all += r.second;
+    for (int i = r.first; i < r.first + r.second && !rc;) {
+      if (!bad[(size_t)i]) { ++i; continue; }
+      int j = i;
+      while (j < r.first + r.second && bad[(size_t)j]) ++j;    // a run of rejected images: one batched pass
+      rc = run_post_global(c, i, j - i, c->stream);
+      n_bad += j - i;
+      i = j;
+    }
+  }
+  c->pfx_off = false;
+  c->pfx_fallbacks += n_bad;
+  // Score distributions in which most of the anchor set stays in play (near-tied scores of an untrained head) gain
+  // nothing from the prefix: pause it for 32, 64, ... 1024 runs, then probe again.
+  if (2 * n_bad > n_all) {
+    c->pfx_backoff = c->pfx_backoff ? (c->pfx_backoff < 1024 ? 2 * c->pfx_backoff : 1024) : 32;
+    c->pfx_skip = c->pfx_backoff;
+  } else {
+    c->pfx_backoff = 0;
+  }
+  return rc;
+}
+
 extern "C" int uda_run(uda_ctx_t* c, int32_t post_mode, int32_t do_post) {
   if (!c) return 1;
   if (c->n_images < 1) return fail(c, "uda_run: no images set");
   HIPC(c, hipSetDevice(c->device));
+  c->pfx_pending.clear();
   if (do_post && c->post_overlap) {
     const int pm = post_mode < 0 ? c->model.post_mode : post_mode;
     if (pm != UDA_POST_GLOBAL && pm != UDA_POST_PER_CLASS) return fail(c, "unknown post mode %d", pm);
     int rc = prepare_post(c, pm);
     if (rc) return rc;
-    return run_network(c, pm, true);
+    rc = run_network(c, pm, true);
+    if (!rc && c->pfx_skip > 0 && c->pfx_pending.empty()) --c->pfx_skip;
+    return rc;
   }
   int rc = run_network(c);
   if (rc) return rc;
@@ -1090,9 +1223,12 @@ extern "C" int uda_run(uda_ctx_t* c, int32_t post_mode, int32_t do_post) {
   return rc;
 }
 
+extern "C" int64_t uda_nms_prefix_fallbacks(const uda_ctx_t* c) { return c ? c->pfx_fallbacks : -1; }
+
 extern "C" int uda_synchronize(uda_ctx_t* c) {
   if (!c) return 1;
   HIPC(c, hipSetDevice(c->device));
+  if (int rc = finish_post(c)) return rc;
   HIPC(c, hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -1101,6 +1237,7 @@ extern "C" int uda_get_detections(uda_ctx_t* c, float* boxes, float* scores, flo
                                   int32_t* valid, float* logits) {
   if (!c) return 1;
   HIPC(c, hipSetDevice(c->device));
+  if (int rc = finish_post(c)) return rc;
   HIPC(c, hipStreamSynchronize(c->stream));
   const size_t n = c->last_n, M = c->model.max_output_size, C = c->model.num_classes;
   const int bc = box_cols_of(c->model, c->last_post_mode), cc = cls_cols_of(c->model, c->last_post_mode);
@@ -1117,6 +1254,7 @@ extern "C" int uda_get_class_probs(uda_ctx_t* c, float* probs, float* entropy) {
   if (!c || !probs || !entropy) return c ? fail(c, "get_class_probs: NULL argument") : 1;
   if (c->last_post_mode != UDA_POST_GLOBAL) return fail(c, "get_class_probs: logits exist only after the global post-process");
   HIPC(c, hipSetDevice(c->device));
+  if (int rc = finish_post(c)) return rc;
   const size_t n = c->last_n, M = c->model.max_output_size, C = c->model.num_classes;
   if (!c->d_oprobs) {
     const size_t N = (size_t)c->model.max_images;
@@ -1145,6 +1283,7 @@ extern "C" int uda_calibrate_box(uda_ctx_t* c, int32_t col0, int32_t mode, int32
   if (iso && (n_tables != want || !tab_off || !xs || !ys))
     return fail(c, "calibrate_box: mode %d needs %d tables, got %d", mode, want, n_tables);
   HIPC(c, hipSetDevice(c->device));
+  if (int rc = finish_post(c)) return rc;
   CalibArgs a{};
   double *d_xs = nullptr, *d_ys = nullptr;
   int32_t* d_off = nullptr;
@@ -1345,10 +1484,35 @@ extern "C" int uda_nms(uda_ctx_t* c, const float* boxes, const float* scores, in
   a.nsel = d_nsel; a.done = d_done; a.n_img = n_img; a.K = k; a.M = max_out;
   a.segs = 1; a.classes = nullptr;
   nms_params(a, iou_thresh, score_thresh, soft_sigma);
-  if (k > 0) run_nms(a, d_scores, max_out, c->stream);
-  else launch_nms_init(a, d_scores, c->stream);
+  uda_ctx::PrefixWs pw;
+  const int lp = prefix_target();
+  if (lp > 0 && k > solo_limit() && k > 2 * lp) HIPC(c, alloc_prefix_ws(pw, (size_t)n_img, 2 * lp, (size_t)max_out));
+  bool prefix = false;
+  {
+    ProfScope ps(c, 17);
+    if (k > 0) prefix = run_nms(a, d_scores, max_out, c->stream, pw.Lcap ? &pw : nullptr, 0);
+    else launch_nms_init(a, d_scores, c->stream);
+  }
   HIPC(c, hipStreamSynchronize(c->stream));
   HIPC(c, hipGetLastError());
+  if (prefix) {            // problems whose prefix was not sufficient: the full candidate set, one problem at a time
+    std::vector<int32_t> bad((size_t)n_img);
+    HIPC(c, hipMemcpy(bad.data(), pw.bad, (size_t)n_img * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int p = 0; p < n_img; ++p) {
+      if (!bad[(size_t)p]) continue;
+      const size_t pk = (size_t)p * k, pm = (size_t)p * max_out;
+      NmsArgs f = a;
+      f.boxes = d_boxes + pk * 4; f.stale = d_stale + pk; f.begin = d_begin + pk; f.tent = d_tent + pk; f.ub = d_ub + pk; f.ev = d_ev + pk;
+      f.sel_idx = d_si + pm; f.sel_score = d_ss + pm; f.sel_box = d_sb + pm * 4; f.bound_key = d_bound + pm; f.win_key = d_win + pm;
+      f.nsel = d_nsel + p; f.done = d_done + p; f.n_img = 1;
+      ProfScope ps(c, 17);
+      run_nms(f, d_scores + pk, max_out, c->stream);
+      ++c->pfx_fallbacks;
+    }
+    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipGetLastError());
+  }
+  free_prefix_ws(pw);
   HIPC(c, hipMemcpy(valid, d_nsel, n_img * sizeof(int32_t), hipMemcpyDeviceToHost));
   HIPC(c, hipMemcpy(idx, d_si, NM * sizeof(int32_t), hipMemcpyDeviceToHost));
   HIPC(c, hipMemcpy(out_scores, d_ss, NM * sizeof(float), hipMemcpyDeviceToHost));

@@ -225,6 +225,36 @@ void launch_nms_finish(const NmsArgs& a, int pad, hipStream_t s);
 // all epochs in one launch, one block per problem (kernels_post.hip "NMS, one launch")
 bool nms_solo_supported(const NmsArgs& a);
 void launch_nms_solo(const NmsArgs& a, const float* scores, hipStream_t s);
+// the same with the per-candidate state in registers, problems of up to 8192 candidates
+bool nms_reg_supported(const NmsArgs& a);
+void launch_nms_reg(const NmsArgs& a, const float* scores, hipStream_t s);
+
+// NMS on the top-scoring prefix of a large candidate set (kernels_post.hip "NMS on a score prefix")
+struct PrefixArgs {
+  const float* scores;   // [n, K]
+  const float* boxes;    // [n, K, 4]
+  int32_t* sub_idx;      // [n, Lcap]  candidate index of every prefix entry, ascending
+  float* sub_scores;     // [n, Lcap]  (-inf padding)
+  float* sub_boxes;      // [n, Lcap, 4]
+  uint32_t* excl_key;    // [n]  order-preserving key of the largest excluded score (0 = nothing excluded)
+  int32_t* bad;          // [n]  1 = the prefix cannot stand in for the full problem
+  int n_img, K, Lp, Lcap;
+};
+void launch_prefix_select(const PrefixArgs& a, hipStream_t s);
+struct PrefixCheckArgs {
+  const int32_t* sub_sel_idx;   // [n, M] positions in the prefix
+  const float* sub_sel_score;   // [n, M]
+  const int32_t* sub_nsel;      // [n]
+  const int32_t* sub_idx;       // [n, Lcap]
+  const uint32_t* excl_key;     // [n]
+  int32_t* sel_idx;             // [n, M] candidate indices (what the gather stage reads)
+  float* sel_score;             // [n, M]
+  int32_t* nsel;                // [n]
+  int32_t* bad;                 // [n]
+  int n_img, M, Lcap;
+  float score_thr;
+};
+void launch_prefix_check(const PrefixCheckArgs& a, hipStream_t s);
 
 struct GatherArgs {
   const int32_t* sel_idx;   // [n, M]

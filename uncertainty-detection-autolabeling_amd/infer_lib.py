@@ -336,6 +336,11 @@ class ServingDriver:
                                    soft_sigma, int(pad), _ptr(idx), _ptr(sc), _ptr(valid)), "uda_nms")
         return idx, sc, valid
 
+    def nms_prefix_fallbacks(self):
+        """Images / NMS problems so far whose score prefix failed the device check and were redone on the full
+        candidate set (identical results either way; include/uda_hip.h uda_nms_prefix_fallbacks)."""
+        return int(self._lib.uda_nms_prefix_fallbacks(self._h))
+
     # ------------------------------------------------------------------ resident-input fast path (bench)
     def stage_images(self, image_arrays):
         """Upload uint8 images once (the PCIe leg); `run_resident` then re-runs the path on them."""
