@@ -564,6 +564,56 @@ def test_fallback_paths_stay_parity_green(env):
     assert r.returncode == 0 and "smoke ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
+NMS_WORKER = r"""
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import numpy as np
+from common import make_params, make_weights
+from uda_amd.infer_lib import ServingDriver
+from oracle import post_ref as P
+p = make_params()
+d = ServingDriver("_", False, p["name"], batch_size=4, model_params=p, weights=make_weights(p))
+rng = np.random.default_rng(7)
+for n, tied, sigma, thr in ((70000, True, 0.25, 0.001), (70000, False, 0.25, 0.001), (40000, False, 0.0, 0.3),
+                            (3000, True, 0.25, 0.001), (6000, False, 0.5, 0.2)):
+    boxes = np.zeros((3, n, 4), np.float32); scores = np.zeros((3, n), np.float32)
+    for i in range(3):
+        c = rng.uniform(0, 600.0, (n, 2)); wh = rng.uniform(4, 120, (n, 2))
+        boxes[i] = np.concatenate([c - wh / 2, c + wh / 2], 1)
+        if tied:
+            scores[i] = 0.01 + rng.normal(0, 1e-4, n)
+            scores[i, rng.integers(0, n, n // 8)] = scores[i, 0]
+        else:
+            scores[i] = rng.uniform(0, 1, n)
+    idx, sc, valid = d.nms(boxes, scores, 100, 0.5, thr, sigma)
+    for i in range(3):
+        ridx, rsc, rvalid = P.nms_v5(boxes[i], scores[i], 100, 0.5, thr, sigma, True)
+        assert valid[i] == rvalid, (n, tied, i, valid[i], rvalid)
+        assert (idx[i] == ridx).all() and (sc[i] == rsc).all(), (n, tied, i)
+print("nms paths ok, redone", d.nms_prefix_fallbacks())
+d.close()
+"""
+
+
+@pytest.mark.parametrize("env", [dict(UDA_NMS_PREFIX="0"), dict(UDA_NMS_PREFIX="0", UDA_NMS_COOP="0"), dict(UDA_NMS_REG="0"),
+                                 dict()],
+                         ids=["cooperative", "two-launches-per-epoch", "global-state-solo", "default"])
+def test_nms_paths_bit_exact(env):
+    """Every NMS execution path - score prefix + register kernel (default), the cooperative single launch over several
+    blocks per problem, the two-launches-per-epoch grid version, the earlier single-launch kernel - against the
+    oracle's NonMaxSuppressionV5 on 70 000 / 40 000 / 6 000 / 3 000 candidates (near-tied and uniform scores, soft and hard).
+    The switches are read once per process, so each configuration runs in its own interpreter."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", NMS_WORKER % {"root": root}], cwd=root, env=e, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "nms paths ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_box_uncertainty_calibration_matches_reference_restatement():
     """SURVEY 8f.2 on the device: every calibrate_boxuncert method on the selected rows against the numpy restatement."""
     from oracle import calib_ref as CR

@@ -1050,7 +1050,7 @@ void launch_nms_solo(const NmsArgs& a, const float* scores, hipStream_t s) {
 //   3. pops: every candidate whose STALE priority outranks the winner becomes exact (begin = k); the winner is recorded.
 // Bit-identical selections and scores to the grid version and to the reference's heap.
 struct RegLds {
-  float sel[4 * 128];
+  alignas(16) float sel[4 * 128];
   unsigned long long red[SOLO_T / 64];
   float wgt[128];
   unsigned long long L;
@@ -1074,19 +1074,43 @@ __device__ __forceinline__ unsigned long long reg_max(RegLds& S, unsigned long l
   return v;
 }
 
+// Pending chain of one candidate: links k-1 .. begin, newest first.  Most links are no-ops - a selected box that does not
+// strictly overlap the candidate has IoU 0, weight exactly 1.0f - so the chain runs in two passes: a cheap interval test
+// over all links that leaves a bit mask of the overlapping ones, then IoU + exp + multiply (the reference's order and
+// early exits) over the set bits only.  Lanes of a wave then diverge over a handful of expensive links instead of
+// paying the double-precision exp at nearly every one of up to 100 links.
 __device__ __forceinline__ float reg_chain(const NmsArgs& a, const RegLds& S, float score, int begin, const float* bx, int k) {
-  for (int j = k - 1; j >= begin; --j) {
-    const float sim = nms_iou(bx, S.sel + 4 * j);
-    float w;
-    if (a.soft || sim <= a.iou_thr) {
-      const float e = a.scale * sim * sim;
-      w = (e == 0.0f) ? 1.0f : (float)exp((double)e);
-    } else {
-      w = 0.0f;
+  unsigned long long m[2] = {0ull, 0ull};       // links 0..63 / 64..127
+  if (a.soft || a.iou_thr >= 0.f) {
+    const float y0 = fminf(bx[0], bx[2]), x0 = fminf(bx[1], bx[3]), y1 = fmaxf(bx[0], bx[2]), x1 = fmaxf(bx[1], bx[3]);
+    for (int j = begin; j < k; ++j) {
+      const float4 sb = *(const float4*)(S.sel + 4 * j);
+      const float sy0 = fminf(sb.x, sb.z), sx0 = fminf(sb.y, sb.w), sy1 = fmaxf(sb.x, sb.z), sx1 = fmaxf(sb.y, sb.w);
+      const bool ov = (fminf(y1, sy1) > fmaxf(y0, sy0)) && (fminf(x1, sx1) > fmaxf(x0, sx0));
+      if (ov) m[j >> 6] |= 1ull << (j & 63);
     }
-    score *= w;
-    if (!a.soft && sim > a.iou_thr) return -INFINITY;
-    if (score <= a.score_thr) return -INFINITY;
+  } else {                                        // (negative hard threshold: IoU 0 suppresses too - no link can be skipped)
+    for (int j = begin; j < k; ++j) m[j >> 6] |= 1ull << (j & 63);
+  }
+#pragma unroll
+  for (int h = 1; h >= 0; --h) {
+    unsigned long long mm = m[h];
+    while (mm) {
+      const int bit = 63 - __clzll((long long)mm);
+      mm &= ~(1ull << bit);
+      const int j = h * 64 + bit;
+      const float sim = nms_iou(bx, S.sel + 4 * j);
+      float w;
+      if (a.soft || sim <= a.iou_thr) {
+        const float e = a.scale * sim * sim;
+        w = (e == 0.0f) ? 1.0f : (float)exp((double)e);
+      } else {
+        w = 0.0f;
+      }
+      score *= w;
+      if (!a.soft && sim > a.iou_thr) return -INFINITY;
+      if (score <= a.score_thr) return -INFINITY;
+    }
   }
   return score;
 }
@@ -1267,6 +1291,320 @@ void launch_nms_reg(const NmsArgs& a, const float* scores, hipStream_t s) {
   else if (a.K <= 4 * SOLO_T) launch_nms_reg_t<4>(a, scores, s);
   else if (a.K <= 6 * SOLO_T) launch_nms_reg_t<6>(a, scores, s);
   else launch_nms_reg_t<8>(a, scores, s);
+}
+
+// ------------------------------------------------------------------------------------ NMS, one cooperative launch
+// The whole anchor set (184 k candidates per image) in ONE launch for all epochs: a problem is spread over `bpi`
+// blocks of 1024 threads, each thread keeps the state of IPT candidates in registers (as in nms_reg_kernel; boxes are
+// fetched from the candidate table when a chain is evaluated), and the two grid-wide dependencies of an epoch - the
+// lower bound and the winner, both atomicMax on per-epoch slots - are crossed with a per-image barrier (a monotonic
+// counter in memory) instead of a kernel boundary.  The grid version pays a chain of dependent global loads per
+// launch (state re-read from memory, 2 launches x 100 epochs); here only the two barriers remain on the critical path.
+// All blocks must be co-resident: launched with hipLaunchCooperativeKernel, which refuses grids that are not, and the
+// spin is bounded (error flag -> every block falls through to the end), so the grid always drains.
+//   A  every block: exact score of its best candidate by upper bound (wave 0) -> atomicMax(bound[k])   | barrier
+//   B  every candidate whose upper bound reaches bound[k]: exact score -> atomicMax(win[k])            | barrier
+//   C  pops (stale priority above the winner -> exact, begin = k); the winner's owner records it.
+__device__ __forceinline__ void coop_barrier(unsigned* ctr, unsigned target, int* err) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    atomicAdd(ctr, 1u);
+    unsigned spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 22)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+    __threadfence();
+  }
+  __syncthreads();
+}
+
+__device__ unsigned long long g_nms_dbg[8];
+__device__ unsigned long long g_nms_dbg2[2];
+#ifdef UDA_NMS_STATS
+#define NMS_STAT(slot, v) atomicAdd(&g_nms_dbg[slot], (unsigned long long)(v))
+#else
+#define NMS_STAT(slot, v)
+#endif
+
+__device__ __forceinline__ float coop_chain(const NmsArgs& a, const RegLds& S, float score, int begin, size_t bidx, int k) {
+  NMS_STAT(0, 1); NMS_STAT(1, k - begin); if (k - begin >= 16) NMS_STAT(2, 1); if (k - begin >= 48) NMS_STAT(3, 1);
+  if (k <= begin) return score;
+  const float4 b4 = *(const float4*)(a.boxes + bidx * 4);
+  const float bx[4] = {b4.x, b4.y, b4.z, b4.w};
+  return reg_chain(a, S, score, begin, bx, k);
+}
+
+template <int IPT>
+__global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float* scores, unsigned* bar, int* err, int bpi) {
+  // Per candidate: the stale score in a register of its thread (scanned every epoch, candidate i0 + j * 1024 + tid), the
+  // cached exact score / upper bound in LDS (scanned every epoch, 128 KB), begin / epoch / a copy of the stale score in
+  // the workspace arrays in memory (touched only when a chain is evaluated, together with the candidate's box).
+  extern __shared__ float U[];                    // [IPT * 1024]
+  __shared__ RegLds S;
+  const int n = blockIdx.x / bpi, blk = blockIdx.x % bpi, tid = threadIdx.x;
+  const size_t bbase = (size_t)n * a.K;           // one problem per image (segs == 1)
+  const int i0 = blk * IPT * SOLO_T;
+  unsigned* ctr = bar + n;
+  unsigned long long* bound = a.bound_key + (size_t)n * a.M;
+  unsigned long long* win = a.win_key + (size_t)n * a.M;
+  float st[IPT];
+#pragma unroll
+  for (int j = 0; j < IPT; ++j) {
+    const int i = i0 + j * SOLO_T + tid;
+    float v = -INFINITY;
+    if (i < a.K) {
+      const float s = scores[bbase + i];
+      if (s > a.score_thr) v = s;
+      a.stale[bbase + i] = v;
+      a.begin[bbase + i] = 0;
+    }
+    st[j] = v;
+    U[j * SOLO_T + tid] = v;
+  }
+  if (blk == 0 && tid < a.M) {
+    a.sel_idx[(size_t)n * a.M + tid] = 0;
+    a.sel_score[(size_t)n * a.M + tid] = 0.f;
+  }
+  int nsel = 0;
+  unsigned phase = 0;
+  __syncthreads();
+
+  // exact score of candidate i in epoch k (links begin .. k-1, newest first); records it as the cached score.  Which
+  // candidates are already exact in this epoch is kept in a per-thread bit mask (`done`) plus the one candidate wave 0
+  // evaluated in step A (S.pbegin), so nothing but stale / begin / box - one round trip, in parallel - comes from memory
+  unsigned done = 0u;
+  auto evaluate = [&](int i, int j, int k) -> float {
+    const size_t g = bbase + i;
+    float v;
+    if (((done >> j) & 1u) || i == S.pbegin) {
+      v = U[i - i0];
+    } else {
+      v = coop_chain(a, S, a.stale[g], a.begin[g], g, k);
+      U[i - i0] = v;
+    }
+    done |= 1u << j;
+    return v;
+  };
+
+  for (int k = 0; k < a.M; ++k) {
+    // (the candidate index is rebuilt from an opaque base in every epoch: otherwise the per-candidate index words and
+    // addresses of all IPT candidates are hoisted out of the epoch loop and spill)
+    int ib = i0 + tid;
+    asm volatile("" : "+v"(ib));
+#ifdef UDA_NMS_STATS
+    const unsigned long long t0 = wall_clock64();
+#endif
+    // ---- A. this block's best candidate by upper bound takes its exact score -> lower bound on the winner.  Scores
+    // first, the index only for the best one: max over j of (ordered score, smaller j) is max over the keys
+    unsigned long long bk = 0ull;
+    {
+      uint32_t bo = 0u;
+      int bj = 0;
+#pragma unroll
+      for (int j = IPT - 1; j >= 0; --j) {
+        const float u = U[j * SOLO_T + tid];
+        if (st[j] != -INFINITY && u != -INFINITY) {
+          const uint32_t o = ord32(u);
+          if (o >= bo) { bo = o; bj = j; }      // descending j with >=: the smallest index wins a tie
+        }
+      }
+      if (bo != 0u) bk = ((unsigned long long)bo << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)(ib + bj * SOLO_T));
+    }
+    bk = reg_max(S, bk);
+    done = 0u;
+    if (tid == 0) S.pbegin = -1;             // (candidate index of step A's exact score, -1 = none)
+    if (bk != 0ull && tid < 64) {
+      const int bi = (int)(0xFFFFFFFFu - (uint32_t)bk);
+      const size_t g = bbase + bi;
+      const int begin = a.begin[g], nl = k - begin;
+      const float stale0 = a.stale[g];
+      const float4 b4 = *(const float4*)(a.boxes + g * 4);
+      const float pb[4] = {b4.x, b4.y, b4.z, b4.w};
+      for (int s0 = 0; s0 < nl; s0 += 64) {
+        const int sl = s0 + tid;
+        if (sl < nl) {
+          const float sim = nms_iou(pb, S.sel + 4 * (k - 1 - sl));
+          float w;
+          if (a.soft || sim <= a.iou_thr) {
+            const float e = a.scale * sim * sim;
+            w = (e == 0.0f) ? 1.0f : (float)exp((double)e);
+          } else {
+            w = 0.0f;
+          }
+          if (!a.soft && sim > a.iou_thr) w = -2.0f;
+          S.wgt[sl] = w;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (tid == 0) {
+        float score = stale0;
+        for (int sl = 0; sl < nl; ++sl) {
+          const float w = S.wgt[sl];
+          if (w == -2.0f) { score = -INFINITY; break; }
+          score *= w;
+          if (score <= a.score_thr) { score = -INFINITY; break; }
+        }
+        U[bi - i0] = score;
+        S.pbegin = bi;
+        if (score != -INFINITY) atomicMax(&bound[k], nms_key(score, bi));
+      }
+    }
+#ifdef UDA_NMS_STATS
+    __syncthreads();
+    const unsigned long long t1 = wall_clock64();
+#endif
+    coop_barrier(ctr, (++phase) * (unsigned)bpi, err);      // (also orders wave 0's U / ev writes for the block)
+#ifdef UDA_NMS_STATS
+    const unsigned long long t2 = wall_clock64();
+#endif
+    const unsigned long long bd = __hip_atomic_load(&bound[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ---- B. exact scores of everything that can still reach the bound (few: a loop over a bit mask)
+    unsigned long long ke = 0ull;
+    unsigned need = 0u;
+    {
+      // key(u, i) >= bd  <=>  ord(u) > ord(bd)  or  (ord(u) == ord(bd) and ~i >= low word of bd)
+      const uint32_t bdo = (uint32_t)(bd >> 32), bdl = (uint32_t)bd;
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) {
+        const float u = U[j * SOLO_T + tid];
+        if (st[j] != -INFINITY && u != -INFINITY) {
+          const uint32_t o = ord32(u);
+          if (o > bdo || (o == bdo && 0xFFFFFFFFu - (uint32_t)(ib + j * SOLO_T) >= bdl)) need |= 1u << j;
+        }
+      }
+    }
+    while (need) {
+      const int j = __ffs((int)need) - 1;
+      need &= need - 1u;
+      const int i = ib + j * SOLO_T;
+      const float v = evaluate(i, j, k);
+      if (v != -INFINITY) {
+        const unsigned long long key = nms_key(v, i);
+        ke = key > ke ? key : ke;
+      }
+    }
+    ke = reg_max(S, ke);
+    if (tid == 0 && ke != 0ull) atomicMax(&win[k], ke);
+#ifdef UDA_NMS_STATS
+    const unsigned long long t3 = wall_clock64();
+#endif
+    coop_barrier(ctr, (++phase) * (unsigned)bpi, err);
+#ifdef UDA_NMS_STATS
+    const unsigned long long t4 = wall_clock64();
+#endif
+    const unsigned long long wk = __hip_atomic_load(&win[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wk == 0ull) break;                  // no live candidate in the whole problem (uniform over its blocks)
+    const int widx = (int)(0xFFFFFFFFu - (uint32_t)wk);
+    if (tid < 4) S.sel[4 * k + tid] = a.boxes[(bbase + widx) * 4 + tid];
+    // ---- C. pops and the winner (chains of epoch k use the selected boxes 0 .. k-1 only)
+    unsigned pops = 0u;
+    {
+      const int rel = widx - i0;           // the winner's slot, if it lives in this block
+      const bool mine = rel >= 0 && rel < IPT * SOLO_T && (rel % SOLO_T) == tid;
+      const int jw = mine ? rel / SOLO_T : -1;
+      if (mine) {
+        const size_t o = (size_t)n * a.M + k;
+        a.sel_idx[o] = widx;
+        a.sel_score[o] = U[rel];
+        *(float4*)(a.sel_box + o * 4) = *(const float4*)(a.boxes + (bbase + widx) * 4);
+        a.stale[bbase + widx] = -INFINITY;
+      }
+      // key(st, i) > wk  <=>  ord(st) > ord(wk)  or  (equal and ~i > low word of wk)
+      const uint32_t wo = (uint32_t)(wk >> 32), wl = (uint32_t)wk;
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) {
+        if (j == jw) st[j] = -INFINITY;
+        if (st[j] != -INFINITY) {
+          const uint32_t o = ord32(st[j]);
+          if (o > wo || (o == wo && 0xFFFFFFFFu - (uint32_t)(ib + j * SOLO_T) > wl)) pops |= 1u << j;
+        }
+      }
+    }
+    need = pops;
+    while (need) {
+      const int j = __ffs((int)need) - 1;
+      need &= need - 1u;
+      const int i = ib + j * SOLO_T;
+      const float v = evaluate(i, j, k);
+      a.stale[bbase + i] = v;
+      a.begin[bbase + i] = k;
+    }
+#pragma unroll
+    for (int j = 0; j < IPT; ++j)
+      if ((pops >> j) & 1u) st[j] = U[j * SOLO_T + tid];
+    nsel = k + 1;
+    __syncthreads();
+#ifdef UDA_NMS_STATS
+    if (tid == 0) {
+      const unsigned long long t5 = wall_clock64();
+      NMS_STAT(4, t1 - t0); NMS_STAT(5, t2 - t1); NMS_STAT(6, t3 - t2); NMS_STAT(7, t4 - t3);
+      atomicAdd(&g_nms_dbg2[0], t5 - t4); atomicAdd(&g_nms_dbg2[1], 1ull);
+    }
+#endif
+  }
+  if (blk == 0 && tid == 0) a.nsel[n] = nsel;
+}
+
+constexpr int COOP_IPT = 32;
+
+// blocks per problem, or 0 when the cooperative kernel cannot take these problems
+int nms_coop_blocks(const NmsArgs& a) {
+  if (a.segs != 1 || a.M > 128 || a.K < 1) return 0;
+  return (a.K + COOP_IPT * SOLO_T - 1) / (COOP_IPT * SOLO_T);
+}
+
+// false = not launched (grid not co-resident on this device, or the runtime refused): the caller uses the grid version
+bool launch_nms_coop(const NmsArgs& a, const float* scores, unsigned* bar, int* err, hipStream_t s) {
+  const int bpi = nms_coop_blocks(a);
+  if (bpi == 0 || a.n_img <= 0) return false;
+  constexpr size_t lds = (size_t)COOP_IPT * SOLO_T * sizeof(float);
+  static int capacity = -1;
+  if (capacity < 0) {
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    capacity = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.cooperativeLaunch &&
+        hipFuncSetAttribute((const void*)nms_coop_kernel<COOP_IPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nms_coop_kernel<COOP_IPT>, SOLO_T, lds) == hipSuccess)
+      capacity = per_cu * prop.multiProcessorCount;
+    (void)hipGetLastError();
+  }
+  static const bool dbg = getenv("UDA_NMS_DEBUG") != nullptr;
+  if ((long long)bpi * a.n_img > capacity) {
+    if (dbg) fprintf(stderr, "[uda] cooperative NMS: %d x %d blocks > capacity %d\n", bpi, a.n_img, capacity);
+    return false;
+  }
+  hipMemsetAsync(a.bound_key, 0, (size_t)a.n_img * a.M * sizeof(unsigned long long), s);
+  hipMemsetAsync(a.win_key, 0, (size_t)a.n_img * a.M * sizeof(unsigned long long), s);
+  hipMemsetAsync(bar, 0, (size_t)a.n_img * sizeof(unsigned), s);
+  NmsArgs aa = a;
+  const float* sc = scores;
+  int b = bpi;
+  void* args[] = {(void*)&aa, (void*)&sc, (void*)&bar, (void*)&err, (void*)&b};
+  const hipError_t e = hipLaunchCooperativeKernel((const void*)nms_coop_kernel<COOP_IPT>, dim3((unsigned)(bpi * a.n_img)),
+                                                  dim3(SOLO_T), args, (unsigned)lds, s);
+  if (e != hipSuccess) {
+    if (dbg) fprintf(stderr, "[uda] cooperative NMS: launch refused: %s\n", hipGetErrorString(e));
+    (void)hipGetLastError();
+    return false;
+  }
+  if (dbg) fprintf(stderr, "[uda] cooperative NMS: %d problems x %d blocks (capacity %d)\n", a.n_img, bpi, capacity);
+#ifdef UDA_NMS_STATS
+  {
+    hipStreamSynchronize(s);
+    unsigned long long h[8];
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_nms_dbg), sizeof(h));
+    fprintf(stderr, "[uda] nms stats (cumulative): chains %llu links %llu chains>=16 %llu chains>=48 %llu\n", h[0], h[1], h[2], h[3]);
+    unsigned long long h2[2];
+    hipMemcpyFromSymbol(h2, HIP_SYMBOL(g_nms_dbg2), sizeof(h2));
+    if (h2[1]) fprintf(stderr, "[uda] nms phases, mean per block-epoch in 10 ns ticks: A %.1f bar1 %.1f B %.1f bar2 %.1f C %.1f (%llu block-epochs)\n",
+                       (double)h[4] / h2[1], (double)h[5] / h2[1], (double)h[6] / h2[1], (double)h[7] / h2[1], (double)h2[0] / h2[1], h2[1]);
+  }
+#endif
+  return true;
 }
 
 // ------------------------------------------------------------------------------------ NMS on a score prefix

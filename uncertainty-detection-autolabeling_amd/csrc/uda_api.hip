@@ -113,6 +113,10 @@ struct uda_ctx {
   bool pfx_off = false;                            // set while finish_post redoes rejected images
   int64_t pfx_fallbacks = 0;                       // images redone on the full candidate set so far
   int pfx_skip = 0, pfx_backoff = 0;               // runs left without the prefix / length of the last pause
+  // cooperative single-launch NMS: per-problem barrier counters + one error word (barrier timed out)
+  unsigned* d_coop_bar = nullptr;
+  int* d_coop_err = nullptr;
+  bool coop_used = false;
   unsigned long long* d_merge_keys = nullptr;
   // outputs
   float *d_oboxes = nullptr, *d_oscores = nullptr, *d_oclasses = nullptr, *d_ologits = nullptr;
@@ -211,6 +215,8 @@ extern "C" void uda_destroy(uda_ctx_t* c) {
   for (void* p : ptrs)
     if (p) hipFree(p);
   free_prefix_ws(c->pfx);
+  if (c->d_coop_bar) hipFree(c->d_coop_bar);
+  if (c->d_coop_err) hipFree(c->d_coop_err);
   for (auto& w : c->ws) {
     void* wp[] = {w.stale, w.tent, w.ub, w.sel_score, w.sel_box, w.ev, w.begin, w.sel_idx, w.nsel, w.done, w.bound, w.win};
     for (void* p : wp)
@@ -549,6 +555,9 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
   if (m.has_uncert && m.loss_attenuation) CK(dalloc(&c->d_ual, N * K * 4));
   if (m.has_uncert && m.box_stacked) CK(dalloc(&c->d_uep, N * K * 4));
   CK(alloc_nms_ws(c->ws[0], N, K, M));
+  CK(dalloc(&c->d_coop_bar, N));
+  CK(dalloc(&c->d_coop_err, 1));
+  CK(hipMemset(c->d_coop_err, 0, sizeof(int)));
   if (prefix_target() > 0 && (int)K > solo_limit() && K > (size_t)2 * prefix_target() && M <= 128)
     CK(alloc_prefix_ws(c->pfx, N, 2 * prefix_target(), M));
   CK(dalloc(&c->d_oboxes, N * M * 12));
@@ -971,7 +980,14 @@ static NmsArgs nms_args_at(uda_ctx::NmsWs& w, size_t p0, int problems, int K, in
 
 // Returns true when the problems were solved on their score prefix (flags in pw->bad[p0 ..] say which ones have to be
 // redone on the full set, see finish_post); `pw` null = never.
-static bool run_nms(const NmsArgs& na, const float* scores, int M, hipStream_t st, uda_ctx::PrefixWs* pw = nullptr, size_t p0 = 0) {
+struct NmsCoop {           // scratch of the cooperative kernel; null members = never use it
+  unsigned* bar = nullptr;
+  int* err = nullptr;
+  bool* used = nullptr;
+};
+
+static bool run_nms(const NmsArgs& na, const float* scores, int M, hipStream_t st, uda_ctx::PrefixWs* pw = nullptr, size_t p0 = 0,
+                    NmsCoop coop = NmsCoop()) {
   // One launch for all epochs (one block per problem) when a problem is small - the top-k / per-class paths with a
   // few thousand candidates each; with the whole anchor set as candidates (184 k near-tied scores under random-init
   // weights) an epoch revisits 10-20 chunks one after the other inside the block and the grid version, which scans
@@ -1009,6 +1025,14 @@ static bool run_nms(const NmsArgs& na, const float* scores, int M, hipStream_t s
     ca.n_img = na.n_img; ca.M = M; ca.Lcap = pw->Lcap; ca.score_thr = na.score_thr;
     launch_prefix_check(ca, st);
     return true;
+  }
+  // the whole set: all epochs in one cooperative launch when its grid is co-resident (UDA_NMS_COOP=0: never), else
+  // two launches per epoch
+  static int coop_on = -1;
+  if (coop_on < 0) { const char* e = getenv("UDA_NMS_COOP"); coop_on = e ? atoi(e) : 1; }
+  if (coop_on && coop.bar && coop.err && launch_nms_coop(na, scores, coop.bar + p0, coop.err, st)) {
+    if (coop.used) *coop.used = true;
+    return false;
   }
   launch_nms_init(na, scores, st);
   for (int e = 0; e < M; ++e) launch_nms_epoch(na, e, st);
@@ -1088,7 +1112,9 @@ static int run_post_global(uda_ctx* c, int i0, int n, hipStream_t st) {
     NmsArgs na = nms_args_at(c->ws[0], (size_t)i0, n, K, M, c->d_cboxes + (size_t)i0 * k * 4);
     nms_params(na, m.nms_iou_thresh, m.nms_score_thresh, m.nms_soft_sigma);
     const bool try_prefix = !c->pfx_off && c->pfx_skip == 0;
-    if (run_nms(na, c->d_cscores + (size_t)i0 * k, M, st, try_prefix ? &c->pfx : nullptr, (size_t)i0))
+    NmsCoop coop;
+    coop.bar = c->d_coop_bar; coop.err = c->d_coop_err; coop.used = &c->coop_used;
+    if (run_nms(na, c->d_cscores + (size_t)i0 * k, M, st, try_prefix ? &c->pfx : nullptr, (size_t)i0, coop))
       c->pfx_pending.push_back({i0, n});
   }
   GatherArgs g{};
@@ -1170,6 +1196,16 @@ static int run_post(uda_ctx* c, int n, int post_mode) {
 // Every reader of the post-process outputs comes through here: images whose score prefix turned out not to be
 // sufficient (flag written by prefix_check_kernel) are redone on the full candidate set before anything is read.
 static int finish_post(uda_ctx* c) {
+  if (c->coop_used) {        // a barrier of the cooperative NMS that timed out leaves garbage: fail loudly
+    c->coop_used = false;
+    HIPC(c, hipStreamSynchronize(c->stream));
+    int e = 0;
+    HIPC(c, hipMemcpy(&e, c->d_coop_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (e) {
+      hipMemset(c->d_coop_err, 0, sizeof(int));
+      return fail(c, "cooperative NMS: a grid barrier timed out (blocks not co-resident?); set UDA_NMS_COOP=0");
+    }
+  }
   if (c->pfx_pending.empty()) return 0;
   HIPC(c, hipStreamSynchronize(c->stream));
   std::vector<std::pair<int, int>> pend;
@@ -1490,7 +1526,9 @@ extern "C" int uda_nms(uda_ctx_t* c, const float* boxes, const float* scores, in
   bool prefix = false;
   {
     ProfScope ps(c, 17);
-    if (k > 0) prefix = run_nms(a, d_scores, max_out, c->stream, pw.Lcap ? &pw : nullptr, 0);
+    NmsCoop coop;
+    if (n_img <= c->model.max_images) { coop.bar = c->d_coop_bar; coop.err = c->d_coop_err; coop.used = &c->coop_used; }
+    if (k > 0) prefix = run_nms(a, d_scores, max_out, c->stream, pw.Lcap ? &pw : nullptr, 0, coop);
     else launch_nms_init(a, d_scores, c->stream);
   }
   HIPC(c, hipStreamSynchronize(c->stream));
@@ -1506,13 +1544,26 @@ extern "C" int uda_nms(uda_ctx_t* c, const float* boxes, const float* scores, in
       f.sel_idx = d_si + pm; f.sel_score = d_ss + pm; f.sel_box = d_sb + pm * 4; f.bound_key = d_bound + pm; f.win_key = d_win + pm;
       f.nsel = d_nsel + p; f.done = d_done + p; f.n_img = 1;
       ProfScope ps(c, 17);
-      run_nms(f, d_scores + pk, max_out, c->stream);
+      NmsCoop coop;
+      coop.bar = c->d_coop_bar; coop.err = c->d_coop_err; coop.used = &c->coop_used;
+      run_nms(f, d_scores + pk, max_out, c->stream, nullptr, 0, coop);
       ++c->pfx_fallbacks;
     }
     HIPC(c, hipStreamSynchronize(c->stream));
     HIPC(c, hipGetLastError());
   }
   free_prefix_ws(pw);
+  if (c->coop_used) {
+    c->coop_used = false;
+    int e = 0;
+    hipMemcpy(&e, c->d_coop_err, sizeof(int), hipMemcpyDeviceToHost);
+    if (e) {
+      hipMemset(c->d_coop_err, 0, sizeof(int));
+      void* fr[] = {d_boxes, d_scores, d_stale, d_tent, d_ub, d_ev, d_begin, d_si, d_ss, d_sb, d_bound, d_win, d_nsel, d_done};
+      for (void* q : fr) hipFree(q);
+      return fail(c, "cooperative NMS: a grid barrier timed out (blocks not co-resident?); set UDA_NMS_COOP=0");
+    }
+  }
   HIPC(c, hipMemcpy(valid, d_nsel, n_img * sizeof(int32_t), hipMemcpyDeviceToHost));
   HIPC(c, hipMemcpy(idx, d_si, NM * sizeof(int32_t), hipMemcpyDeviceToHost));
   HIPC(c, hipMemcpy(out_scores, d_ss, NM * sizeof(float), hipMemcpyDeviceToHost));
