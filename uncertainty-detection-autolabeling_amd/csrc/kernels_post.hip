@@ -1079,8 +1079,9 @@ __device__ __forceinline__ unsigned long long reg_max(RegLds& S, unsigned long l
 // over all links that leaves a bit mask of the overlapping ones, then IoU + exp + multiply (the reference's order and
 // early exits) over the set bits only.  Lanes of a wave then diverge over a handful of expensive links instead of
 // paying the double-precision exp at nearly every one of up to 100 links.
-__device__ __forceinline__ float reg_chain(const NmsArgs& a, const RegLds& S, float score, int begin, const float* bx, int k) {
-  unsigned long long m[2] = {0ull, 0ull};       // links 0..63 / 64..127
+// pass 1: bit mask of the links begin .. k-1 whose selected box strictly overlaps the candidate
+__device__ __forceinline__ void chain_mask(const NmsArgs& a, const RegLds& S, int begin, const float* bx, int k, unsigned long long* m) {
+  m[0] = 0ull; m[1] = 0ull;                      // links 0..63 / 64..127
   if (a.soft || a.iou_thr >= 0.f) {
     const float y0 = fminf(bx[0], bx[2]), x0 = fminf(bx[1], bx[3]), y1 = fmaxf(bx[0], bx[2]), x1 = fmaxf(bx[1], bx[3]);
     for (int j = begin; j < k; ++j) {
@@ -1092,6 +1093,10 @@ __device__ __forceinline__ float reg_chain(const NmsArgs& a, const RegLds& S, fl
   } else {                                        // (negative hard threshold: IoU 0 suppresses too - no link can be skipped)
     for (int j = begin; j < k; ++j) m[j >> 6] |= 1ull << (j & 63);
   }
+}
+
+// pass 2: IoU + exp + multiply over the set bits, newest first, with the reference's early exits
+__device__ __forceinline__ float chain_product(const NmsArgs& a, const RegLds& S, float score, const float* bx, const unsigned long long* m) {
 #pragma unroll
   for (int h = 1; h >= 0; --h) {
     unsigned long long mm = m[h];
@@ -1110,6 +1115,57 @@ __device__ __forceinline__ float reg_chain(const NmsArgs& a, const RegLds& S, fl
       score *= w;
       if (!a.soft && sim > a.iou_thr) return -INFINITY;
       if (score <= a.score_thr) return -INFINITY;
+    }
+  }
+  return score;
+}
+
+// Pending chain of one candidate: links k-1 .. begin, newest first.  Most links are no-ops - a selected box that does not
+// strictly overlap the candidate has IoU 0, weight exactly 1.0f - so the chain runs in two passes: a cheap interval test
+// over all links that leaves a bit mask of the overlapping ones, then IoU + exp + multiply (the reference's order and
+// early exits) over the set bits only.  Lanes of a wave then diverge over a handful of expensive links instead of
+// paying the double-precision exp at nearly every one of up to 100 links.
+__device__ __forceinline__ float reg_chain(const NmsArgs& a, const RegLds& S, float score, int begin, const float* bx, int k) {
+  unsigned long long m[2];
+  chain_mask(a, S, begin, bx, k, m);
+  return chain_product(a, S, score, bx, m);
+}
+
+// The same chain evaluated by a whole wave (all 64 lanes call it with the same arguments): links spread over the lanes,
+// 64 at a time, newest first; only the lanes whose selected box strictly overlaps the candidate compute a weight, and
+// the product runs over those lanes in link order with the weights read out of the lanes' registers.  Every lane
+// returns the same score.
+__device__ __forceinline__ float chain_wave(const NmsArgs& a, const RegLds& S, float score, int begin, const float* pb, int k) {
+  const int lane = threadIdx.x & 63, nl = k - begin;
+  const bool sparse = a.soft || a.iou_thr >= 0.f;
+  const float y0 = fminf(pb[0], pb[2]), x0 = fminf(pb[1], pb[3]), y1 = fmaxf(pb[0], pb[2]), x1 = fmaxf(pb[1], pb[3]);
+  for (int s0 = 0; s0 < nl && score != -INFINITY; s0 += 64) {
+    const int sl = s0 + lane;
+    bool ov = false;
+    float w = 1.0f;
+    if (sl < nl) {
+      const float* sb = S.sel + 4 * (k - 1 - sl);
+      const float sy0 = fminf(sb[0], sb[2]), sx0 = fminf(sb[1], sb[3]), sy1 = fmaxf(sb[0], sb[2]), sx1 = fmaxf(sb[1], sb[3]);
+      ov = !sparse || ((fminf(y1, sy1) > fmaxf(y0, sy0)) && (fminf(x1, sx1) > fmaxf(x0, sx0)));
+      if (ov) {
+        const float sim = nms_iou(pb, sb);
+        if (a.soft || sim <= a.iou_thr) {
+          const float e = a.scale * sim * sim;
+          w = (e == 0.0f) ? 1.0f : (float)exp((double)e);
+        } else {
+          w = 0.0f;
+        }
+        if (!a.soft && sim > a.iou_thr) w = -2.0f;      // hard suppression marker (a weight is never negative)
+      }
+    }
+    unsigned long long mm = __ballot(ov);
+    while (mm) {
+      const int ln = __ffsll((long long)mm) - 1;
+      mm &= mm - 1ull;
+      const float wl = __shfl(w, ln, 64);
+      if (wl == -2.0f) { score = -INFINITY; break; }
+      score *= wl;
+      if (score <= a.score_thr) { score = -INFINITY; break; }
     }
   }
   return score;
@@ -1305,24 +1361,32 @@ void launch_nms_reg(const NmsArgs& a, const float* scores, hipStream_t s) {
 //   A  every block: exact score of its best candidate by upper bound (wave 0) -> atomicMax(bound[k])   | barrier
 //   B  every candidate whose upper bound reaches bound[k]: exact score -> atomicMax(win[k])            | barrier
 //   C  pops (stale priority above the winner -> exact, begin = k); the winner's owner records it.
-__device__ __forceinline__ void coop_barrier(unsigned* ctr, unsigned target, int* err) {
+// Blocks of a problem exchange nothing but device-scope atomics (the per-epoch bound / winner slots and this counter);
+// everything else a block reads was written by itself or is read-only.  So the barrier needs no release / acquire
+// fences - on a multi-XCD part those write back and invalidate the whole L2 (measured: every load after a fenced
+// barrier missed) - only program order between a thread's own atomics, which `pending` (the value returned by the
+// atomicMax the block issued before arriving, 0 if none) enforces: the counter is bumped after that atomic has returned.
+__device__ __forceinline__ void coop_barrier(unsigned* ctr, unsigned target, int* err, unsigned long long pending = 0ull) {
   __syncthreads();
   if (threadIdx.x == 0) {
-    __threadfence();
-    atomicAdd(ctr, 1u);
+    asm volatile("" :: "v"((unsigned)pending), "v"((unsigned)(pending >> 32)));      // the earlier atomic has completed
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // one device-scope load per poll (its round trip is the poll period); the error word is looked at every 4096 polls
     unsigned spins = 0;
-    while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1u << 22)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if ((++spins & 4095u) == 0u) {
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        if (spins > (1u << 22)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
     }
-    __threadfence();
   }
   __syncthreads();
 }
 
 __device__ unsigned long long g_nms_dbg[8];
 __device__ unsigned long long g_nms_dbg2[2];
+__device__ unsigned long long g_nms_dbg3[8];
+__device__ unsigned long long g_nms_hist[16];
 #ifdef UDA_NMS_STATS
 #define NMS_STAT(slot, v) atomicAdd(&g_nms_dbg[slot], (unsigned long long)(v))
 #else
@@ -1337,13 +1401,21 @@ __device__ __forceinline__ float coop_chain(const NmsArgs& a, const RegLds& S, f
   return reg_chain(a, S, score, begin, bx, k);
 }
 
+constexpr int COOP_LIST = 3072;      // entries of the block-wide work list
+constexpr int COOP_HEAVY = 1024;     // entries of the list of chains handed to whole waves
+constexpr int COOP_HEAVY_LINKS = 6;  // overlapping links above which a chain is evaluated by a wave
+
 template <int IPT>
 __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float* scores, unsigned* bar, int* err, int bpi) {
   // Per candidate: the stale score in a register of its thread (scanned every epoch, candidate i0 + j * 1024 + tid), the
   // cached exact score / upper bound in LDS (scanned every epoch, 128 KB), begin / epoch / a copy of the stale score in
   // the workspace arrays in memory (touched only when a chain is evaluated, together with the candidate's box).
-  extern __shared__ float U[];                    // [IPT * 1024]
+  extern __shared__ float U[];                    // [IPT * 1024] | work list [COOP_LIST] | "exact this epoch" bits
+  int* wlist = (int*)(U + IPT * SOLO_T);
+  int* hlist = wlist + COOP_LIST;
+  unsigned* ebits = (unsigned*)(hlist + COOP_HEAVY);  // [IPT * 1024 / 32]
   __shared__ RegLds S;
+  __shared__ int wcount, hcount;
   const int n = blockIdx.x / bpi, blk = blockIdx.x % bpi, tid = threadIdx.x;
   const size_t bbase = (size_t)n * a.K;           // one problem per image (segs == 1)
   const int i0 = blk * IPT * SOLO_T;
@@ -1364,29 +1436,89 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
     st[j] = v;
     U[j * SOLO_T + tid] = v;
   }
-  if (blk == 0 && tid < a.M) {
-    a.sel_idx[(size_t)n * a.M + tid] = 0;
-    a.sel_score[(size_t)n * a.M + tid] = 0.f;
-  }
+  // (the padded form of the outputs - index 0 / score 0 in the slots that stay empty - is written by the launcher's
+  // memsets: a slot must have ONE writer inside the kernel, the L2s of different XCDs are not coherent with each other)
   int nsel = 0;
   unsigned phase = 0;
   __syncthreads();
 
-  // exact score of candidate i in epoch k (links begin .. k-1, newest first); records it as the cached score.  Which
-  // candidates are already exact in this epoch is kept in a per-thread bit mask (`done`) plus the one candidate wave 0
-  // evaluated in step A (S.pbegin), so nothing but stale / begin / box - one round trip, in parallel - comes from memory
-  unsigned done = 0u;
-  auto evaluate = [&](int i, int j, int k) -> float {
-    const size_t g = bbase + i;
-    float v;
-    if (((done >> j) & 1u) || i == S.pbegin) {
-      v = U[i - i0];
-    } else {
-      v = coop_chain(a, S, a.stale[g], a.begin[g], g, k);
-      U[i - i0] = v;
+  // Exact scores (epoch k: links begin .. k-1, newest first) of the candidates flagged in the threads' bit masks.  These
+  // are spatial neighbours, so a few threads would carry all the chains: they go through a block-wide list and every
+  // thread takes entries round-robin (entries beyond the capacity stay with their owners).  A thread runs the cheap mask
+  // pass of its entry; chains with few overlapping links it finishes itself, the others - big boxes overlap most of
+  // the selected ones, up to 100 IoU + exp in a row - go to a second list that whole waves work off (chain_wave).
+  // stale / begin / box come from memory in one round trip; "already exact in this epoch" is a bit per candidate in
+  // LDS.  `fn(rel, v)` receives every candidate with its exact score, once, from some thread.
+  auto run_balanced = [&](unsigned mask, int k, auto&& fn) {
+    if (tid == 0) { wcount = 0; hcount = 0; }
+    __syncthreads();
+    unsigned left = 0u;
+    {
+      unsigned m = mask;
+      while (m) {
+        const int j = __ffs((int)m) - 1;
+        m &= m - 1u;
+        const int pos = atomicAdd(&wcount, 1);
+        if (pos < COOP_LIST) wlist[pos] = j * SOLO_T + tid;
+        else left |= 1u << j;
+      }
     }
-    done |= 1u << j;
-    return v;
+    __syncthreads();
+    const int cnt = wcount < COOP_LIST ? wcount : COOP_LIST;
+#ifdef UDA_NMS_STATS
+    const unsigned long long tb0 = wall_clock64();
+    if (tid == 0) { atomicAdd(&g_nms_dbg3[0], (unsigned long long)wcount); atomicMax(&g_nms_dbg3[1], (unsigned long long)wcount); }
+#endif
+    auto one = [&](int rel) {
+      if ((ebits[rel >> 5] >> (rel & 31)) & 1u) { fn(rel, U[rel]); return; }
+      const size_t g = bbase + i0 + rel;
+      const int begin = a.begin[g];
+      const float stale = a.stale[g];
+      float v = stale;
+      if (k > begin) {
+        const float4 b4 = *(const float4*)(a.boxes + g * 4);
+        const float bx[4] = {b4.x, b4.y, b4.z, b4.w};
+        unsigned long long m[2];
+        chain_mask(a, S, begin, bx, k, m);
+        if (__popcll(m[0]) + __popcll(m[1]) > COOP_HEAVY_LINKS) {
+          const int pos = atomicAdd(&hcount, 1);
+          if (pos < COOP_HEAVY) { hlist[pos] = rel; return; }
+        }
+        v = chain_product(a, S, stale, bx, m);
+      }
+      U[rel] = v;
+      atomicOr(&ebits[rel >> 5], 1u << (rel & 31));
+      fn(rel, v);
+    };
+    for (int e = tid; e < cnt; e += SOLO_T) one(wlist[e]);
+    while (left) {
+      const int j = __ffs((int)left) - 1;
+      left &= left - 1u;
+      one(j * SOLO_T + tid);
+    }
+    __syncthreads();
+#ifdef UDA_NMS_STATS
+    const unsigned long long tb1 = wall_clock64();
+    if (tid == 0) { atomicAdd(&g_nms_dbg3[2], (unsigned long long)hcount); atomicMax(&g_nms_dbg3[3], (unsigned long long)hcount);
+                    atomicAdd(&g_nms_dbg3[4], tb1 - tb0); atomicMax(&g_nms_dbg3[5], tb1 - tb0); }
+#endif
+    const int hc = hcount < COOP_HEAVY ? hcount : COOP_HEAVY;
+    for (int e = tid >> 6; e < hc; e += SOLO_T / 64) {
+      const int rel = hlist[e];
+      const size_t g = bbase + i0 + rel;
+      const float4 b4 = *(const float4*)(a.boxes + g * 4);
+      const float bx[4] = {b4.x, b4.y, b4.z, b4.w};
+      const float v = chain_wave(a, S, a.stale[g], a.begin[g], bx, k);
+      if ((tid & 63) == 0) {
+        U[rel] = v;
+        atomicOr(&ebits[rel >> 5], 1u << (rel & 31));
+        fn(rel, v);
+      }
+    }
+    __syncthreads();
+#ifdef UDA_NMS_STATS
+    if (tid == 0) { const unsigned long long tb2 = wall_clock64(); atomicAdd(&g_nms_dbg3[6], tb2 - tb1); atomicMax(&g_nms_dbg3[7], tb2 - tb1); }
+#endif
   };
 
   for (int k = 0; k < a.M; ++k) {
@@ -1394,6 +1526,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
     // addresses of all IPT candidates are hoisted out of the epoch loop and spill)
     int ib = i0 + tid;
     asm volatile("" : "+v"(ib));
+    unsigned long long pend = 0ull;          // value returned by this thread's last bound / winner atomic
 #ifdef UDA_NMS_STATS
     const unsigned long long t0 = wall_clock64();
 #endif
@@ -1414,49 +1547,28 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
       if (bo != 0u) bk = ((unsigned long long)bo << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)(ib + bj * SOLO_T));
     }
     bk = reg_max(S, bk);
-    done = 0u;
-    if (tid == 0) S.pbegin = -1;             // (candidate index of step A's exact score, -1 = none)
+    ebits[tid] = 0u;                         // IPT * 1024 / 32 = IPT * 32 words: one per thread when IPT == 32
+    if (IPT * 32 > SOLO_T) for (int f = tid + SOLO_T; f < IPT * 32; f += SOLO_T) ebits[f] = 0u;
+    __syncthreads();
     if (bk != 0ull && tid < 64) {
       const int bi = (int)(0xFFFFFFFFu - (uint32_t)bk);
       const size_t g = bbase + bi;
-      const int begin = a.begin[g], nl = k - begin;
+      const int begin = a.begin[g];
       const float stale0 = a.stale[g];
       const float4 b4 = *(const float4*)(a.boxes + g * 4);
       const float pb[4] = {b4.x, b4.y, b4.z, b4.w};
-      for (int s0 = 0; s0 < nl; s0 += 64) {
-        const int sl = s0 + tid;
-        if (sl < nl) {
-          const float sim = nms_iou(pb, S.sel + 4 * (k - 1 - sl));
-          float w;
-          if (a.soft || sim <= a.iou_thr) {
-            const float e = a.scale * sim * sim;
-            w = (e == 0.0f) ? 1.0f : (float)exp((double)e);
-          } else {
-            w = 0.0f;
-          }
-          if (!a.soft && sim > a.iou_thr) w = -2.0f;
-          S.wgt[sl] = w;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
+      const float score = chain_wave(a, S, stale0, begin, pb, k);
       if (tid == 0) {
-        float score = stale0;
-        for (int sl = 0; sl < nl; ++sl) {
-          const float w = S.wgt[sl];
-          if (w == -2.0f) { score = -INFINITY; break; }
-          score *= w;
-          if (score <= a.score_thr) { score = -INFINITY; break; }
-        }
         U[bi - i0] = score;
-        S.pbegin = bi;
-        if (score != -INFINITY) atomicMax(&bound[k], nms_key(score, bi));
+        atomicOr(&ebits[(bi - i0) >> 5], 1u << ((bi - i0) & 31));
+        if (score != -INFINITY) pend = atomicMax(&bound[k], nms_key(score, bi));
       }
     }
 #ifdef UDA_NMS_STATS
     __syncthreads();
     const unsigned long long t1 = wall_clock64();
 #endif
-    coop_barrier(ctr, (++phase) * (unsigned)bpi, err);      // (also orders wave 0's U / ev writes for the block)
+    coop_barrier(ctr, (++phase) * (unsigned)bpi, err, pend);      // (also orders wave 0's U / bit writes for the block)
 #ifdef UDA_NMS_STATS
     const unsigned long long t2 = wall_clock64();
 #endif
@@ -1476,22 +1588,19 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
         }
       }
     }
-    while (need) {
-      const int j = __ffs((int)need) - 1;
-      need &= need - 1u;
-      const int i = ib + j * SOLO_T;
-      const float v = evaluate(i, j, k);
+    run_balanced(need, k, [&](int rel, float v) {
       if (v != -INFINITY) {
-        const unsigned long long key = nms_key(v, i);
+        const unsigned long long key = nms_key(v, i0 + rel);
         ke = key > ke ? key : ke;
       }
-    }
+    });
     ke = reg_max(S, ke);
-    if (tid == 0 && ke != 0ull) atomicMax(&win[k], ke);
+    pend = 0ull;
+    if (tid == 0 && ke != 0ull) pend = atomicMax(&win[k], ke);
 #ifdef UDA_NMS_STATS
     const unsigned long long t3 = wall_clock64();
 #endif
-    coop_barrier(ctr, (++phase) * (unsigned)bpi, err);
+    coop_barrier(ctr, (++phase) * (unsigned)bpi, err, pend);
 #ifdef UDA_NMS_STATS
     const unsigned long long t4 = wall_clock64();
 #endif
@@ -1523,15 +1632,10 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
         }
       }
     }
-    need = pops;
-    while (need) {
-      const int j = __ffs((int)need) - 1;
-      need &= need - 1u;
-      const int i = ib + j * SOLO_T;
-      const float v = evaluate(i, j, k);
-      a.stale[bbase + i] = v;
-      a.begin[bbase + i] = k;
-    }
+    run_balanced(pops, k, [&](int rel, float v) {
+      a.stale[bbase + i0 + rel] = v;
+      a.begin[bbase + i0 + rel] = k;
+    });                                      // (ends with a barrier: U[] of the popped candidates is complete)
 #pragma unroll
     for (int j = 0; j < IPT; ++j)
       if ((pops >> j) & 1u) st[j] = U[j * SOLO_T + tid];
@@ -1542,6 +1646,13 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
       const unsigned long long t5 = wall_clock64();
       NMS_STAT(4, t1 - t0); NMS_STAT(5, t2 - t1); NMS_STAT(6, t3 - t2); NMS_STAT(7, t4 - t3);
       atomicAdd(&g_nms_dbg2[0], t5 - t4); atomicAdd(&g_nms_dbg2[1], 1ull);
+      {
+        const unsigned long long te = t5 - t0;        // whole epoch of this block, 10 ns ticks
+        int bkt = 0;
+        while (bkt < 7 && te >= (2000ull << bkt)) ++bkt;     // < 20, 40, 80, 160, 320, 640, 1280 us, more
+        atomicAdd(&g_nms_hist[bkt], 1ull);
+        atomicAdd(&g_nms_hist[8 + bkt], te);
+      }
     }
 #endif
   }
@@ -1560,7 +1671,8 @@ int nms_coop_blocks(const NmsArgs& a) {
 bool launch_nms_coop(const NmsArgs& a, const float* scores, unsigned* bar, int* err, hipStream_t s) {
   const int bpi = nms_coop_blocks(a);
   if (bpi == 0 || a.n_img <= 0) return false;
-  constexpr size_t lds = (size_t)COOP_IPT * SOLO_T * sizeof(float);
+  constexpr size_t lds = (size_t)COOP_IPT * SOLO_T * sizeof(float) + (size_t)(COOP_LIST + COOP_HEAVY) * sizeof(int) +
+                         (size_t)COOP_IPT * 32 * sizeof(unsigned);
   static int capacity = -1;
   if (capacity < 0) {
     int dev = 0, per_cu = 0;
@@ -1580,6 +1692,8 @@ bool launch_nms_coop(const NmsArgs& a, const float* scores, unsigned* bar, int* 
   hipMemsetAsync(a.bound_key, 0, (size_t)a.n_img * a.M * sizeof(unsigned long long), s);
   hipMemsetAsync(a.win_key, 0, (size_t)a.n_img * a.M * sizeof(unsigned long long), s);
   hipMemsetAsync(bar, 0, (size_t)a.n_img * sizeof(unsigned), s);
+  hipMemsetAsync(a.sel_idx, 0, (size_t)a.n_img * a.M * sizeof(int32_t), s);
+  hipMemsetAsync(a.sel_score, 0, (size_t)a.n_img * a.M * sizeof(float), s);
   NmsArgs aa = a;
   const float* sc = scores;
   int b = bpi;
@@ -1600,6 +1714,14 @@ bool launch_nms_coop(const NmsArgs& a, const float* scores, unsigned* bar, int* 
     fprintf(stderr, "[uda] nms stats (cumulative): chains %llu links %llu chains>=16 %llu chains>=48 %llu\n", h[0], h[1], h[2], h[3]);
     unsigned long long h2[2];
     hipMemcpyFromSymbol(h2, HIP_SYMBOL(g_nms_dbg2), sizeof(h2));
+    unsigned long long hh[16];
+    hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_nms_hist), sizeof(hh));
+    fprintf(stderr, "[uda] nms epoch-time histogram (block-epochs : total ms) <20us %llu:%.1f <40 %llu:%.1f <80 %llu:%.1f <160 %llu:%.1f <320 %llu:%.1f <640 %llu:%.1f <1280 %llu:%.1f more %llu:%.1f\n",
+            hh[0], hh[8] * 1e-5, hh[1], hh[9] * 1e-5, hh[2], hh[10] * 1e-5, hh[3], hh[11] * 1e-5, hh[4], hh[12] * 1e-5, hh[5], hh[13] * 1e-5, hh[6], hh[14] * 1e-5, hh[7], hh[15] * 1e-5);
+    unsigned long long h3[8];
+    hipMemcpyFromSymbol(h3, HIP_SYMBOL(g_nms_dbg3), sizeof(h3));
+    if (h2[1]) fprintf(stderr, "[uda] nms lists per block-phase: entries mean %.1f max %llu, heavy mean %.1f max %llu; stage1 mean %.1f max %llu, stage2 mean %.1f max %llu ticks\n",
+                       (double)h3[0] / (2 * h2[1]), h3[1], (double)h3[2] / (2 * h2[1]), h3[3], (double)h3[4] / (2 * h2[1]), h3[5], (double)h3[6] / (2 * h2[1]), h3[7]);
     if (h2[1]) fprintf(stderr, "[uda] nms phases, mean per block-epoch in 10 ns ticks: A %.1f bar1 %.1f B %.1f bar2 %.1f C %.1f (%llu block-epochs)\n",
                        (double)h[4] / h2[1], (double)h[5] / h2[1], (double)h[6] / h2[1], (double)h[7] / h2[1], (double)h2[0] / h2[1], h2[1]);
   }
