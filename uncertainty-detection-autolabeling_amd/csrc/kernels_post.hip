@@ -1694,15 +1694,14 @@ bool launch_nms_coop(const NmsArgs& a, const float* scores, unsigned* bar, int* 
   hipMemsetAsync(bar, 0, (size_t)a.n_img * sizeof(unsigned), s);
   hipMemsetAsync(a.sel_idx, 0, (size_t)a.n_img * a.M * sizeof(int32_t), s);
   hipMemsetAsync(a.sel_score, 0, (size_t)a.n_img * a.M * sizeof(float), s);
-  NmsArgs aa = a;
-  const float* sc = scores;
-  int b = bpi;
-  void* args[] = {(void*)&aa, (void*)&sc, (void*)&bar, (void*)&err, (void*)&b};
-  const hipError_t e = hipLaunchCooperativeKernel((const void*)nms_coop_kernel<COOP_IPT>, dim3((unsigned)(bpi * a.n_img)),
-                                                  dim3(SOLO_T), args, (unsigned)lds, s);
+  // An ordinary launch: the grid fits the device (checked above against the occupancy of this kernel), so every block
+  // becomes resident as soon as whatever else runs on the device drains - other kernels never wait for this one - and the
+  // bounded spin is the safety net.  (hipLaunchCooperativeKernel gives the same placement plus a formal check, but
+  // rocprofv3's kernel tracing crashes at process exit after a cooperative launch, ROCm 7.2.)
+  hipLaunchKernelGGL((nms_coop_kernel<COOP_IPT>), dim3((unsigned)(bpi * a.n_img)), dim3(SOLO_T), lds, s, a, scores, bar, err, bpi);
+  const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     if (dbg) fprintf(stderr, "[uda] cooperative NMS: launch refused: %s\n", hipGetErrorString(e));
-    (void)hipGetLastError();
     return false;
   }
   if (dbg) fprintf(stderr, "[uda] cooperative NMS: %d problems x %d blocks (capacity %d)\n", a.n_img, bpi, capacity);

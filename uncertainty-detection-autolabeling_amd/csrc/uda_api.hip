@@ -117,6 +117,7 @@ struct uda_ctx {
   unsigned* d_coop_bar = nullptr;
   int* d_coop_err = nullptr;
   bool coop_used = false;
+  bool coop_off = false;                           // set after a barrier time-out: this handle stays on the two-launch version
   unsigned long long* d_merge_keys = nullptr;
   // outputs
   float *d_oboxes = nullptr, *d_oscores = nullptr, *d_oclasses = nullptr, *d_ologits = nullptr;
@@ -1113,7 +1114,7 @@ static int run_post_global(uda_ctx* c, int i0, int n, hipStream_t st) {
     nms_params(na, m.nms_iou_thresh, m.nms_score_thresh, m.nms_soft_sigma);
     const bool try_prefix = !c->pfx_off && c->pfx_skip == 0;
     NmsCoop coop;
-    coop.bar = c->d_coop_bar; coop.err = c->d_coop_err; coop.used = &c->coop_used;
+    if (!c->coop_off) { coop.bar = c->d_coop_bar; coop.err = c->d_coop_err; coop.used = &c->coop_used; }
     if (run_nms(na, c->d_cscores + (size_t)i0 * k, M, st, try_prefix ? &c->pfx : nullptr, (size_t)i0, coop))
       c->pfx_pending.push_back({i0, n});
   }
@@ -1202,8 +1203,21 @@ static int finish_post(uda_ctx* c) {
     int e = 0;
     HIPC(c, hipMemcpy(&e, c->d_coop_err, sizeof(int), hipMemcpyDeviceToHost));
     if (e) {
+      // A barrier timed out: the blocks of a problem were not all resident (another process holding part of the GPU
+      // with a grid of the same kind).  The outputs are garbage: redo the whole post-process with the two-launch
+      // version, and keep this handle on it.
       hipMemset(c->d_coop_err, 0, sizeof(int));
-      return fail(c, "cooperative NMS: a grid barrier timed out (blocks not co-resident?); set UDA_NMS_COOP=0");
+      c->coop_off = true;
+      c->pfx_pending.clear();
+      fprintf(stderr, "[uda] cooperative NMS: grid barrier timed out; falling back to two launches per epoch\n");
+      if (c->last_post_mode == UDA_POST_GLOBAL) {
+        c->pfx_off = true;
+        const int rc = run_post_global(c, 0, c->last_n, c->stream);
+        c->pfx_off = false;
+        if (rc) return rc;
+        HIPC(c, hipStreamSynchronize(c->stream));
+      }
+      return 0;
     }
   }
   if (c->pfx_pending.empty()) return 0;
@@ -1527,7 +1541,7 @@ extern "C" int uda_nms(uda_ctx_t* c, const float* boxes, const float* scores, in
   {
     ProfScope ps(c, 17);
     NmsCoop coop;
-    if (n_img <= c->model.max_images) { coop.bar = c->d_coop_bar; coop.err = c->d_coop_err; coop.used = &c->coop_used; }
+    if (n_img <= c->model.max_images && !c->coop_off) { coop.bar = c->d_coop_bar; coop.err = c->d_coop_err; coop.used = &c->coop_used; }
     if (k > 0) prefix = run_nms(a, d_scores, max_out, c->stream, pw.Lcap ? &pw : nullptr, 0, coop);
     else launch_nms_init(a, d_scores, c->stream);
   }
@@ -1545,7 +1559,7 @@ extern "C" int uda_nms(uda_ctx_t* c, const float* boxes, const float* scores, in
       f.nsel = d_nsel + p; f.done = d_done + p; f.n_img = 1;
       ProfScope ps(c, 17);
       NmsCoop coop;
-      coop.bar = c->d_coop_bar; coop.err = c->d_coop_err; coop.used = &c->coop_used;
+      if (!c->coop_off) { coop.bar = c->d_coop_bar; coop.err = c->d_coop_err; coop.used = &c->coop_used; }
       run_nms(f, d_scores + pk, max_out, c->stream, nullptr, 0, coop);
       ++c->pfx_fallbacks;
     }
@@ -1557,11 +1571,12 @@ extern "C" int uda_nms(uda_ctx_t* c, const float* boxes, const float* scores, in
     c->coop_used = false;
     int e = 0;
     hipMemcpy(&e, c->d_coop_err, sizeof(int), hipMemcpyDeviceToHost);
-    if (e) {
+    if (e) {           // barrier time-out: redo with the two-launch version (see finish_post)
       hipMemset(c->d_coop_err, 0, sizeof(int));
-      void* fr[] = {d_boxes, d_scores, d_stale, d_tent, d_ub, d_ev, d_begin, d_si, d_ss, d_sb, d_bound, d_win, d_nsel, d_done};
-      for (void* q : fr) hipFree(q);
-      return fail(c, "cooperative NMS: a grid barrier timed out (blocks not co-resident?); set UDA_NMS_COOP=0");
+      c->coop_off = true;
+      fprintf(stderr, "[uda] cooperative NMS: grid barrier timed out; falling back to two launches per epoch\n");
+      run_nms(a, d_scores, max_out, c->stream);
+      HIPC(c, hipStreamSynchronize(c->stream));
     }
   }
   HIPC(c, hipMemcpy(valid, d_nsel, n_img * sizeof(int32_t), hipMemcpyDeviceToHost));
