@@ -1356,7 +1356,7 @@ void launch_nms_reg(const NmsArgs& a, const float* scores, hipStream_t s) {
 // lower bound and the winner, both atomicMax on per-epoch slots - are crossed with a per-image barrier (a monotonic
 // counter in memory) instead of a kernel boundary.  The grid version pays a chain of dependent global loads per
 // launch (state re-read from memory, 2 launches x 100 epochs); here only the two barriers remain on the critical path.
-// All blocks must be co-resident: launched with hipLaunchCooperativeKernel, which refuses grids that are not, and the
+// All blocks must be co-resident: the launcher refuses grids larger than the device holds (occupancy x CUs), and the
 // spin is bounded (error flag -> every block falls through to the end), so the grid always drains.
 //   A  every block: exact score of its best candidate by upper bound (wave 0) -> atomicMax(bound[k])   | barrier
 //   B  every candidate whose upper bound reaches bound[k]: exact score -> atomicMax(win[k])            | barrier
