@@ -1361,26 +1361,39 @@ void launch_nms_reg(const NmsArgs& a, const float* scores, hipStream_t s) {
 //   A  every block: exact score of its best candidate by upper bound (wave 0) -> atomicMax(bound[k])   | barrier
 //   B  every candidate whose upper bound reaches bound[k]: exact score -> atomicMax(win[k])            | barrier
 //   C  pops (stale priority above the winner -> exact, begin = k); the winner's owner records it.
-// Blocks of a problem exchange nothing but device-scope atomics (the per-epoch bound / winner slots and this counter);
-// everything else a block reads was written by itself or is read-only.  So the barrier needs no release / acquire
-// fences - on a multi-XCD part those write back and invalidate the whole L2 (measured: every load after a fenced
-// barrier missed) - only program order between a thread's own atomics, which `pending` (the value returned by the
-// atomicMax the block issued before arriving, 0 if none) enforces: the counter is bumped after that atomic has returned.
-__device__ __forceinline__ void coop_barrier(unsigned* ctr, unsigned target, int* err, unsigned long long pending = 0ull) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    asm volatile("" :: "v"((unsigned)pending), "v"((unsigned)(pending >> 32)));      // the earlier atomic has completed
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // one device-scope load per poll (its round trip is the poll period); the error word is looked at every 4096 polls
-    unsigned spins = 0;
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      if ((++spins & 4095u) == 0u) {
-        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-        if (spins > (1u << 22)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+// Grid-wide step of a problem: every block contributes a 64-bit key, all blocks get the maximum.  Data and arrival are
+// ONE word per block: slot[blk] = key (or 1 = "arrived with nothing"; slots start at 0, real keys are >= 2^63), written
+// by one relaxed device-scope store; wave 0 polls the problem's slots, one per lane, until none is 0.  One store and
+// one load round trip per step, no counter, no atomic read-modify-write on the critical path, and no fences: the
+// blocks of a problem exchange nothing else (everything else a block reads was written by itself or is read-only;
+// on a multi-XCD part a release / acquire pair writes back and invalidates the whole L2 - measured: every load
+// after a fenced barrier missed).  The spin is bounded: a time-out raises *err and every later step falls through.
+constexpr int COOP_MAX_BPI = 8;
+__device__ __forceinline__ unsigned long long coop_exchange(unsigned long long* slots, int blk, int bpi, unsigned long long mine,
+                                                            RegLds& S, int* err) {
+  __syncthreads();                           // `mine` may come out of LDS traffic of the whole block
+  if (threadIdx.x < 64) {
+    if (threadIdx.x == 0) __hip_atomic_store(&slots[blk], mine ? mine : 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long v = 1ull;
+    if ((int)threadIdx.x < bpi) {
+      unsigned spins = 0;
+      while ((v = __hip_atomic_load(&slots[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0ull) {
+        if ((++spins & 4095u) == 0u) {
+          if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+          if (spins > (1u << 22)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
       }
     }
+    if (v <= 1ull) v = 0ull;
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) {  // bpi <= 8
+      const unsigned long long o = __shfl_xor(v, off, 64);
+      v = o > v ? o : v;
+    }
+    if (threadIdx.x == 0) S.L = v;
   }
   __syncthreads();
+  return S.L;
 }
 
 __device__ unsigned long long g_nms_dbg[8];
@@ -1406,7 +1419,7 @@ constexpr int COOP_HEAVY = 1024;     // entries of the list of chains handed to 
 constexpr int COOP_HEAVY_LINKS = 6;  // overlapping links above which a chain is evaluated by a wave
 
 template <int IPT>
-__global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float* scores, unsigned* bar, int* err, int bpi) {
+__global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float* scores, unsigned long long* slots_all, int* err, int bpi) {
   // Per candidate: the stale score in a register of its thread (scanned every epoch, candidate i0 + j * 1024 + tid), the
   // cached exact score / upper bound in LDS (scanned every epoch, 128 KB), begin / epoch / a copy of the stale score in
   // the workspace arrays in memory (touched only when a chain is evaluated, together with the candidate's box).
@@ -1419,9 +1432,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
   const int n = blockIdx.x / bpi, blk = blockIdx.x % bpi, tid = threadIdx.x;
   const size_t bbase = (size_t)n * a.K;           // one problem per image (segs == 1)
   const int i0 = blk * IPT * SOLO_T;
-  unsigned* ctr = bar + n;
-  unsigned long long* bound = a.bound_key + (size_t)n * a.M;
-  unsigned long long* win = a.win_key + (size_t)n * a.M;
+  unsigned long long* slots = slots_all + (size_t)n * a.M * 2 * COOP_MAX_BPI;      // [epoch][bound | winner][block]
   float st[IPT];
 #pragma unroll
   for (int j = 0; j < IPT; ++j) {
@@ -1439,7 +1450,6 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
   // (the padded form of the outputs - index 0 / score 0 in the slots that stay empty - is written by the launcher's
   // memsets: a slot must have ONE writer inside the kernel, the L2s of different XCDs are not coherent with each other)
   int nsel = 0;
-  unsigned phase = 0;
   __syncthreads();
 
   // Exact scores (epoch k: links begin .. k-1, newest first) of the candidates flagged in the threads' bit masks.  These
@@ -1526,7 +1536,6 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
     // addresses of all IPT candidates are hoisted out of the epoch loop and spill)
     int ib = i0 + tid;
     asm volatile("" : "+v"(ib));
-    unsigned long long pend = 0ull;          // value returned by this thread's last bound / winner atomic
 #ifdef UDA_NMS_STATS
     const unsigned long long t0 = wall_clock64();
 #endif
@@ -1561,18 +1570,20 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
       if (tid == 0) {
         U[bi - i0] = score;
         atomicOr(&ebits[(bi - i0) >> 5], 1u << ((bi - i0) & 31));
-        if (score != -INFINITY) pend = atomicMax(&bound[k], nms_key(score, bi));
+        S.L = (score != -INFINITY) ? nms_key(score, bi) : 0ull;
       }
     }
+    if (bk == 0ull && tid == 0) S.L = 0ull;
 #ifdef UDA_NMS_STATS
     __syncthreads();
     const unsigned long long t1 = wall_clock64();
 #endif
-    coop_barrier(ctr, (++phase) * (unsigned)bpi, err, pend);      // (also orders wave 0's U / bit writes for the block)
+    __syncthreads();
+    const unsigned long long lk = S.L;       // this block's exact lower bound
+    const unsigned long long bd = coop_exchange(slots + (size_t)(2 * k) * COOP_MAX_BPI, blk, bpi, lk, S, err);
 #ifdef UDA_NMS_STATS
     const unsigned long long t2 = wall_clock64();
 #endif
-    const unsigned long long bd = __hip_atomic_load(&bound[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // ---- B. exact scores of everything that can still reach the bound (few: a loop over a bit mask)
     unsigned long long ke = 0ull;
     unsigned need = 0u;
@@ -1595,16 +1606,14 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
       }
     });
     ke = reg_max(S, ke);
-    pend = 0ull;
-    if (tid == 0 && ke != 0ull) pend = atomicMax(&win[k], ke);
+
 #ifdef UDA_NMS_STATS
     const unsigned long long t3 = wall_clock64();
 #endif
-    coop_barrier(ctr, (++phase) * (unsigned)bpi, err, pend);
+    const unsigned long long wk = coop_exchange(slots + (size_t)(2 * k + 1) * COOP_MAX_BPI, blk, bpi, ke, S, err);
 #ifdef UDA_NMS_STATS
     const unsigned long long t4 = wall_clock64();
 #endif
-    const unsigned long long wk = __hip_atomic_load(&win[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (wk == 0ull) break;                  // no live candidate in the whole problem (uniform over its blocks)
     const int widx = (int)(0xFFFFFFFFu - (uint32_t)wk);
     if (tid < 4) S.sel[4 * k + tid] = a.boxes[(bbase + widx) * 4 + tid];
@@ -1664,11 +1673,15 @@ constexpr int COOP_IPT = 32;
 // blocks per problem, or 0 when the cooperative kernel cannot take these problems
 int nms_coop_blocks(const NmsArgs& a) {
   if (a.segs != 1 || a.M > 128 || a.K < 1) return 0;
-  return (a.K + COOP_IPT * SOLO_T - 1) / (COOP_IPT * SOLO_T);
+  const int bpi = (a.K + COOP_IPT * SOLO_T - 1) / (COOP_IPT * SOLO_T);
+  return bpi <= COOP_MAX_BPI ? bpi : 0;
 }
 
+// 64-bit words of exchange slots per problem (the caller's scratch: n_img x this)
+size_t nms_coop_slot_words(int M) { return (size_t)M * 2 * COOP_MAX_BPI; }
+
 // false = not launched (grid not co-resident on this device, or the runtime refused): the caller uses the grid version
-bool launch_nms_coop(const NmsArgs& a, const float* scores, unsigned* bar, int* err, hipStream_t s) {
+bool launch_nms_coop(const NmsArgs& a, const float* scores, unsigned long long* slots, int* err, hipStream_t s) {
   const int bpi = nms_coop_blocks(a);
   if (bpi == 0 || a.n_img <= 0) return false;
   constexpr size_t lds = (size_t)COOP_IPT * SOLO_T * sizeof(float) + (size_t)(COOP_LIST + COOP_HEAVY) * sizeof(int) +
@@ -1689,16 +1702,14 @@ bool launch_nms_coop(const NmsArgs& a, const float* scores, unsigned* bar, int* 
     if (dbg) fprintf(stderr, "[uda] cooperative NMS: %d x %d blocks > capacity %d\n", bpi, a.n_img, capacity);
     return false;
   }
-  hipMemsetAsync(a.bound_key, 0, (size_t)a.n_img * a.M * sizeof(unsigned long long), s);
-  hipMemsetAsync(a.win_key, 0, (size_t)a.n_img * a.M * sizeof(unsigned long long), s);
-  hipMemsetAsync(bar, 0, (size_t)a.n_img * sizeof(unsigned), s);
+  hipMemsetAsync(slots, 0, (size_t)a.n_img * nms_coop_slot_words(a.M) * sizeof(unsigned long long), s);
   hipMemsetAsync(a.sel_idx, 0, (size_t)a.n_img * a.M * sizeof(int32_t), s);
   hipMemsetAsync(a.sel_score, 0, (size_t)a.n_img * a.M * sizeof(float), s);
   // An ordinary launch: the grid fits the device (checked above against the occupancy of this kernel), so every block
   // becomes resident as soon as whatever else runs on the device drains - other kernels never wait for this one - and the
   // bounded spin is the safety net.  (hipLaunchCooperativeKernel gives the same placement plus a formal check, but
   // rocprofv3's kernel tracing crashes at process exit after a cooperative launch, ROCm 7.2.)
-  hipLaunchKernelGGL((nms_coop_kernel<COOP_IPT>), dim3((unsigned)(bpi * a.n_img)), dim3(SOLO_T), lds, s, a, scores, bar, err, bpi);
+  hipLaunchKernelGGL((nms_coop_kernel<COOP_IPT>), dim3((unsigned)(bpi * a.n_img)), dim3(SOLO_T), lds, s, a, scores, slots, err, bpi);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     if (dbg) fprintf(stderr, "[uda] cooperative NMS: launch refused: %s\n", hipGetErrorString(e));

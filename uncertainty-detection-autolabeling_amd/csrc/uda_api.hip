@@ -114,7 +114,7 @@ struct uda_ctx {
   int64_t pfx_fallbacks = 0;                       // images redone on the full candidate set so far
   int pfx_skip = 0, pfx_backoff = 0;               // runs left without the prefix / length of the last pause
   // cooperative single-launch NMS: per-problem barrier counters + one error word (barrier timed out)
-  unsigned* d_coop_bar = nullptr;
+  unsigned long long* d_coop_bar = nullptr;       // exchange slots, max_images x nms_coop_slot_words(max_output_size)
   int* d_coop_err = nullptr;
   bool coop_used = false;
   bool coop_off = false;                           // set after a barrier time-out: this handle stays on the two-launch version
@@ -556,7 +556,7 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
   if (m.has_uncert && m.loss_attenuation) CK(dalloc(&c->d_ual, N * K * 4));
   if (m.has_uncert && m.box_stacked) CK(dalloc(&c->d_uep, N * K * 4));
   CK(alloc_nms_ws(c->ws[0], N, K, M));
-  CK(dalloc(&c->d_coop_bar, N));
+  CK(dalloc(&c->d_coop_bar, N * nms_coop_slot_words((int)M)));
   CK(dalloc(&c->d_coop_err, 1));
   CK(hipMemset(c->d_coop_err, 0, sizeof(int)));
   if (prefix_target() > 0 && (int)K > solo_limit() && K > (size_t)2 * prefix_target() && M <= 128)
@@ -982,7 +982,7 @@ static NmsArgs nms_args_at(uda_ctx::NmsWs& w, size_t p0, int problems, int K, in
 // Returns true when the problems were solved on their score prefix (flags in pw->bad[p0 ..] say which ones have to be
 // redone on the full set, see finish_post); `pw` null = never.
 struct NmsCoop {           // scratch of the cooperative kernel; null members = never use it
-  unsigned* bar = nullptr;
+  unsigned long long* bar = nullptr;    // exchange slots (per problem nms_coop_slot_words(M) words)
   int* err = nullptr;
   bool* used = nullptr;
 };
@@ -1031,7 +1031,7 @@ static bool run_nms(const NmsArgs& na, const float* scores, int M, hipStream_t s
   // two launches per epoch
   static int coop_on = -1;
   if (coop_on < 0) { const char* e = getenv("UDA_NMS_COOP"); coop_on = e ? atoi(e) : 1; }
-  if (coop_on && coop.bar && coop.err && launch_nms_coop(na, scores, coop.bar + p0, coop.err, st)) {
+  if (coop_on && coop.bar && coop.err && launch_nms_coop(na, scores, coop.bar + p0 * nms_coop_slot_words(M), coop.err, st)) {
     if (coop.used) *coop.used = true;
     return false;
   }
@@ -1541,7 +1541,7 @@ extern "C" int uda_nms(uda_ctx_t* c, const float* boxes, const float* scores, in
   {
     ProfScope ps(c, 17);
     NmsCoop coop;
-    if (n_img <= c->model.max_images && !c->coop_off) { coop.bar = c->d_coop_bar; coop.err = c->d_coop_err; coop.used = &c->coop_used; }
+    if ((size_t)n_img * nms_coop_slot_words(max_out) <= (size_t)c->model.max_images * nms_coop_slot_words(c->model.max_output_size) && !c->coop_off) { coop.bar = c->d_coop_bar; coop.err = c->d_coop_err; coop.used = &c->coop_used; }
     if (k > 0) prefix = run_nms(a, d_scores, max_out, c->stream, pw.Lcap ? &pw : nullptr, 0, coop);
     else launch_nms_init(a, d_scores, c->stream);
   }

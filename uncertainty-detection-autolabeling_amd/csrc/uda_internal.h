@@ -229,9 +229,10 @@ void launch_nms_solo(const NmsArgs& a, const float* scores, hipStream_t s);
 bool nms_reg_supported(const NmsArgs& a);
 void launch_nms_reg(const NmsArgs& a, const float* scores, hipStream_t s);
 
-// all epochs of large problems in one cooperative launch (per-image barriers); bar [n_img] / err [1] are scratch words
+// all epochs of large problems in one launch of a co-resident grid; slots [n_img x nms_coop_slot_words(M)] / err [1] are scratch
 int nms_coop_blocks(const NmsArgs& a);
-bool launch_nms_coop(const NmsArgs& a, const float* scores, unsigned* bar, int* err, hipStream_t s);
+size_t nms_coop_slot_words(int M);
+bool launch_nms_coop(const NmsArgs& a, const float* scores, unsigned long long* slots, int* err, hipStream_t s);
 
 // NMS on the top-scoring prefix of a large candidate set (kernels_post.hip "NMS on a score prefix")
 struct PrefixArgs {
