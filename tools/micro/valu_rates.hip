@@ -17,8 +17,20 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, int iters, float 
       if (OP == 1) asm volatile("v_rcp_f32 %0, %0" : "+v"(v[i]));
       if (OP == 2) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(v[i]) : "v"(seed));
       if (OP == 3) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[i]) : "v"(seed));
+      if (OP == 7) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(v[i]) : "v"(seed), "v"(v[(i + 5) & 15]));
       if (OP == 5) asm volatile("v_sqrt_f32 %0, %0" : "+v"(v[i]));
       if (OP == 6) asm volatile("v_log_f32 %0, %0" : "+v"(v[i]));
+    }
+    if (OP == 8) {      // v_pk_fma_f32: acc pair += a pair * broadcast weight pair
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 p = {v[i], v[i + 1]};
+        const f2 q = {seed, seed};
+        const f2 r = {v[(i + 6) & 15], v[(i + 7) & 15]};
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p) : "v"(q), "v"(r));
+        v[i] = p.x; v[i + 1] = p.y;
+      }
     }
     if (OP == 4) {
 #pragma unroll
@@ -67,6 +79,8 @@ int main() {
   run<2>("v_mul_f32", 16, d_out, cus, ghz);
   run<3>("v_fma_f32", 16, d_out, cus, ghz);
   run<4>("v_pk_mul_f32", 8, d_out, cus, ghz);
+  run<7>("v_fmac_f32", 16, d_out, cus, ghz);
+  run<8>("v_pk_fma_f32", 8, d_out, cus, ghz);
   run<0>("v_exp_f32", 16, d_out, cus, ghz);
   run<1>("v_rcp_f32", 16, d_out, cus, ghz);
   run<5>("v_sqrt_f32", 16, d_out, cus, ghz);
