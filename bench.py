@@ -204,6 +204,10 @@ def main():
                     "algorithmic_bytes_per_launch": int(per_launch_bytes),
                     "tflops": round(cst["flops"] / cst["launches"] / (avg_ms * 1e-3) / 1e12, 2),
                     "share_of_step": round(dom_ms / a.steps / (elapsed / a.steps * 1e3), 3)}
+            if KIND_NAMES.get(dominant, "") == "mbx":
+                roof["note"] = ("VALU-bound family (a swish is v_exp + v_rcp: 2/3 of its issue time), VALU ~70% busy; "
+                                "plain streaming kernels reach 4.5-5.7 TB/s on this box (tools/micro/hbm_rates.hip), "
+                                "see DESIGN.md 4.3")
             tf = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tf):
                 try:
