@@ -165,31 +165,42 @@ def test_nms_kernel_bit_exact(n, tied, sigma, thr):
     d.close()
 
 
-@pytest.mark.parametrize("case", ["sparse", "dense", "all_tied", "identical_boxes", "threshold", "hard"])
-def test_nms_score_prefix_and_fallback(case):
-    """Candidate sets above 8192 run on their score prefix; when the device check rejects the prefix the problem is
-    redone on the full set.  Either way: bit-exact against the oracle's NonMaxSuppressionV5."""
-    from oracle import post_ref as P
-    p = make_params()
-    d = _driver(p, make_weights(p), 1)
+PREFIX_WORKER = r"""
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import numpy as np
+from common import make_params, make_weights
+from uda_amd.infer_lib import ServingDriver
+from oracle import post_ref as P
+p = make_params()
+d = ServingDriver("_", False, p["name"], batch_size=1, model_params=p, weights=make_weights(p))
+def rand_boxes(rng, n, span, tied):
+    c = rng.uniform(0, span, (n, 2)); wh = rng.uniform(4, 120, (n, 2))
+    b = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+    if tied:
+        s = (0.01 + rng.normal(0, 1e-4, n)).astype(np.float32)
+        s[rng.integers(0, n, n // 8)] = s[0]
+    else:
+        s = rng.uniform(0, 1, n).astype(np.float32)
+    return b, s
+for case in ("sparse", "dense", "all_tied", "identical_boxes", "threshold", "hard"):
     rng = np.random.default_rng(len(case))
     n_img, n = 3, 30000
     sigma, thr = 0.25, 0.001
-    boxes = np.zeros((n_img, n, 4), np.float32)
-    scores = np.zeros((n_img, n), np.float32)
+    boxes = np.zeros((n_img, n, 4), np.float32); scores = np.zeros((n_img, n), np.float32)
     for i in range(n_img):
-        boxes[i], scores[i] = _rand_boxes(rng, n, span=40000.0 if case == "sparse" else 400.0, tied=(case == "dense"))
-    expect_fallback = None
+        boxes[i], scores[i] = rand_boxes(rng, n, 40000.0 if case == "sparse" else 400.0, case == "dense")
+    expect = None
     if case == "sparse":
-        expect_fallback = 0                 # boxes hardly overlap: the 100 winners are the top scores
+        expect = 0                      # boxes hardly overlap: the 100 winners are the top scores
     elif case == "all_tied":
-        scores[:] = 0.37                    # more exact ties than any prefix holds
-        expect_fallback = n_img
+        scores[:] = 0.37                # more exact ties than any prefix holds
+        expect = n_img
     elif case == "identical_boxes":
-        boxes[:] = boxes[:, :1]             # every selection decays every other score: the winners fall below the cut
-        expect_fallback = n_img
+        boxes[:] = boxes[:, :1]         # every selection decays every other score: the winners fall below the cut
+        expect = n_img
     elif case == "threshold":
-        sigma, thr = 0.0, 0.5               # hard NMS, half of the candidates above the threshold
+        sigma, thr = 0.0, 0.5           # hard NMS, half of the candidates above the threshold
     elif case == "hard":
         sigma, thr = 0.0, float("-inf")
     before = d.nms_prefix_fallbacks()
@@ -197,18 +208,33 @@ def test_nms_score_prefix_and_fallback(case):
     fell = d.nms_prefix_fallbacks() - before
     for i in range(n_img):
         ridx, rsc, rvalid = P.nms_v5(boxes[i], scores[i], 100, 0.5, thr, sigma, True)
-        assert valid[i] == rvalid
-        np.testing.assert_array_equal(idx[i], ridx)
-        np.testing.assert_array_equal(sc[i], rsc)
-    assert 0 <= fell <= n_img
-    if expect_fallback is not None:
-        assert fell == expect_fallback, (case, fell)
-    d.close()
+        assert valid[i] == rvalid, (case, i)
+        assert (idx[i] == ridx).all() and (sc[i] == rsc).all(), (case, i)
+    assert 0 <= fell <= n_img and (expect is None or fell == expect), (case, fell, expect)
+    print(case, "redone", fell)
+print("prefix ok")
+d.close()
+"""
 
 
-def test_postprocess_large_anchor_set_uses_prefix_and_matches_oracle():
-    """256x384 input: 18 414 candidates per image, so the global NMS takes the score-prefix path inside the serve
-    post-process; outputs must still equal the oracle's bit for bit."""
+def test_nms_score_prefix_and_fallback():
+    """Where the co-resident grid cannot take a problem (here: switched off), candidate sets above 8192 run on their
+    score prefix; when the device check rejects the prefix the problem is redone on the full set.  Either way:
+    bit-exact against the oracle's NonMaxSuppressionV5; accepted (sparse boxes) and rejected (exact ties, decay below
+    the cut) prefixes are both exercised."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, UDA_NMS_COOP="0")
+    r = subprocess.run([sys.executable, "-c", PREFIX_WORKER % {"root": root}], cwd=root, env=e, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "prefix ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_postprocess_large_anchor_set_matches_oracle():
+    """256x384 input: 18 414 candidates per image, so the global NMS leaves the single-block kernels (co-resident grid, or
+    score prefix where that is off) inside the serve post-process; outputs must still equal the oracle's bit for bit."""
     from oracle import post_ref as P, preprocess_ref as PP
     p = make_params(image_size="384x256", **FULL_MC)
     x, scales = PP.preprocess(make_images(2, 200, 360, seed=32), (256, 384), p["mean_rgb"], p["stddev_rgb"])
@@ -595,9 +621,9 @@ d.close()
 """
 
 
-@pytest.mark.parametrize("env", [dict(UDA_NMS_PREFIX="0"), dict(UDA_NMS_PREFIX="0", UDA_NMS_COOP="0"), dict(UDA_NMS_REG="0"),
-                                 dict()],
-                         ids=["cooperative", "two-launches-per-epoch", "global-state-solo", "default"])
+@pytest.mark.parametrize("env", [dict(), dict(UDA_NMS_PREFIX="0", UDA_NMS_COOP="0"), dict(UDA_NMS_COOP="0"),
+                                 dict(UDA_NMS_REG="0", UDA_NMS_COOP="0")],
+                         ids=["co-resident-grid", "two-launches-per-epoch", "score-prefix", "global-state-solo"])
 def test_nms_paths_bit_exact(env):
     """Every NMS execution path - score prefix + register kernel (default), the cooperative single launch over several
     blocks per problem, the two-launches-per-epoch grid version, the earlier single-launch kernel - against the

@@ -39,7 +39,7 @@ def main():
     for i in range(n_img):
         boxes[i], scores[i] = detector_like(rng, k)
     p = make_params()
-    d = ServingDriver("_", False, p["name"], batch_size=1, model_params=p, weights=make_weights(p))
+    d = ServingDriver("_", False, p["name"], batch_size=n_img, model_params=p, weights=make_weights(p))
     d.profile_enable([17])
     best = None
     for rep in range(4):

@@ -1240,32 +1240,10 @@ __global__ __launch_bounds__(SOLO_T) void nms_reg_kernel(NmsArgs a, const float*
       }
     __syncthreads();
     if (tid < 64) {
-      const int begin = S.pbegin, nl = k - begin;
       const float pb[4] = {S.pbox[0], S.pbox[1], S.pbox[2], S.pbox[3]};
-      for (int s0 = 0; s0 < nl; s0 += 64) {
-        const int sl = s0 + tid;
-        if (sl < nl) {
-          const float sim = nms_iou(pb, S.sel + 4 * (k - 1 - sl));
-          float w;
-          if (a.soft || sim <= a.iou_thr) {
-            const float e = a.scale * sim * sim;
-            w = (e == 0.0f) ? 1.0f : (float)exp((double)e);
-          } else {
-            w = 0.0f;
-          }
-          if (!a.soft && sim > a.iou_thr) w = -2.0f;
-          S.wgt[sl] = w;
-        }
-      }
+      const float score = chain_wave(a, S, S.pscore, S.pbegin, pb, k);
       __builtin_amdgcn_wave_barrier();
       if (tid == 0) {
-        float score = S.pscore;
-        for (int sl = 0; sl < nl; ++sl) {
-          const float w = S.wgt[sl];
-          if (w == -2.0f) { score = -INFINITY; break; }
-          score *= w;
-          if (score <= a.score_thr) { score = -INFINITY; break; }
-        }
         S.pscore = score;
         S.L = (score != -INFINITY) ? nms_key(score, bi) - 1ull : 0ull;   // "- 1": the candidate itself passes the > L test
       }
@@ -1419,7 +1397,7 @@ constexpr int COOP_HEAVY = 1024;     // entries of the list of chains handed to 
 constexpr int COOP_HEAVY_LINKS = 6;  // overlapping links above which a chain is evaluated by a wave
 
 template <int IPT>
-__global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float* scores, unsigned long long* slots_all, int* err, int bpi) {
+__global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float* scores, unsigned long long* slots_all, int* err, int bpi, int n0) {
   // Per candidate: the stale score in a register of its thread (scanned every epoch, candidate i0 + j * 1024 + tid), the
   // cached exact score / upper bound in LDS (scanned every epoch, 128 KB), begin / epoch / a copy of the stale score in
   // the workspace arrays in memory (touched only when a chain is evaluated, together with the candidate's box).
@@ -1429,7 +1407,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
   unsigned* ebits = (unsigned*)(hlist + COOP_HEAVY);  // [IPT * 1024 / 32]
   __shared__ RegLds S;
   __shared__ int wcount, hcount;
-  const int n = blockIdx.x / bpi, blk = blockIdx.x % bpi, tid = threadIdx.x;
+  const int n = n0 + blockIdx.x / bpi, blk = blockIdx.x % bpi, tid = threadIdx.x;   // n0: first problem of this launch
   const size_t bbase = (size_t)n * a.K;           // one problem per image (segs == 1)
   const int i0 = blk * IPT * SOLO_T;
   unsigned long long* slots = slots_all + (size_t)n * a.M * 2 * COOP_MAX_BPI;      // [epoch][bound | winner][block]
@@ -1698,10 +1676,11 @@ bool launch_nms_coop(const NmsArgs& a, const float* scores, unsigned long long* 
     (void)hipGetLastError();
   }
   static const bool dbg = getenv("UDA_NMS_DEBUG") != nullptr;
-  if ((long long)bpi * a.n_img > capacity) {
-    if (dbg) fprintf(stderr, "[uda] cooperative NMS: %d x %d blocks > capacity %d\n", bpi, a.n_img, capacity);
+  if (bpi > capacity) {
+    if (dbg) fprintf(stderr, "[uda] cooperative NMS: %d blocks per problem > capacity %d\n", bpi, capacity);
     return false;
   }
+  const int per = capacity / bpi;          // problems per launch: more problems than the device holds run in consecutive grids
   hipMemsetAsync(slots, 0, (size_t)a.n_img * nms_coop_slot_words(a.M) * sizeof(unsigned long long), s);
   hipMemsetAsync(a.sel_idx, 0, (size_t)a.n_img * a.M * sizeof(int32_t), s);
   hipMemsetAsync(a.sel_score, 0, (size_t)a.n_img * a.M * sizeof(float), s);
@@ -1709,7 +1688,10 @@ bool launch_nms_coop(const NmsArgs& a, const float* scores, unsigned long long* 
   // becomes resident as soon as whatever else runs on the device drains - other kernels never wait for this one - and the
   // bounded spin is the safety net.  (hipLaunchCooperativeKernel gives the same placement plus a formal check, but
   // rocprofv3's kernel tracing crashes at process exit after a cooperative launch, ROCm 7.2.)
-  hipLaunchKernelGGL((nms_coop_kernel<COOP_IPT>), dim3((unsigned)(bpi * a.n_img)), dim3(SOLO_T), lds, s, a, scores, slots, err, bpi);
+  for (int n0 = 0; n0 < a.n_img; n0 += per) {
+    const int cnt = a.n_img - n0 < per ? a.n_img - n0 : per;
+    hipLaunchKernelGGL((nms_coop_kernel<COOP_IPT>), dim3((unsigned)(bpi * cnt)), dim3(SOLO_T), lds, s, a, scores, slots, err, bpi, n0);
+  }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     if (dbg) fprintf(stderr, "[uda] cooperative NMS: launch refused: %s\n", hipGetErrorString(e));

@@ -1005,8 +1005,16 @@ static bool run_nms(const NmsArgs& na, const float* scores, int M, hipStream_t s
     launch_nms_solo(na, scores, st);
     return false;
   }
-  // Large candidate sets: the single-launch kernel on the candidates that can be popped at all (score prefix), checked
-  // on the device, full set only for the problems the check rejects.
+  // The whole set: all epochs in one launch of a co-resident grid when the device holds it (UDA_NMS_COOP=0: never) ...
+  static int coop_on = -1;
+  if (coop_on < 0) { const char* e = getenv("UDA_NMS_COOP"); coop_on = e ? atoi(e) : 1; }
+  if (coop_on && coop.bar && coop.err && launch_nms_coop(na, scores, coop.bar + p0 * nms_coop_slot_words(M), coop.err, st)) {
+    if (coop.used) *coop.used = true;
+    return false;
+  }
+  // ... else (more than 8 x 32768 candidates per problem, or a grid the device cannot hold): the single-launch kernel on
+  // the candidates that can be popped at all (score prefix), checked on the device, full set - two launches per epoch -
+  // only for the problems the check rejects.
   if (pw && pw->Lcap > 0 && na.segs == 1 && na.K > pw->Lcap && M <= 128) {
     const size_t lc = (size_t)pw->Lcap;
     PrefixArgs pa{};
@@ -1026,14 +1034,6 @@ static bool run_nms(const NmsArgs& na, const float* scores, int M, hipStream_t s
     ca.n_img = na.n_img; ca.M = M; ca.Lcap = pw->Lcap; ca.score_thr = na.score_thr;
     launch_prefix_check(ca, st);
     return true;
-  }
-  // the whole set: all epochs in one cooperative launch when its grid is co-resident (UDA_NMS_COOP=0: never), else
-  // two launches per epoch
-  static int coop_on = -1;
-  if (coop_on < 0) { const char* e = getenv("UDA_NMS_COOP"); coop_on = e ? atoi(e) : 1; }
-  if (coop_on && coop.bar && coop.err && launch_nms_coop(na, scores, coop.bar + p0 * nms_coop_slot_words(M), coop.err, st)) {
-    if (coop.used) *coop.used = true;
-    return false;
   }
   launch_nms_init(na, scores, st);
   for (int e = 0; e < M; ++e) launch_nms_epoch(na, e, st);
