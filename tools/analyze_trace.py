@@ -83,7 +83,7 @@ if fetch or write:
 tot = sum(r[0] for r in res)
 print("chunk of %d images: %d ops, %.2f ms kernel time" % (a.chunk, nops, tot / 1e3))
 for kind in ("pw", "dw", "mbx", "sep", "se", "fuse", "stem", "pool"):
-    sel = [r for r in res if r[1].startswith(kind)]
+    sel = [r for r in res if r[1].split()[0] == kind]
     if sel:
         t = sum(r[0] for r in sel)
         print("  %-5s %8.2f ms  %7.1f GB/s  %6.1f TFLOP/s" % (kind, t / 1e3, sum(r[3] for r in sel) / t / 1e3,
