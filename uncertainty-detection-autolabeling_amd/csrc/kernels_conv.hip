@@ -75,7 +75,73 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
   *(float4*)(a.out + (size_t)gid * 4) = o;
 }
 
+// One thread = one output pixel x 16 output channels: the 27 input values of the 3x3x3 window are loaded once and
+// reused for 16 channels (the 4-channel version issued 27 loads per float4 of output and was bound by the load
+// instruction rate: 1.5 TB/s), the weights come out of LDS as broadcast float4 reads.  Same summation order.
+__global__ __launch_bounds__(256) void stem16_kernel(StemArgs a) {
+  extern __shared__ float wl[];  // [27][Co]
+  for (int i = threadIdx.x; i < 27 * a.Co; i += blockDim.x) wl[i] = a.w[i];
+  __syncthreads();
+  const int cgn = a.Co >> 4;
+  const int64_t total = (int64_t)a.rows * a.Ho * a.Wo * cgn;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  const int cg = (int)(gid % cgn);
+  int64_t p = gid / cgn;
+  const int x = (int)(p % a.Wo);
+  p /= a.Wo;
+  const int y = (int)(p % a.Ho);
+  const int b = (int)(p / a.Ho);
+  const float* inb = a.in + (size_t)b * a.H * a.W * 3;
+  float v[27];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = y * 2 - a.pad_t + ky;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = x * 2 - a.pad_l + kx;
+      const bool in = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const float* px = inb + ((size_t)(in ? iy : 0) * a.W + (in ? ix : 0)) * 3;
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci) v[(ky * 3 + kx) * 3 + ci] = in ? px[ci] : 0.f;
+    }
+  }
+  float4 acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int t = 0; t < 27; ++t) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 w = *(const float4*)(wl + t * a.Co + cg * 16 + q * 4);
+      acc[q].x = fmaf(v[t], w.x, acc[q].x);
+      acc[q].y = fmaf(v[t], w.y, acc[q].y);
+      acc[q].z = fmaf(v[t], w.z, acc[q].z);
+      acc[q].w = fmaf(v[t], w.w, acc[q].w);
+    }
+  }
+  float* op = a.out + (size_t)gid * 16;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 s = *(const float4*)(a.bn_scale + cg * 16 + q * 4);
+    const float4 t = *(const float4*)(a.bn_shift + cg * 16 + q * 4);
+    float4 o;
+    o.x = swishf(fmaf(acc[q].x, s.x, t.x));
+    o.y = swishf(fmaf(acc[q].y, s.y, t.y));
+    o.z = swishf(fmaf(acc[q].z, s.z, t.z));
+    o.w = swishf(fmaf(acc[q].w, s.w, t.w));
+    *(float4*)(op + q * 4) = o;
+  }
+}
+
 void launch_stem(const StemArgs& a, hipStream_t s) {
+  static int wide = -1;
+  if (wide < 0) { const char* e = getenv("UDA_STEM16"); wide = e ? atoi(e) : 1; }
+  if (wide && (a.Co & 15) == 0) {
+    const int64_t total = (int64_t)a.rows * a.Ho * a.Wo * (a.Co >> 4);
+    hipLaunchKernelGGL(stem16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 27 * a.Co * sizeof(float), s, a);
+    return;
+  }
   const int64_t total = (int64_t)a.rows * a.Ho * a.Wo * (a.Co >> 2);
   const int grid = (int)((total + 255) / 256);
   hipLaunchKernelGGL(stem_kernel, dim3(grid), dim3(256), 27 * a.Co * sizeof(float), s, a);
