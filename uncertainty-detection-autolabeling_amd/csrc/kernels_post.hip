@@ -270,8 +270,116 @@ __global__ __launch_bounds__(AGG_BLOCK) void aggregate_kernel(AggArgs a) {
   }
 }
 
+// The same for the common small case (T samples of both heads, C classes, T * (C + 4) <= 110 values per candidate):
+// the logits and decoded boxes of the candidate stay in REGISTERS between the mean pass and the deviation pass.  The
+// LDS-parked version holds 28 KB per 64 threads (5 waves per CU: latency-bound, 2.3 ms); this one has no LDS, all
+// T * C logit loads of a thread are in flight at once, and 16 waves fit a CU.  Same arithmetic order (bit-exact).
+template <int T, int C>
+__global__ __launch_bounds__(128) void aggregate_reg_kernel(AggArgs a) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)a.n_img * a.K) return;
+  const int n = (int)(gid / a.K);
+  int ai = (int)(gid % a.K), fixed_c = -1;
+  if (a.cand_flat) {
+    const int flat = a.cand_flat[gid];
+    ai = flat / C;
+    fixed_c = flat % C;
+  }
+  int lvl = 0;
+  while (lvl + 1 < a.lv.num_levels && ai >= a.lv.a_off[lvl + 1]) ++lvl;
+  const int loc = ai - a.lv.a_off[lvl];
+  const int p = loc / a.A, al = loc % a.A;
+  const int hw = a.lv.hw[lvl];
+  const int cch = a.A * C;
+  const float* cbase = a.lv.cls[lvl] + ((size_t)n * T * hw + p) * cch + al * C;
+  const size_t cstride = (size_t)hw * cch;
+  const float fT = (float)T;
+  float cl[T * C];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int c = 0; c < C; ++c) cl[t * C + c] = cbase[t * cstride + c];
+  float best = -INFINITY;
+  int best_c = 0;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    float m = cl[c], sd = 0.f;
+#pragma unroll
+    for (int t = 1; t < T; ++t) m = m + cl[t * C + c];
+    m = m / fT;
+    if (a.u_cls && (fixed_c < 0 || fixed_c == c)) {
+      float v = 0.f;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const float dlt = cl[t * C + c] - m;
+        v = v + dlt * dlt;
+      }
+      sd = sqrtf(v / fT);
+    }
+    a.logits[(size_t)gid * C + c] = m;
+    if (fixed_c < 0) {
+      if (a.u_cls) a.u_cls[(size_t)gid * C + c] = sd;
+      if (m > best) {
+        best = m;
+        best_c = c;
+      }
+    } else if (c == fixed_c) {
+      if (a.u_cls) a.u_cls[gid] = sd;
+      best = m;
+      best_c = c;
+    }
+  }
+  a.scores[gid] = (float)(1.0 / (1.0 + exp(-(double)best)));
+  a.classes[gid] = best_c;
+
+  const int bch = a.A * (a.loss_att ? 8 : 4);
+  const float* bbase = a.lv.box[lvl] + ((size_t)n * T * hw + p) * bch + al * 4;
+  const size_t bstride = (size_t)hw * bch;
+  const float an[4] = {a.anchors[ai * 4 + 0], a.anchors[ai * 4 + 1], a.anchors[ai * 4 + 2], a.anchors[ai * 4 + 3]};
+  float bxs[T * 4];
+  float sb[4], ss[4];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    Dec d;
+    decode_one(a, bbase + t * bstride, a.A, an, d);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sb[k] = t ? sb[k] + d.box[k] : d.box[k];
+      ss[k] = t ? ss[k] + d.sig[k] : d.sig[k];
+      bxs[t * 4 + k] = d.box[k];
+    }
+  }
+  const float fTb = (float)T;
+  float mb[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    mb[k] = sb[k] / fTb;
+    a.boxes[(size_t)gid * 4 + k] = mb[k];
+    if (a.u_al) a.u_al[(size_t)gid * 4 + k] = ss[k] / fTb;
+  }
+  if (a.u_ep) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float dlt = bxs[t * 4 + k] - mb[k];
+        v[k] = v[k] + dlt * dlt;
+      }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a.u_ep[(size_t)gid * 4 + k] = sqrtf(v[k] / fTb);
+  }
+}
+
 void launch_aggregate(const AggArgs& a0, hipStream_t s) {
   AggArgs a = a0;
+  static int regs = -1;
+  if (regs < 0) { const char* e = getenv("UDA_AGG_REG"); regs = e ? atoi(e) : 1; }
+  if (regs && a.Tc == 10 && a.Tb == 10 && a.C == 7) {
+    const int64_t tot = (int64_t)a.n_img * a.K;
+    hipLaunchKernelGGL((aggregate_reg_kernel<10, 7>), dim3((unsigned)((tot + 127) / 128)), dim3(128), 0, s, a);
+    return;
+  }
   const int64_t total = (int64_t)a.n_img * a.K;
   const int box_slots = a.Tb > 1 ? a.Tb * 4 : 0;
   a.park_all = (a.Tc * a.C + box_slots) * AGG_BLOCK * (int)sizeof(float) <= 48 * 1024;   // >= 3 blocks per CU
