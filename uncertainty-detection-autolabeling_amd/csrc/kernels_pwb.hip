@@ -980,8 +980,14 @@ void launch_mbxb(const MbxArgs& a, int rows, int k, int stride, hipStream_t s) {
 // 8 x 16 + halo for 5x5 = 8 slices) in registers; the packed expand weights of a 32-channel slab are shared
 // through a double-buffered LDS image (requested during the depthwise phase of the previous slab).
 // Per slab: expand (3 MFMAs per k-step) -> E slab in LDS -> barrier -> depthwise + output + SE sums -> barrier.
+// (the second __launch_bounds__ argument is waves per SIMD: a 512-thread block puts 2 waves on every SIMD, so "4" = two
+// blocks per CU = at most 128 VGPRs.  The 5x5 variants with up to 8 k-steps fit that once the 25 depthwise taps are read
+// from LDS at their use instead of living in registers; with two blocks per CU the expand phase of one block (MFMA +
+// transcendentals) overlaps the depthwise phase of the other (FMA + LDS) - with one block both phases run in lockstep.)
 template <int K, int KSF>
-__global__ __launch_bounds__(512, 2) void mbxd_kernel(MbxArgs a) {
+__global__ __launch_bounds__(512, (K == 5 && KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a) {
+  constexpr bool WK_LDS = (K == 5 && KSF <= 8);
+  constexpr int KY_UNROLL = WK_LDS ? 1 : K;     // (a fully unrolled tap loop hoists all 25 LDS tap reads back into registers)
   constexpr int NW = 8;
   constexpr int TH = (K == 3) ? 12 : 8, TW = 16;
   constexpr int IH = TH + K - 1, IW = TW + K - 1;
@@ -1119,9 +1125,11 @@ __global__ __launch_bounds__(512, 2) void mbxd_kernel(MbxArgs a) {
       }
     }
     // ---- depthwise on E for channel 32 ch + c
-    float wk[K * K];
+    float wk[WK_LDS ? 1 : K * K];
+    if constexpr (!WK_LDS) {
 #pragma unroll
-    for (int t = 0; t < K * K; ++t) wk[t] = pcur[t * 32 + c];
+      for (int t = 0; t < K * K; ++t) wk[t] = pcur[t * 32 + c];
+    }
     const float sc1 = pcur[K * K * 32 + c], sh1 = pcur[(K * K + 1) * 32 + c];
     float ssum = 0.f;
     if (dcol) {
@@ -1132,7 +1140,7 @@ __global__ __launch_bounds__(512, 2) void mbxd_kernel(MbxArgs a) {
         float acc[XW];
 #pragma unroll
         for (int o = 0; o < XW; ++o) acc[o] = 0.f;
-#pragma unroll
+#pragma unroll KY_UNROLL
         for (int ky = 0; ky < K; ++ky) {
           float rowv[NCOL];
           const float* er = E + ((size_t)(orow + ky) * IW + oxs) * ES + c;
@@ -1140,8 +1148,9 @@ __global__ __launch_bounds__(512, 2) void mbxd_kernel(MbxArgs a) {
           for (int j = 0; j < NCOL; ++j) rowv[j] = er[j * ES];
 #pragma unroll
           for (int kx = 0; kx < K; ++kx) {
+            const float w = WK_LDS ? pcur[(ky * K + kx) * 32 + c] : wk[WK_LDS ? 0 : ky * K + kx];
 #pragma unroll
-            for (int o = 0; o < XW; ++o) acc[o] = fmaf(rowv[o + kx], wk[ky * K + kx], acc[o]);
+            for (int o = 0; o < XW; ++o) acc[o] = fmaf(rowv[o + kx], w, acc[o]);
           }
         }
         float* op = a.out + (((size_t)b * a.Ho + oy) * a.Wo + ox0 + oxs) * a.Cmid + col;
