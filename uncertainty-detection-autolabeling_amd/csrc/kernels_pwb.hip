@@ -1175,12 +1175,302 @@ __global__ __launch_bounds__(512, (K == 5 && KSF <= 8) ? 4 : 2) void mbxd_kernel
   }
 }
 
+// ---------------------------------------------------------------- fused MBConv front half, deep blocks, pipelined
+// The variants with 13 / 14 k-steps (Cin 192 / 208) hold 104 / 112 VGPRs of operand fragments per wave, so only one
+// block fits a CU and in mbxd_kernel its two phases run in lockstep: the matrix pipe idles during the depthwise phase
+// and the VALU during the 39 dependent MFMAs of the expand.  Here every wave overlaps them itself: iteration `ch`
+// issues the MFMAs of slab ch + 1 in between the LDS reads and FMAs of the depthwise of slab ch (one straight-line
+// region; the matrix core runs asynchronously to the VALU), then activates that accumulator into the other E buffer.
+// E, the packed weights and the SE sums are double-buffered, the per-slab depthwise block triple-buffered, and ONE
+// barrier per slab remains.
+template <int K, int KSF>
+__global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
+  constexpr int NW = 8;
+  constexpr int TH = (K == 3) ? 12 : 8, TW = 16;
+  constexpr int IH = TH + K - 1, IW = TW + K - 1;
+  constexpr int NP = IH * IW;
+  static_assert(NP <= 256, "input tile must fit 8 slices of 32 pixels");
+  constexpr int NPP = 256;
+  constexpr int NG = NW * 2;
+  constexpr int ES = 33;
+  constexpr int XW = (K == 3) ? 4 : 8;
+  constexpr int UPR = TW / XW;
+  constexpr int NUNIT = TH * UPR;
+  constexpr int UPT = NUNIT / NG;             // units per thread: 3 (3x3) / 1 (5x5)
+  constexpr int NCOL = XW + K - 1;
+  constexpr int BSLAB = KSF * 2 * 64;
+  constexpr int NPAR = (K * K + 2) * 32;
+  extern __shared__ __attribute__((aligned(16))) float plds[];
+  float* E = plds;                            // [2][NPP][ES]
+  float* red = E + (size_t)2 * NPP * ES;      // [2][NG][32]
+  float* par = red + 2 * NG * 32;             // [3][NPAR]
+  uint4* Bs = (uint4*)(par + 3 * NPAR);       // [2][BSLAB]
+  float* mks = (float*)(Bs + 2 * BSLAB);      // [2][32 * NCH]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, b_in = b / a.in_div;
+  const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+  const int iy0 = oy0 - a.pad_t, ix0 = ox0 - a.pad_l;
+  const float* xin = a.in + (size_t)b_in * a.H * a.W * a.Cin;
+  const int NCH = (a.Cmid + 31) >> 5;
+  const uint4* Wp = (const uint4*)a.wsplit;
+
+  // ---- operands of slabs 0 and 1 -> LDS
+  for (int f = tid; f < 2 * BSLAB; f += 512) {
+    const int sl = f / BSLAB, r = f - sl * BSLAB;
+    const int ks = r >> 7, rest = r & 127;
+    const int ch = sl < NCH ? sl : NCH - 1;
+    Bs[f] = Wp[(((size_t)ks * NCH + ch) * 2 + (rest >> 6)) * 64 + (rest & 63)];
+  }
+  for (int f = tid; f < 2 * NPAR; f += 512) {
+    const int sl = f / NPAR;
+    par[f] = a.wpar[(size_t)(sl < NCH ? sl : NCH - 1) * NPAR + (f - sl * NPAR)];
+  }
+  for (int f = tid; f < 2 * 32 * NCH; f += 512) {
+    const int which = f / (32 * NCH), col = f - which * 32 * NCH;
+    const float* m = which ? a.mask1 : a.mask0;
+    mks[f] = ((m && col < a.Cmid) ? m[(size_t)b * a.Cmid + col] : 1.f) * UDA_NEG_LN2;
+  }
+  bf16x8 ah[KSF], al[KSF];
+  {
+    const int p = wave * 32 + li;
+    const int iy = iy0 + p / IW, ix = ix0 + p % IW;
+    const bool in = (p < NP) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    const float* px = xin + ((size_t)(in ? iy : 0) * a.W + (in ? ix : 0)) * a.Cin;
+#pragma unroll
+    for (int ks = 0; ks < KSF; ++ks) {
+      const int k = ks * 16 + 8 * lh;
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      if (in && k < a.Cin) {
+        v0 = *(const float4*)(px + k);
+        v1 = *(const float4*)(px + k + 4);
+      }
+      if (k == a.Cin) v0.x = in ? 1.f : 0.f;
+      const unsigned h0 = pack_bf16(v0.x, v0.y), h1 = pack_bf16(v0.z, v0.w);
+      const unsigned h2 = pack_bf16(v1.x, v1.y), h3 = pack_bf16(v1.z, v1.w);
+      const unsigned l0 = pack_bf16(v0.x - bf16_lo_f32(h0), v0.y - bf16_hi_f32(h0));
+      const unsigned l1 = pack_bf16(v0.z - bf16_lo_f32(h1), v0.w - bf16_hi_f32(h1));
+      const unsigned l2 = pack_bf16(v1.x - bf16_lo_f32(h2), v1.y - bf16_hi_f32(h2));
+      const unsigned l3 = pack_bf16(v1.z - bf16_lo_f32(h3), v1.w - bf16_hi_f32(h3));
+      ah[ks] = __builtin_bit_cast(bf16x8, make_uint4(h0, h1, h2, h3));
+      al[ks] = __builtin_bit_cast(bf16x8, make_uint4(l0, l1, l2, l3));
+    }
+  }
+  __syncthreads();
+
+  const int c = tid & 31, g = tid >> 5;
+  const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  constexpr int B_PER = (BSLAB + 511) / 512;
+  constexpr int P_PER = (NPAR + 511) / 512;
+
+  // ---- slab 0: expand -> E[0] (nothing to overlap with yet)
+  {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KSF; ++ks) {
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, Bs[(ks * 2 + 0) * 64 + lane]);
+      const bf16x8 bl = __builtin_bit_cast(bf16x8, Bs[(ks * 2 + 1) * 64 + lane]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh, acc, 0, 0, 0);
+    }
+    const float mk0 = mks[li];
+    float* ep = E + (size_t)(wave * 32 + 4 * lh) * ES + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swish_folded(acc[r], mk0);
+  }
+
+  for (int ch = 0; ch < NCH; ++ch) {
+    __syncthreads();      // E[ch & 1], Bs[(ch + 1) & 1], par[(ch + 1) % 3], red[(ch - 1) & 1] are complete
+    const int col = ch * 32 + c;
+    const bool dcol = col < a.Cmid;
+    const float* Ec = E + (size_t)(ch & 1) * NPP * ES;
+    float* En = E + (size_t)((ch + 1) & 1) * NPP * ES;
+    const float* pcur = par + (ch % 3) * NPAR;
+    const uint4* bnext = Bs + (size_t)((ch + 1) & 1) * BSLAB;
+    const bool more = ch + 1 < NCH, more2 = ch + 2 < NCH;
+    if (ch > 0 && a.se_partial && g == 0 && (ch - 1) * 32 + c < a.Cmid) {      // SE tile sums of the previous slab
+      const float* rp = red + ((ch - 1) & 1) * NG * 32;
+      float t = rp[c];
+#pragma unroll
+      for (int gg = 1; gg < NG; ++gg) t += rp[gg * 32 + c];
+      a.se_partial[((size_t)b * a.n_tiles + tile) * a.Cmid + (ch - 1) * 32 + c] = t;
+    }
+    // ---- operands of slab ch + 2 are requested now and written to LDS at the end of the iteration
+    uint4 nb[B_PER];
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int f = tid + 512 * i;
+      const int ks = f >> 7, rest = f & 127;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (more2 && f < BSLAB) v = Wp[(((size_t)ks * NCH + (ch + 2)) * 2 + (rest >> 6)) * 64 + (rest & 63)];
+      nb[i] = v;
+    }
+    float np_[P_PER];
+    const float* wnext = a.wpar + (size_t)(more2 ? ch + 2 : ch) * NPAR;
+#pragma unroll
+    for (int i = 0; i < P_PER; ++i) {
+      const int f = tid + 512 * i;
+      np_[i] = wnext[f < NPAR ? f : 0];
+    }
+    // ---- depthwise of slab ch, with the MFMAs of slab ch + 1 issued in between (one scheduling region)
+    float wk[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) wk[t] = pcur[t * 32 + c];
+    const float sc1 = pcur[K * K * 32 + c], sh1 = pcur[(K * K + 1) * 32 + c];
+    const float mk1 = mks[32 * NCH + ch * 32 + c];
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float dacc[UPT][XW];
+#pragma unroll
+    for (int ui = 0; ui < UPT; ++ui)
+#pragma unroll
+      for (int o = 0; o < XW; ++o) dacc[ui][o] = 0.f;
+    // The region is laid out by hand, chunk by chunk, and fenced with sched_barrier so that it stays that way (left to
+    // itself the scheduler groups all MFMAs in front of all FMAs, and the in-order wave then idles through every one of
+    // the dependent MFMAs): one MFMA - 8 passes on the matrix core - then the FMAs, the E reads of the NEXT tap row and
+    // the fragment reads of the NEXT k-step that fit under it.
+    constexpr int ROWS = UPT * K;                  // (unit, tap row) steps of the depthwise
+    constexpr int MPR = (KSF + ROWS - 1) / ROWS;   // k-steps of the expand issued per step
+    constexpr int MPS = 3 * MPR;                   // MFMAs per step
+    constexpr int NF = K * XW;                     // FMAs per step
+    constexpr int FPM = (NF + MPS - 1) / MPS, RPM = (NCOL + MPS - 1) / MPS;
+    auto e_row = [&](int st) -> const float* {
+      const int ui = st / K, ky = st % K;
+      const int u = g + NG * ui;
+      const int orow = u / UPR, oxs = (u % UPR) * XW;
+      return Ec + ((size_t)(orow + ky) * IW + oxs) * ES + c;
+    };
+    float rowv[2][NCOL];
+    {
+      const float* er = e_row(0);
+#pragma unroll
+      for (int j = 0; j < NCOL; ++j) rowv[0][j] = er[j * ES];
+    }
+    bf16x8 bh_c = __builtin_bit_cast(bf16x8, bnext[lane]), bl_c = __builtin_bit_cast(bf16x8, bnext[64 + lane]);
+    bf16x8 bh_n = bh_c, bl_n = bl_c;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int st = 0; st < ROWS; ++st) {
+      const int ui = st / K, ky = st % K;
+      const float* ern = e_row(st + 1 < ROWS ? st + 1 : st);
+#pragma unroll
+      for (int m = 0; m < MPS; ++m) {
+        const int ks = st * MPR + m / 3, t = m % 3;
+        if (ks < KSF) {
+          if (t == 0 && ks + 1 < KSF) {
+            bh_n = __builtin_bit_cast(bf16x8, bnext[((ks + 1) * 2 + 0) * 64 + lane]);
+            bl_n = __builtin_bit_cast(bf16x8, bnext[((ks + 1) * 2 + 1) * 64 + lane]);
+          }
+          if (t == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh_c, acc, 0, 0, 0);
+          if (t == 1) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl_c, acc, 0, 0, 0);
+          if (t == 2) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh_c, acc, 0, 0, 0);
+            bh_c = bh_n; bl_c = bl_n;
+          }
+        }
+#pragma unroll
+        for (int f = m * FPM; f < (m + 1) * FPM; ++f)
+          if (f < NF) {
+            const int kx = f / XW, o = f % XW;
+            dacc[ui][o] = fmaf(rowv[st & 1][o + kx], wk[ky * K + kx], dacc[ui][o]);
+          }
+        if (st + 1 < ROWS) {
+#pragma unroll
+          for (int r = m * RPM; r < (m + 1) * RPM; ++r)
+            if (r < NCOL) rowv[(st + 1) & 1][r] = ern[r * ES];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // (pin the sums here: otherwise the FMAs are sunk into the guarded store blocks below, behind all the MFMAs)
+#pragma unroll
+    for (int ui = 0; ui < UPT; ++ui)
+#pragma unroll
+      for (int o = 0; o < XW; ++o) asm volatile("" : "+v"(dacc[ui][o]));
+    // ---- outputs of slab ch
+    float ssum = 0.f;
+    if (dcol) {
+#pragma unroll
+      for (int ui = 0; ui < UPT; ++ui) {
+        const int u = g + NG * ui;
+        const int orow = u / UPR, oxs = (u % UPR) * XW;
+        const int oy = oy0 + orow;
+        if (oy >= a.Ho) continue;
+        float* op = a.out + (((size_t)b * a.Ho + oy) * a.Wo + ox0 + oxs) * a.Cmid + col;
+#pragma unroll
+        for (int o = 0; o < XW; ++o) {
+          if (ox0 + oxs + o < a.Wo) {
+            const float v = swish_folded(fmaf(dacc[ui][o], sc1, sh1), mk1);
+            op[(size_t)o * a.Cmid] = v;
+            ssum += v;
+          }
+        }
+      }
+    }
+    if (a.se_partial) red[((ch & 1) * NG + g) * 32 + c] = ssum;
+    // ---- slab ch + 1: activate -> the other E buffer (its readers, depthwise ch - 1, finished before the barrier above)
+    if (more) {
+      const float mk0 = mks[(ch + 1) * 32 + li];
+      float* ep = En + (size_t)(wave * 32 + 4 * lh) * ES + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swish_folded(acc[r], mk0);
+    }
+    // ---- slab ch + 2 operands -> LDS: Bs[ch & 1] (its MFMAs were issued one iteration ago), par[(ch + 2) % 3]
+    {
+      uint4* bw = Bs + (size_t)(ch & 1) * BSLAB;
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i) {
+        const int f = tid + 512 * i;
+        if (more2 && f < BSLAB) bw[f] = nb[i];
+      }
+      float* pw = par + ((ch + 2) % 3) * NPAR;
+#pragma unroll
+      for (int i = 0; i < P_PER; ++i) {
+        const int f = tid + 512 * i;
+        if (more2 && f < NPAR) pw[f] = np_[i];
+      }
+    }
+  }
+  if (a.se_partial) {
+    __syncthreads();
+    const int lc = (NCH - 1) * 32 + c;
+    if (g == 0 && lc < a.Cmid) {
+      const float* rp = red + ((NCH - 1) & 1) * NG * 32;
+      float t = rp[c];
+#pragma unroll
+      for (int gg = 1; gg < NG; ++gg) t += rp[gg * 32 + c];
+      a.se_partial[((size_t)b * a.n_tiles + tile) * a.Cmid + lc] = t;
+    }
+  }
+}
+
+template <int K, int KSF>
+static void launch_mbxp_t(const MbxArgs& a, int rows, hipStream_t s) {
+  constexpr int TH = (K == 3) ? 12 : 8;
+  const size_t lds = ((size_t)2 * 256 * 33 + 2 * 16 * 32 + 3 * (K * K + 2) * 32 + 2 * 32 * ((a.Cmid + 31) / 32)) * sizeof(float) +
+                     (size_t)2 * KSF * 2 * 64 * sizeof(uint4);
+  static size_t attr_lds = 64 * 1024;
+  if (lds > attr_lds) {
+    hipFuncSetAttribute((const void*)mbxp_kernel<K, KSF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_lds = lds;
+  }
+  const dim3 grid((a.Wo + 15) / 16, (a.Ho + TH - 1) / TH, rows);
+  hipLaunchKernelGGL((mbxp_kernel<K, KSF>), grid, dim3(512), lds, s, a);
+}
+
 bool mbxd_supported(int Cin, int Cmid, int k, int stride) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("UDA_FUSE_MBXD"); on = e ? atoi(e) : 1; }
   const int ksf = (Cin + 1 + 15) / 16;
+  static int maxksf = -1;
+  if (maxksf < 0) { const char* e = getenv("UDA_MBXD_MAXKSF"); maxksf = e ? atoi(e) : 14; }
   return on && stride == 1 && (k == 3 || k == 5) && Cin % 8 == 0 && Cin > 48 && (ksf == 6 || ksf == 8 || ksf == 13 || ksf == 14) &&
-         Cmid % 4 == 0;
+         ksf <= maxksf && Cmid % 4 == 0;
 }
 
 int mbxd_tiles(int Ho, int Wo, int k) {
@@ -1204,6 +1494,13 @@ static void launch_mbxd_t(const MbxArgs& a, int rows, hipStream_t s) {
 
 void launch_mbxd(const MbxArgs& a, int rows, int k, hipStream_t s) {
   const int ksf = (a.Cin + 1 + 15) / 16;
+  static int pipe = -1;
+  if (pipe < 0) { const char* e = getenv("UDA_MBXP"); pipe = e ? atoi(e) : 1; }
+  if (pipe && ksf >= 13) {          // one block per CU anyway: the self-overlapping variant
+    if (k == 3) { if (ksf == 13) launch_mbxp_t<3, 13>(a, rows, s); else launch_mbxp_t<3, 14>(a, rows, s); }
+    else { if (ksf == 13) launch_mbxp_t<5, 13>(a, rows, s); else launch_mbxp_t<5, 14>(a, rows, s); }
+    return;
+  }
   if (k == 3) {
     switch (ksf) {
       case 6: launch_mbxd_t<3, 6>(a, rows, s); break;

@@ -75,7 +75,8 @@ def mbx_supported(cin, cmid, k, stride):
         return False
     if mbx_deep(cin):       # mirror of mbxd_supported: stride 1, 16-deep k-steps of Cin + 1 in {6, 8, 13, 14}, split-bf16 path on
         return (int(os.environ.get("UDA_FUSE_MBXD", "1")) and int(os.environ.get("UDA_PW_TERMS", "3")) != 0
-                and int(os.environ.get("UDA_MBX_BF16", "1")) and stride == 1 and (cin + 1 + 15) // 16 in (6, 8, 13, 14))
+                and int(os.environ.get("UDA_MBX_BF16", "1")) and stride == 1 and (cin + 1 + 15) // 16 in (6, 8, 13, 14)
+                and (cin + 1 + 15) // 16 <= int(os.environ.get("UDA_MBXD_MAXKSF", "14")))
     return 16 <= cin and stride in (1, 2)
 
 
