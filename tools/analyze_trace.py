@@ -39,7 +39,7 @@ def pmc_per_op(path, counter, scale):
 
 
 rows = list(csv.DictReader(open(a.trace)))
-names = ("stem_kernel", "stem16_kernel", "pw_kernel", "pwb_kernel", "pwb_shared_kernel", "dw_kernel", "se_kernel", "fuse_kernel", "mbx_kernel", "mbxb_kernel", "mbxd_kernel", "sep_kernel")
+names = ("stem_kernel", "stem16_kernel", "pw_kernel", "pwb_kernel", "pwb_shared_kernel", "dw_kernel", "se_kernel", "fuse_kernel", "mbx_kernel", "mbxb_kernel", "mbxd_kernel", "mbxp_kernel", "sep_kernel")
 idx = [i for i, r in enumerate(rows) if "preprocess" in r["Kernel_Name"]]
 rows = rows[idx[-1]:]
 conv = [r for r in rows if any(n in r["Kernel_Name"] for n in names)]
