@@ -254,7 +254,9 @@ def test_postprocess_large_anchor_set_matches_oracle():
 @pytest.mark.parametrize("name,over", [("plain", PLAIN), ("lossatt", LOSS_ATT), ("full_mc", FULL_MC),
                                        ("head_mc", HEAD_MC), ("mc_noatt", MC_NO_ATT), ("box_only", BOX_ONLY_MC),
                                        ("full_mc_t10", dict(FULL_MC, mc_dropoutsamp=10)),      # register-resident aggregate
-                                       ("mc_noatt_t10", dict(MC_NO_ATT, mc_dropoutsamp=10))])
+                                       ("mc_noatt_t10", dict(MC_NO_ATT, mc_dropoutsamp=10)),
+                                       ("full_mc_t10_c3", dict(FULL_MC, mc_dropoutsamp=10, num_classes=3)),     # runtime class loop
+                                       ("full_mc_t20_c10", dict(FULL_MC, mc_dropoutsamp=20, num_classes=10))])  # BDD-like
 def test_postprocess_bit_exact_on_oracle_heads(name, over):
     """Same head outputs in -> the HIP post-process must reproduce the oracle's output tuple exactly."""
     from oracle import post_ref as P, preprocess_ref as PP

@@ -274,8 +274,9 @@ __global__ __launch_bounds__(AGG_BLOCK) void aggregate_kernel(AggArgs a) {
 // the logits and decoded boxes of the candidate stay in REGISTERS between the mean pass and the deviation pass.  The
 // LDS-parked version holds 28 KB per 64 threads (5 waves per CU: latency-bound, 2.3 ms); this one has no LDS, all
 // T * C logit loads of a thread are in flight at once, and 16 waves fit a CU.  Same arithmetic order (bit-exact).
-template <int T, int C>
+template <int T, int CT>     // CT = 0: any number of classes, one class at a time (T logits in registers per class)
 __global__ __launch_bounds__(128) void aggregate_reg_kernel(AggArgs a) {
+  const int C = CT ? CT : a.C;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (int64_t)a.n_img * a.K) return;
   const int n = (int)(gid / a.K);
@@ -294,24 +295,18 @@ __global__ __launch_bounds__(128) void aggregate_reg_kernel(AggArgs a) {
   const float* cbase = a.lv.cls[lvl] + ((size_t)n * T * hw + p) * cch + al * C;
   const size_t cstride = (size_t)hw * cch;
   const float fT = (float)T;
-  float cl[T * C];
-#pragma unroll
-  for (int t = 0; t < T; ++t)
-#pragma unroll
-    for (int c = 0; c < C; ++c) cl[t * C + c] = cbase[t * cstride + c];
   float best = -INFINITY;
   int best_c = 0;
+  auto one_class = [&](int c, const float* x) {       // x[t] = logit of sample t
+    float m = x[0], sd = 0.f;
 #pragma unroll
-  for (int c = 0; c < C; ++c) {
-    float m = cl[c], sd = 0.f;
-#pragma unroll
-    for (int t = 1; t < T; ++t) m = m + cl[t * C + c];
+    for (int t = 1; t < T; ++t) m = m + x[t];
     m = m / fT;
     if (a.u_cls && (fixed_c < 0 || fixed_c == c)) {
       float v = 0.f;
 #pragma unroll
       for (int t = 0; t < T; ++t) {
-        const float dlt = cl[t * C + c] - m;
+        const float dlt = x[t] - m;
         v = v + dlt * dlt;
       }
       sd = sqrtf(v / fT);
@@ -327,6 +322,27 @@ __global__ __launch_bounds__(128) void aggregate_reg_kernel(AggArgs a) {
       if (a.u_cls) a.u_cls[gid] = sd;
       best = m;
       best_c = c;
+    }
+  };
+  if constexpr (CT > 0) {
+    float cl[T * (CT ? CT : 1)];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) cl[t * CT + c] = cbase[t * cstride + c];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      float x[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) x[t] = cl[t * CT + c];
+      one_class(c, x);
+    }
+  } else {
+    for (int c = 0; c < C; ++c) {
+      float x[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) x[t] = cbase[t * cstride + c];
+      one_class(c, x);
     }
   }
   a.scores[gid] = (float)(1.0 / (1.0 + exp(-(double)best)));
@@ -375,9 +391,12 @@ void launch_aggregate(const AggArgs& a0, hipStream_t s) {
   AggArgs a = a0;
   static int regs = -1;
   if (regs < 0) { const char* e = getenv("UDA_AGG_REG"); regs = e ? atoi(e) : 1; }
-  if (regs && a.Tc == 10 && a.Tb == 10 && a.C == 7) {
+  if (regs && a.Tc == a.Tb && (a.Tc == 10 || a.Tc == 20)) {
     const int64_t tot = (int64_t)a.n_img * a.K;
-    hipLaunchKernelGGL((aggregate_reg_kernel<10, 7>), dim3((unsigned)((tot + 127) / 128)), dim3(128), 0, s, a);
+    const dim3 grid((unsigned)((tot + 127) / 128)), block(128);
+    if (a.Tc == 10 && a.C == 7) hipLaunchKernelGGL((aggregate_reg_kernel<10, 7>), grid, block, 0, s, a);
+    else if (a.Tc == 10) hipLaunchKernelGGL((aggregate_reg_kernel<10, 0>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((aggregate_reg_kernel<20, 0>), grid, block, 0, s, a);
     return;
   }
   const int64_t total = (int64_t)a.n_img * a.K;
