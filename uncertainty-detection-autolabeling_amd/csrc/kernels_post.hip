@@ -1555,6 +1555,8 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
   // (the padded form of the outputs - index 0 / score 0 in the slots that stay empty - is written by the launcher's
   // memsets: a slot must have ONE writer inside the kernel, the L2s of different XCDs are not coherent with each other)
   int nsel = 0;
+  if (tid == 0) { wcount = 0; hcount = 0; }
+  for (int f = tid; f < IPT * 32; f += SOLO_T) ebits[f] = 0u;
   __syncthreads();
 
   // Exact scores (epoch k: links begin .. k-1, newest first) of the candidates flagged in the threads' bit masks.  These
@@ -1565,8 +1567,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
   // stale / begin / box come from memory in one round trip; "already exact in this epoch" is a bit per candidate in
   // LDS.  `fn(rel, v)` receives every candidate with its exact score, once, from some thread.
   auto run_balanced = [&](unsigned mask, int k, auto&& fn) {
-    if (tid == 0) { wcount = 0; hcount = 0; }
-    __syncthreads();
+    // (wcount / hcount are 0 here: reset at the end of the previous call, with block barriers in between)
     unsigned left = 0u;
     {
       unsigned m = mask;
@@ -1618,6 +1619,10 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
                     atomicAdd(&g_nms_dbg3[4], tb1 - tb0); atomicMax(&g_nms_dbg3[5], tb1 - tb0); }
 #endif
     const int hc = hcount < COOP_HEAVY ? hcount : COOP_HEAVY;
+    if (hc == 0) {                           // the common case: no heavy chain, one barrier less
+      if (tid == 0) wcount = 0;
+      return;
+    }
     for (int e = tid >> 6; e < hc; e += SOLO_T / 64) {
       const int rel = hlist[e];
       const size_t g = bbase + i0 + rel;
@@ -1634,6 +1639,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
 #ifdef UDA_NMS_STATS
     if (tid == 0) { const unsigned long long tb2 = wall_clock64(); atomicAdd(&g_nms_dbg3[6], tb2 - tb1); atomicMax(&g_nms_dbg3[7], tb2 - tb1); }
 #endif
+    if (tid == 0) { wcount = 0; hcount = 0; }
   };
 
   for (int k = 0; k < a.M; ++k) {
@@ -1661,9 +1667,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
       if (bo != 0u) bk = ((unsigned long long)bo << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)(ib + bj * SOLO_T));
     }
     bk = reg_max(S, bk);
-    ebits[tid] = 0u;                         // IPT * 1024 / 32 = IPT * 32 words: one per thread when IPT == 32
-    if (IPT * 32 > SOLO_T) for (int f = tid + SOLO_T; f < IPT * 32; f += SOLO_T) ebits[f] = 0u;
-    __syncthreads();
+
     if (bk != 0ull && tid < 64) {
       const int bi = (int)(0xFFFFFFFFu - (uint32_t)bk);
       const size_t g = bbase + bi;
@@ -1754,6 +1758,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
     for (int j = 0; j < IPT; ++j)
       if ((pops >> j) & 1u) st[j] = U[j * SOLO_T + tid];
     nsel = k + 1;
+    for (int f = tid; f < IPT * 32; f += SOLO_T) ebits[f] = 0u;      // "exact in this epoch" bits of the next epoch
     __syncthreads();
 #ifdef UDA_NMS_STATS
     if (tid == 0) {
