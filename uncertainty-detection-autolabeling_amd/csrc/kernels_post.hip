@@ -1806,6 +1806,7 @@ bool launch_nms_coop(const NmsArgs& a, const float* scores, unsigned long long* 
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nms_coop_kernel<COOP_IPT>, SOLO_T, lds) == hipSuccess)
       capacity = per_cu * prop.multiProcessorCount;
     (void)hipGetLastError();
+    if (const char* e = getenv("UDA_NMS_COOP_CAP")) capacity = atoi(e);     // test hook: a wrong capacity must end in the time-out path, not in a hang
   }
   static const bool dbg = getenv("UDA_NMS_DEBUG") != nullptr;
   if (bpi > capacity) {
