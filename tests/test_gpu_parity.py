@@ -644,6 +644,43 @@ def test_nms_paths_bit_exact(env):
     assert r.returncode == 0 and "nms paths ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
+OVERSUB_WORKER = r"""
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import numpy as np
+from common import make_params, make_weights
+from uda_amd.infer_lib import ServingDriver
+from oracle import post_ref as P
+p = make_params()
+n_img, n = 64, 150000          # 64 problems x 5 blocks = 320 blocks of 1024 threads, one per CU: more than the device holds
+d = ServingDriver("_", False, p["name"], batch_size=n_img, model_params=p, weights=make_weights(p))
+rng = np.random.default_rng(1)
+c = rng.uniform(0, 600.0, (n_img, n, 2)); wh = rng.uniform(4, 120, (n_img, n, 2))
+boxes = np.concatenate([c - wh / 2, c + wh / 2], 2).astype(np.float32)
+scores = rng.uniform(0, 1, (n_img, n)).astype(np.float32)
+idx, sc, valid = d.nms(boxes, scores, 100, 0.5, 0.001, 0.25)
+for i in (0, 31, 63):
+    ridx, rsc, rvalid = P.nms_v5(boxes[i], scores[i], 100, 0.5, 0.001, 0.25, True)
+    assert valid[i] == rvalid and (idx[i] == ridx).all() and (sc[i] == rsc).all(), i
+print("oversubscribed ok")
+d.close()
+"""
+
+
+def test_nms_grid_larger_than_the_device_completes():
+    """The single-launch NMS needs the blocks of a problem resident together.  With the capacity check overridden the
+    grid is larger than the device: it must still complete (blocks are dispatched in order, finished problems free their
+    CUs; the bounded spin is the safety net) and return the oracle's selections."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, UDA_NMS_COOP_CAP="100000")
+    r = subprocess.run([sys.executable, "-c", OVERSUB_WORKER % {"root": root}], cwd=root, env=e, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and "oversubscribed ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_box_uncertainty_calibration_matches_reference_restatement():
     """SURVEY 8f.2 on the device: every calibrate_boxuncert method on the selected rows against the numpy restatement."""
     from oracle import calib_ref as CR
