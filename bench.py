@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Headline benchmark: images x MC-samples / s (and p50 serve latency) of the MC-dropout
+"""Headline benchmark: images x MC-samples / s (and p50 detect latency) of the MC-dropout
 EfficientDet-D0 path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
@@ -11,10 +11,17 @@ decode -> NonMaxSuppressionV5 -> packed detections, for `--batch` images per GPU
 every rank owns its own shard of images; the only exchange is the all-gather of the KB-scale
 detection records at the end of each step).  Workload = BASELINE.json configs[1]: D0, 32 synthetic
 KITTI-resolution images (1280x768), T=10, full MC dropout + loss attenuation, C=7.
+`--config 2|3|4` selects the per-GPU share of BASELINE configs[2] (BDD-like, C=10, T=20), [3]
+(5-member deep ensemble, members striped over the ranks) or [4] (D2 at 1024x1024, T=30, per-class NMS).
 
 Prints ONE JSON line (rank 0) with the driver's contract plus
-  roofline     dominant kernel kind: algorithmic bytes / HIP-event device time vs the 8 TB/s HBM peak
-  cpu_baseline the CPU oracle (restatement, not TF) timed on a bounded sample in a subprocess
+  roofline       dominant kernel kind: algorithmic bytes / HIP-event device time vs the 8 TB/s HBM peak
+  cpu_baseline   the CPU oracle (restatement, not TF) timed on a bounded sample in a subprocess
+  precision      ms_per_step of the same workload with six-term ("float32-equivalent") and exact f32-input
+                 MFMA products, each measured in a child process that sets the switch before its first GPU call
+  h2d_inclusive  ms_per_step with the uint8 batch uploaded inside every step (the reference times serve(image)
+                 including the feed, validate_model.py:154-158)
+  p50_detect_latency_ms   batch-1 serve() of one image, T as configured, upload and download included
 """
 import argparse
 import json
@@ -36,6 +43,8 @@ KIND_KERNELS = {"stem": "stem16_kernel", "pw": "pwb_kernel", "dw": "dw_kernel", 
                 "pool": "fuse_kernel", "mbx": "mbxb_kernel+mbxd_kernel+mbxp_kernel", "sep": "sep_kernel", "aggregate": "aggregate_reg_kernel",
                 "nms": "nms_coop_kernel", "preprocess": "preprocess_kernel"}
 LAYERWISE_MB_PER_UNIT = {("efficientdet-d0", "1280x768", 7): 1798.7}   # SURVEY 8d, full MC
+CONFIG_NAMES = {1: "BASELINE configs[1]", 2: "BASELINE configs[2], per-GPU share", 3: "BASELINE configs[3]",
+                4: "BASELINE configs[4], per-GPU share"}
 
 
 def parse():
@@ -43,33 +52,51 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
-    ap.add_argument("--samples", type=int, default=10, help="MC samples T")
-    ap.add_argument("--image-size", default="1280x768", help="WxH as the reference writes it")
-    ap.add_argument("--classes", type=int, default=7)
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4], help="BASELINE.json configs index (1 = the headline)")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step")
+    ap.add_argument("--samples", type=int, default=None, help="MC samples T")
+    ap.add_argument("--image-size", default=None, help="WxH as the reference writes it")
+    ap.add_argument("--raw-size", default=None, help="WxH of the raw uint8 images (default: the network size)")
+    ap.add_argument("--classes", type=int, default=None)
     ap.add_argument("--variant", default="full", choices=["full", "head"],
                     help="full: mc_dropoutrate=0.05 everywhere; head: class/box head dropout only")
-    ap.add_argument("--chunk", type=int, default=32, help="images per pass of the op list")
-    ap.add_argument("--model", default="efficientdet-d0")
+    ap.add_argument("--chunk", type=int, default=None, help="images per pass of the op list")
+    ap.add_argument("--model", default=None)
+    ap.add_argument("--post-mode", default=None, choices=["global", "per_class"])
+    ap.add_argument("--ensemble", type=int, default=0, help="deep ensemble of this many deterministic members instead of MC dropout")
     ap.add_argument("--cls-spread", type=float, default=1.0,
                     help="scale of the class-head output layer: 1 = the reference initialiser (near-tied scores), "
                          "larger = spread-out scores as a trained head gives (side measurement, never the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side", action="store_true", help="skip the precision children, the H2D-inclusive and the batch-1 legs")
+    ap.add_argument("--child", action="store_true", help="(internal) GPU leg only, short JSON")
     ap.add_argument("--force-dist", action="store_true", help="use the process group (RCCL) path even at world size 1")
-    ap.add_argument("--cpu-sample-t", type=int, default=10)
-    ap.add_argument("--cpu-sample-images", type=int, default=4)
-    return ap.parse_args()
+    ap.add_argument("--cpu-sample-images", type=int, default=1)
+    a = ap.parse_args()
+    preset = {1: dict(batch=32, samples=10, image_size="1280x768", classes=7, model="efficientdet-d0", post_mode="global"),
+              2: dict(batch=32, samples=20, image_size="1280x768", raw_size="1280x720", classes=10, model="efficientdet-d0",
+                      post_mode="global"),
+              3: dict(batch=8, samples=1, image_size="1280x768", classes=7, model="efficientdet-d0", post_mode="global", ensemble=5),
+              4: dict(batch=2, samples=30, image_size="1024x1024", classes=7, model="efficientdet-d2", post_mode="per_class")}[a.config]
+    for k, v in preset.items():
+        if getattr(a, k) in (None, 0):
+            setattr(a, k, v)
+    if a.raw_size is None:
+        a.raw_size = a.image_size
+    if a.chunk is None:
+        a.chunk = a.batch
+    return a
 
 
 def make_params(a):
     from uda_amd import hparams_config
     cfg = hparams_config.get_efficientdet_config(a.model)
-    over = dict(image_size=a.image_size, num_classes=a.classes, mc_dropout=True, mc_dropoutsamp=a.samples,
-                loss_attenuation=True, enable_softmax=True)
-    if a.variant == "full":
-        over.update(mc_dropoutrate=0.05)
-    else:
-        over.update(mc_classheadrate=0.05, mc_boxheadrate=0.05)
+    over = dict(image_size=a.image_size, num_classes=a.classes, loss_attenuation=True, enable_softmax=True)
+    if not a.ensemble:
+        over.update(mc_dropout=True, mc_dropoutsamp=a.samples)
+        over.update(dict(mc_dropoutrate=0.05) if a.variant == "full" else dict(mc_classheadrate=0.05, mc_boxheadrate=0.05))
+    if a.config == 4:           # eval settings (eval.py:75)
+        over.update(nms_configs=dict(max_nms_inputs=5000))
     cfg.override(over)
     p = cfg.as_dict()
     p["is_training_bn"] = False
@@ -79,15 +106,31 @@ def make_params(a):
 def cpu_baseline(a):
     """Oracle timed in a clean subprocess (no GPU runtime in that process)."""
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--image-size", a.image_size,
-           "--classes", str(a.classes), "--samples", str(a.cpu_sample_t), "--images", str(a.cpu_sample_images), "--variant", a.variant,
-           "--model", a.model]
+           "--classes", str(a.classes), "--samples", str(max(a.samples, 1)), "--images", str(a.cpu_sample_images),
+           "--variant", a.variant, "--model", a.model]
     try:
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
         return json.loads(line)
     except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
         return {"value": None, "unit": "images*MC-samples/s", "cores": None, "kind": "port",
                 "sample": "failed: %r" % (e,)}
+
+
+def precision_child(a, terms):
+    """ms_per_step of the same workload with UDA_PW_TERMS=<terms>, in a child started with the switch in its environment
+    (the library reads it once, at its first call)."""
+    env = dict(os.environ, UDA_PW_TERMS=str(terms))
+    cmd = [sys.executable, os.path.abspath(__file__), "--child", "--no-cpu-baseline", "--no-side", "--steps", str(max(2, min(a.steps, 3))),
+           "--warmup", "1", "--config", str(a.config), "--batch", str(a.batch), "--samples", str(a.samples), "--image-size", a.image_size,
+           "--raw-size", a.raw_size, "--classes", str(a.classes), "--variant", a.variant, "--chunk", str(a.chunk), "--model", a.model,
+           "--post-mode", a.post_mode, "--ensemble", str(a.ensemble)]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as e:
+        return {"ms_per_step": None, "error": repr(e)}
 
 
 def log(msg):
@@ -103,6 +146,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    tdev = None
     if world > 1 or a.gpus > 1 or a.force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch                    # torch first: the HIP library then binds to the same runtime
@@ -122,16 +166,20 @@ def main():
             os.dup2(saved, 1)
             os.close(saved)
 
-    from uda_amd import capi, plan as plan_mod, weights as weights_mod
-    from uda_amd.infer_lib import ServingDriver
+    from uda_amd import plan as plan_mod, weights as weights_mod
+    from uda_amd.infer_lib import EnsembleDriver, KerasDriver
 
     params = make_params(a)
-    w = weights_mod.init_weights(params, seed=0, cls_spread=a.cls_spread)
-    drv = ServingDriver("_", False, a.model, batch_size=a.batch, model_params=params, weights=w,
-                        device=local_rank, chunk_images=min(a.chunk, a.batch))
-    W_, H_ = [int(v) for v in a.image_size.lower().split("x")]
+    W_, H_ = [int(v) for v in a.raw_size.lower().split("x")]
     images = np.random.default_rng(2 + rank).integers(0, 256, (a.batch, H_, W_, 3), dtype=np.uint8)
+    terms = os.environ.get("UDA_PW_TERMS", "3")
 
+    if a.ensemble:
+        return ensemble_main(a, params, images, rank, world, local_rank, dist, tdev)
+
+    w = weights_mod.init_weights(params, seed=0, cls_spread=a.cls_spread)
+    drv = KerasDriver("_", False, a.model, a.batch, False, params, weights=w, device=local_rank,
+                      chunk_images=min(a.chunk, a.batch), post_mode=a.post_mode)
     log("driver ready: %s" % (drv.plan.summary(),))
     drv.set_image_offset(rank * a.batch)           # Philox rows of the global (weak-scaled) batch
     t_up = time.perf_counter()
@@ -143,7 +191,9 @@ def main():
             dist.barrier()
         drv.synchronize()
 
-    def step():
+    def step(upload=False):
+        if upload:
+            drv.stage_images(images)
         drv.run_resident(sync=True)
         det = drv._collect(a.batch)
         if dist is not None:
@@ -153,7 +203,7 @@ def main():
 
     # warm-up; the last warm-up step also ranks the kernel kinds by device time.  The very first call of a handle is
     # set-up (lazy allocations, and the global NMS probes whether a score prefix suffices for this score distribution,
-    # see DESIGN.md section 5), so there are always at least two untimed steps.
+    # see DESIGN.md section 5), so there are always at least two untimed steps (`warmup_steps_run` in the line).
     kinds = [1, 2, 3, 4, 5, 6, 7, 8, 16, 17, 18]
     calib = {}
     n_warm = max(2, a.warmup)
@@ -185,9 +235,46 @@ def main():
         elapsed = float(t.item())
 
     dom_ms, dom_launches = drv.profile_read(dominant)
+    drv.profile_enable([])
     costs = plan_mod.op_costs(drv.plan, a.batch)
     units = world * a.batch * a.samples * a.steps
     value = units / elapsed
+
+    if a.child:
+        if rank == 0:
+            print(json.dumps({"ms_per_step": round(elapsed / a.steps * 1e3, 2), "UDA_PW_TERMS": terms,
+                              "kernel_ms_per_step": {KIND_NAMES.get(k, str(k)): round(v[0], 2) for k, v in calib.items()}}), flush=True)
+        drv.close()
+        return
+
+    # ---- side legs (rank 0 of a single-GPU run only; never part of `value`)
+    side = {}
+    if world == 1 and not a.no_side:
+        k_side = max(3, a.steps)
+        drv.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(k_side):
+            step(upload=True)
+        drv.synchronize()
+        side["h2d_inclusive"] = {"ms_per_step": round((time.perf_counter() - t1) / k_side * 1e3, 2),
+                                 "note": "uint8 batch (%.0f MB, pageable host memory) uploaded inside every step" % (images.nbytes / 1e6)}
+    coop_fb, pfx_fb = drv.nms_coop_fallbacks(), drv.nms_prefix_fallbacks()
+    summary = drv.plan.summary()
+    drv.close()
+    if world == 1 and not a.no_side:
+        d1 = KerasDriver("_", False, a.model, 1, False, params, weights=w, device=local_rank, chunk_images=1, post_mode=a.post_mode)
+        one = images[:1]
+        for _ in range(3):
+            d1.serve(one)
+        l1 = []
+        for _ in range(20):
+            ts = time.perf_counter()
+            d1.serve(one)
+            l1.append(time.perf_counter() - ts)
+        side["p50_detect_latency_ms"] = round(float(np.median(l1)) * 1e3, 2)
+        side["detect_latency_note"] = "batch 1, T=%d, serve(image) = upload + preprocess + network x T + post-process + download; 20 calls" % a.samples
+        coop_fb += d1.nms_coop_fallbacks()
+        d1.close()
 
     if rank == 0:
         roof = None
@@ -205,47 +292,118 @@ def main():
                     "tflops": round(cst["flops"] / cst["launches"] / (avg_ms * 1e-3) / 1e12, 2),
                     "share_of_step": round(dom_ms / a.steps / (elapsed / a.steps * 1e3), 3)}
             if KIND_NAMES.get(dominant, "") == "mbx":
-                roof["note"] = ("VALU-bound family (a swish is v_exp + v_rcp: 2/3 of its issue time), VALU ~70% busy; "
-                                "plain streaming kernels reach 4.5-5.7 TB/s on this box (tools/micro/hbm_rates.hip), "
-                                "see DESIGN.md 4.3")
+                roof["note"] = ("fused MBConv front halves: VALU / occupancy-bound (two transcendentals per swish), not a streaming "
+                                "kernel; plain streaming kernels reach 4.5-5.7 TB/s on this box (tools/micro/hbm_rates.hip), see DESIGN.md 4.3")
+            # `traffic` (HBM bytes per launch from the PMC counters) cannot be collected inside this process: it comes from
+            # separate rocprofv3 --pmc passes.  The figure of the last committed profile of this command is quoted beside it.
             tf = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tf):
                 try:
-                    roof["traffic"] = json.load(open(tf)).get(KIND_NAMES.get(dominant, ""), None)
+                    roof["traffic_committed_profile"] = {"bytes_per_launch": json.load(open(tf)).get(KIND_NAMES.get(dominant, ""), None),
+                                                         "source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                                                                   "FETCH x2 on gfx950; not measured in this run)"}
                 except Exception:
                     pass
         lw = LAYERWISE_MB_PER_UNIT.get((a.model, a.image_size, a.classes)) if a.variant == "full" else None
         pipeline = None
         if lw:      # whole conv stack against the layer-wise byte count SURVEY 8d prices the path with (fusion may beat it)
             pipeline = {"layerwise_MB_per_unit": lw, "layerwise_GBps": round(lw * value / 1e3, 1),
-                        "frac_of_hbm_peak": round(lw * value / 1e3 / HBM_PEAK_GBS, 4),
+                        "note": "bookkeeping against SURVEY 8d's unfused layer-wise byte count, NOT an achieved HBM rate: the fused "
+                                "kernels move far less than that",
                         "gflop_per_unit": 16.97, "tflops": round(16.97 * value / 1e3, 2)}
         line = {
             "metric": "images*MC-samples/sec, EfficientDet-D0 MC-dropout serve (preprocess+net xT+decode+NMS)",
             "value": round(value, 2), "unit": "images*MC-samples/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "p50_serve_latency_ms": round(float(np.median(lat)) * 1e3, 2),
-            "config": {"workload": "BASELINE configs[1]: %s, %d synthetic KITTI-res images (%s) per GPU, "
-                                   "MC-dropout T=%d (%s), loss attenuation, C=%d, global soft-NMS"
-                                   % (a.model, a.batch, a.image_size, a.samples, a.variant, a.classes),
+            "warmup": a.warmup, "warmup_steps_run": n_warm, "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (tensors and accumulators float32; 1x1 products split-bf16 MFMA x%s)" % terms if terms != "0" else "f32",
+            "data": "synthetic",
+            "p50_step_ms": round(float(np.median(lat)) * 1e3, 2),
+            "config": {"workload": "%s: %s, %d synthetic images (%s raw, %s network) per GPU, MC-dropout T=%d (%s), loss attenuation, "
+                                   "C=%d, %s soft-NMS" % (CONFIG_NAMES[a.config], a.model, a.batch, a.raw_size, a.image_size, a.samples,
+                                                          a.variant, a.classes, a.post_mode),
                        "images_per_gpu": a.batch, "mc_samples": a.samples, "chunk_images": a.chunk,
                        "weights": "random init (reference initialisers), seed 0" +
                                   ("" if a.cls_spread == 1.0 else ", class-predict kernel x %g" % a.cls_spread),
                        "contraction": "float32 tensors and accumulators; 1x1 products as split-bf16 MFMA with %s cross terms "
-                                      "(UDA_PW_TERMS; 0 = exact f32-input MFMA)" % os.environ.get("UDA_PW_TERMS", "3"),
-                       "sharding": "images across ranks, all-gather of detections"},
+                                      "(UDA_PW_TERMS; 6 = float32-equivalent everywhere, 0 = exact f32-input MFMA)" % terms,
+                       "sharding": "images across ranks, all-gather of detections", "plan": summary},
             "kernel_ms_per_step": {KIND_NAMES.get(k, str(k)): round(v[0], 2) for k, v in calib.items()},
             "h2d_upload_ms": round(upload_s * 1e3, 1),
-            "nms_prefix_redone_images": drv.nms_prefix_fallbacks(),
+            "nms_prefix_redone_images": pfx_fb,
+            "nms_coop_fallbacks": coop_fb,
             "roofline": roof,
             "pipeline": pipeline,
         }
+        line.update(side)
+        if world == 1 and not a.no_side:
+            log("GPU part done (%.2f units/s); precision children (UDA_PW_TERMS=6, 0) ..." % value)
+            line["precision"] = {"default_terms": terms,
+                                 "six_terms_float32_equivalent": precision_child(a, 6),
+                                 "exact_f32_mfma": precision_child(a, 0),
+                                 "note": "same workload, each in a child process whose environment carries the switch before its first "
+                                         "GPU call; detection-level effect of 3 terms vs exact: tests/test_gpu_fullsize.py"}
         if world == 1 and not a.no_cpu_baseline:
-            log("GPU part done (%.2f units/s); timing the CPU oracle on a bounded sample ..." % value)
+            log("timing the CPU oracle on a bounded sample ...")
             line["cpu_baseline"] = cpu_baseline(a)
         print(json.dumps(line), flush=True)
-    drv.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def ensemble_main(a, params, images, rank, world, local_rank, dist, tdev):
+    """BASELINE configs[3]: M deterministic members (independent random-init weight sets), aggregated like MC samples.
+    One GPU: EnsembleDriver.  Several ranks: members striped round-robin, head outputs re-sharded by image over RCCL,
+    every rank aggregates / NMSes its image shard, one all-gather of the detections (dist.serve_ensemble_striped)."""
+    from uda_amd import weights as weights_mod
+    from uda_amd.infer_lib import EnsembleDriver, ServingDriver
+    M = a.ensemble
+    n_total = a.batch * world                      # weak scaling: the batch grows with the ranks, members stay M
+    if world == 1:
+        ws = [weights_mod.init_weights(params, seed=40 + m) for m in range(M)]
+        ens = EnsembleDriver(ws, a.model, batch_size=a.batch, model_params=params, device=local_rank, chunk_images=a.chunk)
+        run = lambda: ens.serve(images)
+        close = ens.close
+    else:
+        from uda_amd import dist as udist
+        allimg = np.concatenate([np.random.default_rng(2 + r).integers(0, 256, images.shape, dtype=np.uint8) for r in range(world)])
+        mine = {m: ServingDriver(a.model, n_total, False, params, weights=weights_mod.init_weights(params, seed=40 + m),
+                                 device=local_rank, chunk_images=a.chunk) for m in range(M) if udist.member_owner(m, world) == rank}
+        pm = dict(params, mc_dropout=True, mc_dropoutrate=1e-9, mc_dropoutsamp=M)
+        post = ServingDriver(a.model, n_total, False, pm, post_only=True, device=local_rank, chunk_images=1)
+        run = lambda: udist.serve_ensemble_striped(mine, post, allimg, M, rank, world, device=tdev)
+
+        def close():
+            for d in list(mine.values()) + [post]:
+                d.close()
+    for _ in range(max(2, a.warmup)):
+        run()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        run()
+    if dist is not None:
+        import torch
+        torch.cuda.synchronize()
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    units = n_total * M * a.steps
+    if rank == 0:
+        print(json.dumps({
+            "metric": "images*ensemble-members/sec, 5-member deep ensemble of EfficientDet-D0 (preprocess+net+aggregate+decode+NMS)",
+            "value": round(units / elapsed, 2), "unit": "images*members/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (1x1 products split-bf16 MFMA x%s)" % os.environ.get("UDA_PW_TERMS", "3"), "data": "synthetic",
+            "config": {"workload": "%s: %d-member deep ensemble of %s, %d synthetic images (%s) per GPU, members striped over %d rank(s), "
+                                   "uploads included" % (CONFIG_NAMES[3], M, a.model, a.batch, a.image_size, world),
+                       "images_per_gpu": a.batch, "members": M}}), flush=True)
+    close()
     if dist is not None:
         dist.destroy_process_group()
 

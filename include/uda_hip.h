@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define UDA_ABI_VERSION 1
+#define UDA_ABI_VERSION 2
 #define UDA_MAX_LEVELS 8
 #define UDA_MAX_FUSE_INPUTS 3
 
@@ -165,6 +165,12 @@ int uda_synchronize(uda_ctx_t* ctx);
  * device; this counts the images / problems that failed the check and were redone on the full set (the results
  * are identical either way). */
 int64_t uda_nms_prefix_fallbacks(const uda_ctx_t* ctx);
+/* Global NMS over the whole anchor set normally runs as ONE launch of a co-resident grid whose blocks exchange keys
+ * through memory with a bounded spin.  When a spin runs out (the grid was not co-resident: e.g.
+ * another process interleaving such grids on the same GPU) the post-process is redone with two launches per epoch and
+ * the handle stays on that version; this counts those redone post-process runs (0 in normal operation; results are
+ * identical either way).  UDA_NMS_COOP_SPIN=<polls> shortens the bound (test hook). */
+int64_t uda_nms_coop_fallbacks(const uda_ctx_t* ctx);
 
 /* Detections of the last uda_run (synchronises).  Shapes for n images, M = max_output_size:
  *   boxes   [n, M, box_cols]   box_cols = 4 (+4 aleatoric sigma)(+4 epistemic sigma)
@@ -199,9 +205,21 @@ int uda_calibrate_box(uda_ctx_t* ctx, int32_t col0, int32_t mode, int32_t relati
  * box [T_b, n, h, w, 4A or 8A] in the reference's stacking order (T axis first; T_x = 1
  * and the axis is dropped by the caller when that head is not stacked). */
 int uda_get_head_outputs(uda_ctx_t* ctx, int32_t level, float* cls, float* box);
-/* Inject head outputs (same layout) and run only the post-process on them. */
-int uda_set_head_outputs(uda_ctx_t* ctx, int32_t level, int32_t n, const float* cls, const float* box);
+/* Inject head outputs (same layout) and run only the post-process on them.  cls_floats / box_floats = number of floats
+ * the host buffers hold; they must equal T_x * n * h * w * channels of the handle's layout (an error otherwise: the
+ * caller passed an unstacked array to a stacked head or the other way round). */
+int uda_set_head_outputs(uda_ctx_t* ctx, int32_t level, int32_t n, const float* cls, int64_t cls_floats,
+                         const float* box, int64_t box_floats);
+/* post-process (ServingDriver._postprocess, infer_lib.py:263-267) on the head outputs RESIDENT in the handle - injected
+ * with uda_set_head_outputs / uda_copy_heads / written through uda_head_outputs_device, or left by the last uda_run. */
 int uda_postprocess_heads(uda_ctx_t* ctx, int32_t n, const float* image_scales, int32_t post_mode);
+/* Device address of the handle's head-output buffer of `level` (which: 0 class, 1 box): rows [image][sample], each of
+ * *floats_per_row floats, *rows_per_image = T for a stacked head else 1; capacity max_images images.  For device-side
+ * exchanges (RCCL over xGMI: ensemble re-shard) without a host hop; the caller orders its own stream against
+ * the handle's with uda_synchronize.  uda_set_num_images tells the handle how many images such a write filled in. */
+int uda_head_outputs_device(uda_ctx_t* ctx, int32_t level, int32_t which, void** dev_ptr, int64_t* floats_per_row,
+                            int32_t* rows_per_image);
+int uda_set_num_images(uda_ctx_t* ctx, int32_t n);
 /* Deep ensembles (BASELINE configs[3]; the reference has no ensemble code): copy the
  * head outputs of the last run of `src` (a deterministic member network, T = 1) into sample slot
  * `sample` of `dst` (a handle whose model has mc_samples = number of members and stacked heads);

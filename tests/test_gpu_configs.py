@@ -24,8 +24,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _driver(params, w, batch, **kw):
-    from uda_amd.infer_lib import ServingDriver
-    return ServingDriver("_", False, params["name"], batch_size=batch, model_params=params, weights=w, **kw)
+    from uda_amd.infer_lib import KerasDriver, ServingDriver
+    return KerasDriver("_", False, params["name"], batch_size=batch, model_params=params, weights=w, **kw)
 
 
 def _oracle_heads(p, w, imgs, hw, seed):
@@ -70,7 +70,7 @@ import sys
 sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
 import numpy as np
 from common import FULL_MC, MC_NO_ATT, make_images, make_params, make_weights
-from uda_amd.infer_lib import ServingDriver
+from uda_amd.infer_lib import KerasDriver, ServingDriver
 from oracle import effdet_ref as E, philox_ref as R, post_ref as P, preprocess_ref as PP
 for over, spread in ((dict(FULL_MC, mc_dropoutsamp=10), 1.0), (dict(FULL_MC, mc_dropoutsamp=20, num_classes=10), 1.0),
                      (dict(FULL_MC, mc_dropoutsamp=10), 20.0), (dict(MC_NO_ATT, mc_dropoutsamp=10), 20.0)):
@@ -80,7 +80,7 @@ for over, spread in ((dict(FULL_MC, mc_dropoutsamp=10), 1.0), (dict(FULL_MC, mc_
     masks = R.make_masks(E.dropout_sites(p), 21, 2, p["mc_dropoutsamp"])
     rcls, rbox = E.forward(w, p, x, masks)
     want = P.postprocess_global(p, rcls, rbox, scales)
-    d = ServingDriver("_", False, p["name"], batch_size=2, model_params=p, weights=w)
+    d = KerasDriver("_", False, p["name"], batch_size=2, model_params=p, weights=w)
     got = d.postprocess(rcls, rbox, scales)
     assert len(got) == len(want)
     for g, r in zip(got, want):

@@ -30,7 +30,7 @@ def detector_like(rng, k, objects=20, per_object=40):
 
 def main():
     from common import make_params, make_weights
-    from uda_amd.infer_lib import ServingDriver
+    from uda_amd.infer_lib import KerasDriver, ServingDriver
     from oracle import post_ref as P
     n_img, k = 32, 184140
     rng = np.random.default_rng(0)
@@ -39,7 +39,7 @@ def main():
     for i in range(n_img):
         boxes[i], scores[i] = detector_like(rng, k)
     p = make_params()
-    d = ServingDriver("_", False, p["name"], batch_size=n_img, model_params=p, weights=make_weights(p))
+    d = KerasDriver("_", False, p["name"], batch_size=n_img, model_params=p, weights=make_weights(p))
     d.profile_enable([17])
     best = None
     for rep in range(4):

@@ -1,9 +1,9 @@
 import sys, time, numpy as np
 import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 from common import make_params, make_weights, FULL_MC
-from uda_amd.infer_lib import ServingDriver
+from uda_amd.infer_lib import KerasDriver, ServingDriver
 p = make_params(**FULL_MC); w = make_weights(p)
-d = ServingDriver("_", False, p["name"], batch_size=1, model_params=p, weights=w)
+d = KerasDriver("_", False, p["name"], batch_size=1, model_params=p, weights=w)
 rng = np.random.default_rng(0)
 n, K = 112, 5000
 c = rng.uniform(0, 500, (n, K, 2)); wh = rng.uniform(5, 80, (n, K, 2))

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("UDA_LIB") or os.path.join(CSRC, "libuda_hip.so")   # UDA_LIB: an alternative build for A/B runs
 HEADER = os.path.join(os.path.dirname(HERE), "include", "uda_hip.h")
 
-UDA_ABI_VERSION = 1
+UDA_ABI_VERSION = 2
 MAX_LEVELS = 8
 MAX_FUSE = 3
 
@@ -79,13 +79,16 @@ _SIGNATURES = {
     "uda_run": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "uda_synchronize": (C.c_int, [_P]),
     "uda_nms_prefix_fallbacks": (C.c_int64, [_P]),
+    "uda_nms_coop_fallbacks": (C.c_int64, [_P]),
     "uda_get_detections": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "uda_detection_cols": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "uda_get_class_probs": (C.c_int, [_P, _P, _P]),
     "uda_calibrate_box": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "uda_serve": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "uda_get_head_outputs": (C.c_int, [_P, C.c_int32, _P, _P]),
-    "uda_set_head_outputs": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
+    "uda_set_head_outputs": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int64, _P, C.c_int64]),
+    "uda_head_outputs_device": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "uda_set_num_images": (C.c_int, [_P, C.c_int32]),
     "uda_postprocess_heads": (C.c_int, [_P, C.c_int32, _P, C.c_int32]),
     "uda_copy_heads": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     "uda_predict": (C.c_int, [_P, _P, C.c_int32]),

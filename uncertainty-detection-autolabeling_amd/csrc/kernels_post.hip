@@ -1475,7 +1475,7 @@ void launch_nms_reg(const NmsArgs& a, const float* scores, hipStream_t s) {
 // after a fenced barrier missed).  The spin is bounded: a time-out raises *err and every later step falls through.
 constexpr int COOP_MAX_BPI = 8;
 __device__ __forceinline__ unsigned long long coop_exchange(unsigned long long* slots, int blk, int bpi, unsigned long long mine,
-                                                            RegLds& S, int* err) {
+                                                            RegLds& S, int* err, unsigned spin_max) {
   __syncthreads();                           // `mine` may come out of LDS traffic of the whole block
   if (threadIdx.x < 64) {
     if (threadIdx.x == 0) __hip_atomic_store(&slots[blk], mine ? mine : 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1483,9 +1483,10 @@ __device__ __forceinline__ unsigned long long coop_exchange(unsigned long long* 
     if ((int)threadIdx.x < bpi) {
       unsigned spins = 0;
       while ((v = __hip_atomic_load(&slots[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0ull) {
-        if ((++spins & 4095u) == 0u) {
+        ++spins;
+        if ((spins & 4095u) == 0u || spins > spin_max) {
           if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-          if (spins > (1u << 22)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+          if (spins > spin_max) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         }
       }
     }
@@ -1524,7 +1525,7 @@ constexpr int COOP_HEAVY = 1024;     // entries of the list of chains handed to 
 constexpr int COOP_HEAVY_LINKS = 6;  // overlapping links above which a chain is evaluated by a wave
 
 template <int IPT>
-__global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float* scores, unsigned long long* slots_all, int* err, int bpi, int n0) {
+__global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float* scores, unsigned long long* slots_all, int* err, int bpi, int n0, unsigned spin_max) {
   // Per candidate: the stale score in a register of its thread (scanned every epoch, candidate i0 + j * 1024 + tid), the
   // cached exact score / upper bound in LDS (scanned every epoch, 128 KB), begin / epoch / a copy of the stale score in
   // the workspace arrays in memory (touched only when a chain is evaluated, together with the candidate's box).
@@ -1689,7 +1690,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
 #endif
     __syncthreads();
     const unsigned long long lk = S.L;       // this block's exact lower bound
-    const unsigned long long bd = coop_exchange(slots + (size_t)(2 * k) * COOP_MAX_BPI, blk, bpi, lk, S, err);
+    const unsigned long long bd = coop_exchange(slots + (size_t)(2 * k) * COOP_MAX_BPI, blk, bpi, lk, S, err, spin_max);
 #ifdef UDA_NMS_STATS
     const unsigned long long t2 = wall_clock64();
 #endif
@@ -1719,7 +1720,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
 #ifdef UDA_NMS_STATS
     const unsigned long long t3 = wall_clock64();
 #endif
-    const unsigned long long wk = coop_exchange(slots + (size_t)(2 * k + 1) * COOP_MAX_BPI, blk, bpi, ke, S, err);
+    const unsigned long long wk = coop_exchange(slots + (size_t)(2 * k + 1) * COOP_MAX_BPI, blk, bpi, ke, S, err, spin_max);
 #ifdef UDA_NMS_STATS
     const unsigned long long t4 = wall_clock64();
 #endif
@@ -1796,18 +1797,29 @@ bool launch_nms_coop(const NmsArgs& a, const float* scores, unsigned long long* 
   if (bpi == 0 || a.n_img <= 0) return false;
   constexpr size_t lds = (size_t)COOP_IPT * SOLO_T * sizeof(float) + (size_t)(COOP_LIST + COOP_HEAVY) * sizeof(int) +
                          (size_t)COOP_IPT * 32 * sizeof(unsigned);
-  static int capacity = -1;
-  if (capacity < 0) {
-    int dev = 0, per_cu = 0;
+  // co-resident blocks of this kernel per device (occupancy x CUs), one entry per HIP device of the process
+  static int capacity_of[64];
+  static bool capacity_known[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (!capacity_known[dev]) {
+    int per_cu = 0;
     hipDeviceProp_t prop;
-    capacity = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.cooperativeLaunch &&
+    int cap = 0;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.cooperativeLaunch &&
         hipFuncSetAttribute((const void*)nms_coop_kernel<COOP_IPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nms_coop_kernel<COOP_IPT>, SOLO_T, lds) == hipSuccess)
-      capacity = per_cu * prop.multiProcessorCount;
+      cap = per_cu * prop.multiProcessorCount;
     (void)hipGetLastError();
-    if (const char* e = getenv("UDA_NMS_COOP_CAP")) capacity = atoi(e);     // test hook: a wrong capacity must end in the time-out path, not in a hang
+    if (const char* e = getenv("UDA_NMS_COOP_CAP")) cap = atoi(e);     // test hook: a wrong capacity must end in the time-out path, not in a hang
+    capacity_of[dev] = cap;
+    capacity_known[dev] = true;
   }
+  const int capacity = capacity_of[dev];
+  // polls of an exchange slot before a block gives up (UDA_NMS_COOP_SPIN: debug knob, a tiny bound forces the time-out -> redo path)
+  static long long spin_env = -1;
+  if (spin_env < 0) { const char* e = getenv("UDA_NMS_COOP_SPIN"); spin_env = e ? atoll(e) : (1ll << 22); if (spin_env < 0) spin_env = 0; }
+  const unsigned spin_max = (unsigned)(spin_env > 0xffffffffll ? 0xffffffffll : spin_env);
   static const bool dbg = getenv("UDA_NMS_DEBUG") != nullptr;
   if (bpi > capacity) {
     if (dbg) fprintf(stderr, "[uda] cooperative NMS: %d blocks per problem > capacity %d\n", bpi, capacity);
@@ -1823,7 +1835,7 @@ bool launch_nms_coop(const NmsArgs& a, const float* scores, unsigned long long* 
   // rocprofv3's kernel tracing crashes at process exit after a cooperative launch, ROCm 7.2.)
   for (int n0 = 0; n0 < a.n_img; n0 += per) {
     const int cnt = a.n_img - n0 < per ? a.n_img - n0 : per;
-    hipLaunchKernelGGL((nms_coop_kernel<COOP_IPT>), dim3((unsigned)(bpi * cnt)), dim3(SOLO_T), lds, s, a, scores, slots, err, bpi, n0);
+    hipLaunchKernelGGL((nms_coop_kernel<COOP_IPT>), dim3((unsigned)(bpi * cnt)), dim3(SOLO_T), lds, s, a, scores, slots, err, bpi, n0, spin_max);
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

@@ -23,6 +23,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "uda_internal.h"
 
 namespace uda {
@@ -41,6 +43,25 @@ __device__ __forceinline__ float swishf_b(float x) { return x * sigmoidf_b(x); }
 constexpr float UDA_NEG_LN2 = -0.6931471805599453f;
 __device__ __forceinline__ float swish_folded(float y, float k) {
   return (y * k) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y));
+}
+
+// the same without the constant factor: y / (1 + 2^y) = swish(x) / (-ln 2) for y = -log2(e) x.  The fused MBConv kernels
+// store THIS as the expanded activation and fold (-ln 2) x (dropout keep-scale of the channel) into the BN scale that
+// follows the depthwise convolution (a per-channel factor commutes with a depthwise convolution): one multiply less per
+// expanded element.
+__device__ __forceinline__ float swish_core(float y) { return y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y)); }
+
+// Store through a UNIFORM base (scalar register pair) plus a 32-bit per-lane byte offset: global_store_dword v, v, s[..].
+// The base is made opaque so that the address is not re-associated into per-lane 64-bit pointers (which the compiler
+// then hoists out of the slab loop: 2 registers per output, spilled at the occupancy these kernels need).
+typedef __attribute__((address_space(1))) char uda_gchar;
+typedef __attribute__((address_space(1))) float uda_gfloat;
+__device__ __forceinline__ void store_uniform_base(float* base, unsigned byte_off, float v) {
+  // (written as one instruction: left to the compiler the scalar base is copied into a register pair per lane and the
+  // 64-bit add comes back.  vmcnt stays conservative: an outstanding store the compiler does not know of only makes a
+  // later counted wait cover more operations, never fewer - memory operations retire in order.)
+  uda_gchar* g = (uda_gchar*)base;
+  asm volatile("global_store_dword %0, %1, %2" : : "v"(byte_off), "v"(v), "s"(g) : "memory");
 }
 
 // two floats -> packed bf16 pair (round to nearest even; v_cvt_pk_bf16_f32), element 0 in the low half
@@ -676,8 +697,19 @@ __host__ __device__ constexpr MbxCfgB mbxb_cfg(int k, int s) {
 // in registers 0..7 of each lane half - exactly an A-operand fragment of the expand MFMA with the k order
 // (j, h) -> channel (j & 3) + 8 (j >> 2) + 4 h, which the host applies to the rows of the packed expand weights.
 // No lane movement, no LDS, and the 16-channel tensor never goes to HBM.
+// Occupancy is what this kernel lives on (PMC, round 2: VALU 53 % busy at two waves per SIMD, a quarter of the wave
+// time spent in waits): the packed expand weights of a slab go through a 4-8 KB LDS image instead of 2 x 17 registers
+// per wave, and E has no padding (both its writers and its readers put consecutive channels of ONE pixel on consecutive
+// lanes: conflict-free at a row stride of 32 floats), so that the 3x3 variants fit 128 registers and 40 KB of LDS:
+// four blocks = 16 waves per CU (5x5: three blocks; the 25 taps stay in registers).
+// Wider inputs (3 or 4 k-steps: 48-64 registers of operand fragments per wave) do not reach that occupancy either way
+// and keep the weight fragments of the current and the next slab in registers (measured: the LDS image costs them 6-9 %,
+// its reads sit on the critical path right behind the slab barrier).
+#ifndef UDA_MBXB_MINW
+#define UDA_MBXB_MINW(K, S, KSF) ((KSF) <= 2 ? ((K) == 3 ? 4 : 3) : (((K) == 3 && (S) == 2 && (KSF) <= 3) ? 3 : 2))
+#endif
 template <int K, int S, int KSF, bool FUSE0>   // KSF = 16-deep MFMA k-steps covering Cin + 1
-__global__ __launch_bounds__(256, ((K == 3 && S == 2 && KSF <= 3) ? 3 : 2)) void mbxb_kernel(MbxArgs a) {
+__global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(MbxArgs a) {
   constexpr int NW = 4;
   constexpr int TH = mbxb_cfg(K, S).th, TW = mbxb_cfg(K, S).tw;
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
@@ -686,18 +718,21 @@ __global__ __launch_bounds__(256, ((K == 3 && S == 2 && KSF <= 3) ? 3 : 2)) void
   constexpr int NMT = NPP / 32;
   constexpr int NG = NW * 2;                  // depthwise thread groups (32 channels each)
   constexpr int MTW = (NMT + NW - 1) / NW;    // pixel slices per wave
-  constexpr int ES = 33;
+  constexpr int ES = 32;
   // depthwise units: XW consecutive outputs of one row; NUNIT units over the NG thread groups
   constexpr int XW = (S == 1) ? 8 : (K == 3 ? 6 : 5);
   constexpr int UPR = TW / XW;                // units per output row
   constexpr int NUNIT = TH * UPR;             // 24 (3x3 s1), 16 (5x5 s1), 8 (stride 2)
   static_assert(TW % XW == 0 && NUNIT % NG == 0, "units must tile the output tile and the thread groups");
   constexpr int NCOL = (XW - 1) * S + K;
-  extern __shared__ float mlds[];
+  extern __shared__ __attribute__((aligned(16))) float mlds[];
   float* E = mlds;                            // [NPP][ES]
   float* red = E + (size_t)NPP * ES;          // [NG][32]
   constexpr int NPAR = (K * K + 2) * 32;      // per slab: depthwise taps [K*K][32] | BN scale | BN shift (host-packed, a.wpar)
   float* par = red + NG * 32;                 // [2][NPAR]
+  constexpr bool B_LDS = KSF <= 2;            // packed expand weights of a slab: LDS image (else registers, one slab ahead)
+  constexpr int BSLAB = KSF * 2 * 64;         // uint4 per slab of packed expand weights
+  uint4* Bs = (uint4*)(par + 2 * NPAR);       // [KSF][2 parts][64 lanes]: rewritten between the two barriers of a slab
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -799,56 +834,99 @@ __global__ __launch_bounds__(256, ((K == 3 && S == 2 && KSF <= 3) ? 3 : 2)) void
   const int NCH = (a.Cmid + 31) >> 5;
   const uint4* Wp = (const uint4*)a.wsplit;
 
-  // B fragments (and the expand-side dropout scale) are requested one slab ahead; the depthwise-side
-  // operands of a slab are requested when its expand phase starts and are consumed after it.
-  struct SlabB {
-    uint4 bh[KSF], bl[KSF];
-    float mk0;
-  };
-  auto load_b = [&](int ch, SlabB& q) {
+  // ---- loop-invariant addressing of the depthwise stage.  Unit u = g + NG * ui of this thread: XW outputs of output row
+  // orow starting at column oxs.  eoff = float offset of the unit's E window (tap rows / columns are compile-time
+  // displacements), ooff = element offset of the unit's first output relative to the block's output base, which is
+  // UNIFORM (scalar registers): the stores use a scalar base + a 32-bit lane offset, no 64-bit vector arithmetic.
+  constexpr int UPT = NUNIT / NG;
+  int eoff[UPT];
+  unsigned ooff[UPT];
 #pragma unroll
-    for (int ks = 0; ks < KSF; ++ks) {
-      q.bh[ks] = Wp[(((size_t)ks * NCH + ch) * 2 + 0) * 64 + lane];
-      q.bl[ks] = Wp[(((size_t)ks * NCH + ch) * 2 + 1) * 64 + lane];
-    }
-    const int ecol = ch * 32 + li;
-    const float* m0 = a.mask0 ? a.mask0 + (size_t)b * a.Cmid + (ecol < a.Cmid ? ecol : 0) : (const float*)Wp;
-    const float v0 = *m0;
-    q.mk0 = (a.mask0 ? v0 : 1.f) * UDA_NEG_LN2;
-  };
-  // The depthwise-side operands of a slab (taps, BN scale / shift: one contiguous host-packed block per slab) go
-  // through LDS and, like the B fragments and the dropout scales, are requested while the PREVIOUS slab's expand
-  // phase ends - before that slab's output stores are issued (vmcnt retires loads and stores in order) - by plain
-  // branch-free loads, so that no wait is placed right behind them.
+  for (int ui = 0; ui < UPT; ++ui) {
+    const int u = g + NG * ui;
+    const int orow = u / UPR, oxs = (u % UPR) * XW;
+    eoff[ui] = ((orow * S) * IW + oxs * S) * ES + c;
+    ooff[ui] = (unsigned)((orow * a.Wo + oxs) * a.Cmid + c) * 4u;      // bytes
+  }
+  float* const obase = a.out + (((size_t)b * a.Ho + oy0) * a.Wo + ox0) * a.Cmid;
+  const unsigned cm = (unsigned)a.Cmid;
+  // a tile that lies inside the output and whose slabs are whole takes the unguarded path (block-uniform decision)
+  const bool full = (oy0 + TH <= a.Ho) && (ox0 + TW <= a.Wo) && ((a.Cmid & 31) == 0);
+
+  // Per-slab operands - packed expand weights (LDS image Bs), depthwise taps + BN scale / shift (LDS, one contiguous
+  // host-packed block per slab), the two dropout scales (registers) - are requested while the PREVIOUS slab's expand
+  // phase runs, i.e. before that slab's output stores are issued (vmcnt retires loads and stores in order), by plain
+  // branch-free loads, so that no wait is placed right behind them; they are written to LDS between the two barriers.
   constexpr int P_PER = (NPAR + 255) / 256;
-  SlabB cur, nxt;
-  load_b(0, cur);
+  constexpr int B_PER = (BSLAB + 255) / 256;
+  auto b_src = [&](int ch, int f) -> const uint4* {       // element f of slab ch in the [ks][part][lane] image
+    const int ks = f >> 7, rest = f & 127;
+    return Wp + (((size_t)ks * NCH + ch) * 2 + (rest >> 6)) * 64 + (rest & 63);
+  };
+  constexpr int KR = B_LDS ? 1 : KSF;         // register copies (B_LDS: unused)
+  uint4 rbh[KR], rbl[KR], nbh[KR], nbl[KR];
+  auto load_regs = [&](int ch, uint4* h, uint4* l) {
+#pragma unroll
+    for (int ks = 0; ks < KR; ++ks) {
+      h[ks] = Wp[(((size_t)ks * NCH + ch) * 2 + 0) * 64 + lane];
+      l[ks] = Wp[(((size_t)ks * NCH + ch) * 2 + 1) * 64 + lane];
+    }
+  };
+  if constexpr (B_LDS) {
+    for (int f = tid; f < BSLAB; f += 256) Bs[f] = *b_src(0, f);
+  } else {
+    load_regs(0, rbh, rbl);
+  }
   for (int f = tid; f < NPAR; f += 256) par[f] = a.wpar[f];
-  float mk1 = ((c < a.Cmid && a.mask1) ? a.mask1[(size_t)b * a.Cmid + c] : 1.f) * UDA_NEG_LN2, mk1n = mk1;
+  auto mask_at = [&](const float* m, int ch) -> float {   // keep-scale x (-ln 2) of channel 32 ch + c (c == li) of this sample row
+    const int col_ = ch * 32 + c;
+    const float* mp = m ? m + (size_t)b * a.Cmid + (col_ < a.Cmid ? col_ : 0) : a.wpar;
+    const float v = *mp;
+    return (m ? v : 1.f) * UDA_NEG_LN2;
+  };
+  float mk0 = mask_at(a.mask0, 0), mk0n = mk0;            // expand side: applied after the depthwise (see swish_core)
+  float mk1 = mask_at(a.mask1, 0), mk1n = mk1;
   __syncthreads();
 
   for (int ch = 0; ch < NCH; ++ch) {
     const int col = ch * 32 + c;
     const bool dcol = col < a.Cmid;
     const float* pcur = par + (ch & 1) * NPAR;
-    // ---- the NEXT slab's operands are requested first (B fragments + expand dropout scale into registers, the
-    // depthwise block and its dropout scale for LDS): unconditional, branch-free loads with a whole phase to arrive
+    // ---- the NEXT slab's operands are requested first: unconditional, branch-free loads with a whole phase to arrive
     const bool more = ch + 1 < NCH;
-    load_b(more ? ch + 1 : ch, nxt);
+    const int chn = more ? ch + 1 : ch;
+    uint4 nb[B_PER];
+    if constexpr (B_LDS) {
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i) {
+        const int f = tid + 256 * i;
+        nb[i] = *b_src(chn, f < BSLAB ? f : 0);
+      }
+    } else {
+      load_regs(chn, nbh, nbl);
+    }
     float np_[P_PER];
-    const float* wnext = a.wpar + (size_t)(more ? ch + 1 : ch) * NPAR;
+    const float* wnext = a.wpar + (size_t)chn * NPAR;
 #pragma unroll
     for (int i = 0; i < P_PER; ++i) {
       const int f = tid + 256 * i;
       np_[i] = wnext[f < NPAR ? f : 0];
     }
-    {
-      const int ncol = (more ? ch + 1 : ch) * 32 + c;
-      const float* m1 = a.mask1 ? a.mask1 + (size_t)b * a.Cmid + (ncol < a.Cmid ? ncol : 0) : a.wpar;
-      const float v1 = *m1;
-      mk1n = (a.mask1 ? v1 : 1.f) * UDA_NEG_LN2;
+    mk0n = mask_at(a.mask0, chn);
+    mk1n = mask_at(a.mask1, chn);
+    // this slab's weight fragments: one LDS image for the block, read once per wave and used for both of its slices
+    bf16x8 bh[KSF], bl[KSF];
+#pragma unroll
+    for (int ks = 0; ks < KSF; ++ks) {
+      if constexpr (B_LDS) {
+        bh[ks] = __builtin_bit_cast(bf16x8, Bs[(ks * 2 + 0) * 64 + lane]);
+        bl[ks] = __builtin_bit_cast(bf16x8, Bs[(ks * 2 + 1) * 64 + lane]);
+      } else {
+        bh[ks] = __builtin_bit_cast(bf16x8, rbh[ks < KR ? ks : 0]);
+        bl[ks] = __builtin_bit_cast(bf16x8, rbl[ks < KR ? ks : 0]);
+      }
     }
-    // ---- expand: E[p][j] = swish(sum_k X[p][k] We'[k][32 ch + j]) * mask0
+    // ---- expand: E[p][j] = swish(sum_k X[p][k] We'[k][32 ch + j]) / (-ln 2)   (dropout scale: after the depthwise)
 #pragma unroll
     for (int t = 0; t < MTW; ++t) {
       const int mt = wave + NW * t;
@@ -858,71 +936,87 @@ __global__ __launch_bounds__(256, ((K == 3 && S == 2 && KSF <= 3) ? 3 : 2)) void
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KSF; ++ks) {
-          const bf16x8 bh = __builtin_bit_cast(bf16x8, cur.bh[ks]), bl = __builtin_bit_cast(bf16x8, cur.bl[ks]);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t][ks], bh, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t][ks], bl, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t][ks], bh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t][ks], bh[ks], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t][ks], bl[ks], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t][ks], bh[ks], acc, 0, 0, 0);
         }
         float* ep = E + (size_t)(mt * 32 + 4 * lh) * ES + li;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swish_folded(acc[r], cur.mk0);
+        for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swish_core(acc[r]);
       }
     }
     __syncthreads();
     // the next slab's operands have had the whole expand phase to arrive; they are consumed HERE, ahead of this
-    // slab's output stores, so that no later wait has to retire those stores (vmcnt retires in order)
+    // slab's output stores, so that no later wait has to retire those stores (vmcnt retires in order).  (The single
+    // weight image is free: every wave read its fragments before the barrier above.)
     {
+      if constexpr (B_LDS) {
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+          const int f = tid + 256 * i;
+          if (more && f < BSLAB) Bs[f] = nb[i];
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < KR; ++ks)
+          asm volatile("" : "+v"(nbh[ks].x), "+v"(nbh[ks].y), "+v"(nbh[ks].z), "+v"(nbh[ks].w),
+                            "+v"(nbl[ks].x), "+v"(nbl[ks].y), "+v"(nbl[ks].z), "+v"(nbl[ks].w));
+      }
       float* pnext = par + ((ch + 1) & 1) * NPAR;
 #pragma unroll
       for (int i = 0; i < P_PER; ++i) {
         const int f = tid + 256 * i;
         if (more && f < NPAR) pnext[f] = np_[i];
       }
-#pragma unroll
-      for (int ks = 0; ks < KSF; ++ks)
-        asm volatile("" : "+v"(nxt.bh[ks].x), "+v"(nxt.bh[ks].y), "+v"(nxt.bh[ks].z), "+v"(nxt.bh[ks].w),
-                          "+v"(nxt.bl[ks].x), "+v"(nxt.bl[ks].y), "+v"(nxt.bl[ks].z), "+v"(nxt.bl[ks].w));
-      asm volatile("" : "+v"(nxt.mk0), "+v"(mk1n));
+      asm volatile("" : "+v"(mk0n), "+v"(mk1n));
     }
     // ---- depthwise on E for channel 32 ch + c
     float wk[K * K];
 #pragma unroll
     for (int t = 0; t < K * K; ++t) wk[t] = pcur[t * 32 + c];
-    const float sc1 = pcur[K * K * 32 + c], sh1 = pcur[(K * K + 1) * 32 + c];
+    // BN scale x (-ln 2) x expand-side dropout scale of this channel (see swish_core)
+    const float sc1 = pcur[K * K * 32 + c] * mk0, sh1 = pcur[(K * K + 1) * 32 + c];
     float ssum = 0.f;
-    if (dcol) {
+    float* const ob = obase + ch * 32;            // uniform
+    auto dw_units = [&](auto guard) {
+      constexpr bool GUARD = decltype(guard)::value;
 #pragma unroll
-      for (int ui = 0; ui < NUNIT / NG; ++ui) {
-        const int u = g + NG * ui;
-        const int orow = u / UPR, oxs = (u % UPR) * XW;
-        const int oy = oy0 + orow;
-        if (oy >= a.Ho) continue;
+      for (int ui = 0; ui < UPT; ++ui) {
+        if constexpr (GUARD) {
+          if (oy0 + (g + NG * ui) / UPR >= a.Ho) continue;
+        }
         float acc[XW];
 #pragma unroll
         for (int o = 0; o < XW; ++o) acc[o] = 0.f;
+        const float* eu = E + eoff[ui];
 #pragma unroll
         for (int ky = 0; ky < K; ++ky) {
           float rowv[NCOL];
-          const float* er = E + ((size_t)(orow * S + ky) * IW + oxs * S) * ES + c;
 #pragma unroll
-          for (int j = 0; j < NCOL; ++j) rowv[j] = er[j * ES];
+          for (int j = 0; j < NCOL; ++j) rowv[j] = eu[(ky * IW + j) * ES];
 #pragma unroll
           for (int kx = 0; kx < K; ++kx) {
 #pragma unroll
             for (int o = 0; o < XW; ++o) acc[o] = fmaf(rowv[o * S + kx], wk[ky * K + kx], acc[o]);
           }
         }
-        float* op = a.out + (((size_t)b * a.Ho + oy) * a.Wo + ox0 + oxs) * a.Cmid + col;
 #pragma unroll
         for (int o = 0; o < XW; ++o) {
-          if (ox0 + oxs + o < a.Wo) {
+          bool ok = true;
+          if constexpr (GUARD) ok = ox0 + (int)((g + NG * ui) % UPR) * XW + o < a.Wo;
+          if (ok) {
             const float v = swish_folded(fmaf(acc[o], sc1, sh1), mk1);
-            op[(size_t)o * a.Cmid] = v;
+            store_uniform_base(ob + (size_t)o * cm, ooff[ui], v);
             ssum += v;
           }
         }
+        // units are scheduled one after the other: hoisting the E reads of all units to the front costs 20-30 registers
+        // (and with them a block per CU)
+        __builtin_amdgcn_sched_barrier(0);
       }
-    }
+    };
+    if (full) dw_units(std::false_type());
+    else if (dcol) dw_units(std::true_type());
     if (a.se_partial) red[g * 32 + c] = ssum;
     __syncthreads();   // E may be rewritten; red[] of this slab and the next slab's operands (written after the first barrier) are complete
     if (a.se_partial && g == 0 && dcol) {
@@ -931,8 +1025,12 @@ __global__ __launch_bounds__(256, ((K == 3 && S == 2 && KSF <= 3) ? 3 : 2)) void
       for (int gg = 1; gg < NG; ++gg) t += red[gg * 32 + c];
       a.se_partial[((size_t)b * a.n_tiles + tile) * a.Cmid + col] = t;
     }
-    cur = nxt;
+    mk0 = mk0n;
     mk1 = mk1n;
+    if constexpr (!B_LDS) {
+#pragma unroll
+      for (int ks = 0; ks < KR; ++ks) { rbh[ks] = nbh[ks]; rbl[ks] = nbl[ks]; }
+    }
   }
 }
 
@@ -950,7 +1048,7 @@ static void launch_mbxb_t(const MbxArgs& a, int rows, hipStream_t s) {
   constexpr int TH = mbxb_cfg(K, S).th, TW = mbxb_cfg(K, S).tw;
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
   constexpr int NPP = (IH * IW + 31) / 32 * 32;
-  const size_t lds = ((size_t)NPP * 33 + 8 * 32 + 2 * (K * K + 2) * 32) * sizeof(float);
+  const size_t lds = ((size_t)NPP * 32 + 8 * 32 + 2 * (K * K + 2) * 32) * sizeof(float) + (size_t)KSF * 2 * 64 * sizeof(uint4);
   const dim3 grid((a.Wo + TW - 1) / TW, (a.Ho + TH - 1) / TH, rows);
   if constexpr (KSF == 2) {
     if (a.gate) { hipLaunchKernelGGL((mbxb_kernel<K, S, KSF, true>), grid, dim3(256), lds, s, a); return; }
@@ -985,7 +1083,7 @@ void launch_mbxb(const MbxArgs& a, int rows, int k, int stride, hipStream_t s) {
 // from LDS at their use instead of living in registers; with two blocks per CU the expand phase of one block (MFMA +
 // transcendentals) overlaps the depthwise phase of the other (FMA + LDS) - with one block both phases run in lockstep.)
 template <int K, int KSF>
-__global__ __launch_bounds__(512, (K == 5 && KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a) {
+__global__ __launch_bounds__(512, (KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a) {
   constexpr bool WK_LDS = (K == 5 && KSF <= 8);
   constexpr int KY_UNROLL = WK_LDS ? 1 : K;     // (a fully unrolled tap loop hoists all 25 LDS tap reads back into registers)
   constexpr int NW = 8;
@@ -1064,12 +1162,28 @@ __global__ __launch_bounds__(512, (K == 5 && KSF <= 8) ? 4 : 2) void mbxd_kernel
   const int c = tid & 31, g = tid >> 5;       // depthwise stage: channel within the slab, thread group
   const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
   constexpr int B_PER = (BSLAB + 511) / 512;  // uint4 of the next slab per thread
+  // loop-invariant addressing of the depthwise stage (see mbxb_kernel): E window offsets, output offsets relative to the
+  // block's uniform output base, and the block-uniform "whole tile, whole slabs" decision for the unguarded path
+  constexpr int UPT = NUNIT / NG;
+  static_assert(NUNIT % NG == 0, "units must tile the thread groups");
+  int eoff[UPT];
+  unsigned ooff[UPT];
+#pragma unroll
+  for (int ui = 0; ui < UPT; ++ui) {
+    const int u = g + NG * ui;
+    const int orow = u / UPR, oxs = (u % UPR) * XW;
+    eoff[ui] = (orow * IW + oxs) * ES + c;
+    ooff[ui] = (unsigned)((orow * a.Wo + oxs) * a.Cmid + c) * 4u;      // bytes
+  }
+  float* const obase = a.out + (((size_t)b * a.Ho + oy0) * a.Wo + ox0) * a.Cmid;
+  const unsigned cm = (unsigned)a.Cmid;
+  const bool full = (oy0 + TH <= a.Ho) && (ox0 + TW <= a.Wo) && ((a.Cmid & 31) == 0);
 
   for (int ch = 0; ch < NCH; ++ch) {
     const int col = ch * 32 + c;
     const bool dcol = col < a.Cmid;
     const uint4* bcur = Bs;
-    const float mk0 = mks[ch * 32 + li], mk1 = mks[32 * NCH + ch * 32 + c];
+    const float mk0c = mks[ch * 32 + c], mk1 = mks[32 * NCH + ch * 32 + c];   // expand-side scale of channel c: applied after the depthwise
     const float* pcur = par + (ch & 1) * NPAR;
     // ---- the NEXT slab's operands are requested first: they have the whole expand phase to arrive
     const bool more = ch + 1 < NCH;
@@ -1090,7 +1204,7 @@ __global__ __launch_bounds__(512, (K == 5 && KSF <= 8) ? 4 : 2) void mbxd_kernel
       const int f = tid + 512 * i;
       np_[i] = wnext[f < NPAR ? f : 0];
     }
-    // ---- expand: E[p][j] = swish(sum_k X[p][k] We'[k][32 ch + j]) * mask0 for this wave's 32 pixels
+    // ---- expand: E[p][j] = swish(sum_k X[p][k] We'[k][32 ch + j]) / (-ln 2) for this wave's 32 pixels
     {
       f32x16 acc;
 #pragma unroll
@@ -1105,7 +1219,7 @@ __global__ __launch_bounds__(512, (K == 5 && KSF <= 8) ? 4 : 2) void mbxd_kernel
       }
       float* ep = E + (size_t)(wave * 32 + 4 * lh) * ES + li;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swish_folded(acc[r], mk0);
+      for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swish_core(acc[r]);
     }
     __syncthreads();
     // the next slab's operands are written to their LDS buffers HERE, ahead of this slab's output stores, so that no
@@ -1130,20 +1244,25 @@ __global__ __launch_bounds__(512, (K == 5 && KSF <= 8) ? 4 : 2) void mbxd_kernel
 #pragma unroll
       for (int t = 0; t < K * K; ++t) wk[t] = pcur[t * 32 + c];
     }
-    const float sc1 = pcur[K * K * 32 + c], sh1 = pcur[(K * K + 1) * 32 + c];
+    const float sc1 = pcur[K * K * 32 + c] * mk0c, sh1 = pcur[(K * K + 1) * 32 + c];
     float ssum = 0.f;
-    if (dcol) {
-      for (int u = g; u < NUNIT; u += NG) {
-        const int orow = u / UPR, oxs = (u % UPR) * XW;
-        const int oy = oy0 + orow;
-        if (oy >= a.Ho) continue;
+    float* const ob = obase + ch * 32;            // uniform
+    auto dw_units = [&](auto guard) {
+      constexpr bool GUARD = decltype(guard)::value;
+#pragma unroll
+      for (int ui = 0; ui < UPT; ++ui) {
+        if constexpr (GUARD) {
+          if (oy0 + (g + NG * ui) / UPR >= a.Ho) continue;
+        }
         float acc[XW];
 #pragma unroll
         for (int o = 0; o < XW; ++o) acc[o] = 0.f;
-#pragma unroll KY_UNROLL
+        const float* eu = E + eoff[ui];
+        constexpr int KYU = (K == 5 && KSF <= 8) ? 1 : K;     // = KY_UNROLL (a pragma inside the lambda cannot name the enclosing local)
+#pragma unroll KYU
         for (int ky = 0; ky < K; ++ky) {
           float rowv[NCOL];
-          const float* er = E + ((size_t)(orow + ky) * IW + oxs) * ES + c;
+          const float* er = eu + ky * IW * ES;
 #pragma unroll
           for (int j = 0; j < NCOL; ++j) rowv[j] = er[j * ES];
 #pragma unroll
@@ -1153,17 +1272,23 @@ __global__ __launch_bounds__(512, (K == 5 && KSF <= 8) ? 4 : 2) void mbxd_kernel
             for (int o = 0; o < XW; ++o) acc[o] = fmaf(rowv[o + kx], w, acc[o]);
           }
         }
-        float* op = a.out + (((size_t)b * a.Ho + oy) * a.Wo + ox0 + oxs) * a.Cmid + col;
 #pragma unroll
         for (int o = 0; o < XW; ++o) {
-          if (ox0 + oxs + o < a.Wo) {
+          bool ok = true;
+          if constexpr (GUARD) ok = ox0 + (int)((g + NG * ui) % UPR) * XW + o < a.Wo;
+          if (ok) {
             const float v = swish_folded(fmaf(acc[o], sc1, sh1), mk1);
-            op[(size_t)o * a.Cmid] = v;
+            store_uniform_base(ob + (size_t)o * cm, ooff[ui], v);
             ssum += v;
           }
         }
+        // units are scheduled one after the other: hoisting the E reads of all units to the front costs 20-30 registers
+        // (and with them a block per CU)
+        __builtin_amdgcn_sched_barrier(0);
       }
-    }
+    };
+    if (full) dw_units(std::false_type());
+    else if (dcol) dw_units(std::true_type());
     if (a.se_partial) red[g * 32 + c] = ssum;
     __syncthreads();   // E may be rewritten; red[] and the next slab's operands (written after the first barrier) are complete
     if (a.se_partial && g == 0 && dcol) {
@@ -1263,6 +1388,19 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
   const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
   constexpr int B_PER = (BSLAB + 511) / 512;
   constexpr int P_PER = (NPAR + 511) / 512;
+  // loop-invariant addressing of the depthwise stage (see mbxb_kernel)
+  int eoff[UPT];
+  unsigned ooff[UPT];
+#pragma unroll
+  for (int ui = 0; ui < UPT; ++ui) {
+    const int u = g + NG * ui;
+    const int orow = u / UPR, oxs = (u % UPR) * XW;
+    eoff[ui] = (orow * IW + oxs) * ES + c;
+    ooff[ui] = (unsigned)((orow * a.Wo + oxs) * a.Cmid + c) * 4u;      // bytes
+  }
+  float* const obase = a.out + (((size_t)b * a.Ho + oy0) * a.Wo + ox0) * a.Cmid;
+  const unsigned cm = (unsigned)a.Cmid;
+  const bool full = (oy0 + TH <= a.Ho) && (ox0 + TW <= a.Wo) && ((a.Cmid & 31) == 0);
 
   // ---- slab 0: expand -> E[0] (nothing to overlap with yet)
   {
@@ -1277,10 +1415,9 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh, acc, 0, 0, 0);
     }
-    const float mk0 = mks[li];
     float* ep = E + (size_t)(wave * 32 + 4 * lh) * ES + li;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swish_folded(acc[r], mk0);
+    for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swish_core(acc[r]);    // x (-ln 2) x dropout scale: after the depthwise
   }
 
   for (int ch = 0; ch < NCH; ++ch) {
@@ -1320,7 +1457,7 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
     float wk[K * K];
 #pragma unroll
     for (int t = 0; t < K * K; ++t) wk[t] = pcur[t * 32 + c];
-    const float sc1 = pcur[K * K * 32 + c], sh1 = pcur[(K * K + 1) * 32 + c];
+    const float sc1 = pcur[K * K * 32 + c] * mks[ch * 32 + c], sh1 = pcur[(K * K + 1) * 32 + c];
     const float mk1 = mks[32 * NCH + ch * 32 + c];
     f32x16 acc;
 #pragma unroll
@@ -1341,9 +1478,7 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
     constexpr int FPM = (NF + MPS - 1) / MPS, RPM = (NCOL + MPS - 1) / MPS;
     auto e_row = [&](int st) -> const float* {
       const int ui = st / K, ky = st % K;
-      const int u = g + NG * ui;
-      const int orow = u / UPR, oxs = (u % UPR) * XW;
-      return Ec + ((size_t)(orow + ky) * IW + oxs) * ES + c;
+      return Ec + eoff[ui] + ky * IW * ES;
     };
     float rowv[2][NCOL];
     {
@@ -1394,31 +1529,34 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
       for (int o = 0; o < XW; ++o) asm volatile("" : "+v"(dacc[ui][o]));
     // ---- outputs of slab ch
     float ssum = 0.f;
-    if (dcol) {
+    float* const ob = obase + ch * 32;            // uniform
+    auto store_units = [&](auto guard) {
+      constexpr bool GUARD = decltype(guard)::value;
 #pragma unroll
       for (int ui = 0; ui < UPT; ++ui) {
-        const int u = g + NG * ui;
-        const int orow = u / UPR, oxs = (u % UPR) * XW;
-        const int oy = oy0 + orow;
-        if (oy >= a.Ho) continue;
-        float* op = a.out + (((size_t)b * a.Ho + oy) * a.Wo + ox0 + oxs) * a.Cmid + col;
+        if constexpr (GUARD) {
+          if (oy0 + (g + NG * ui) / UPR >= a.Ho) continue;
+        }
 #pragma unroll
         for (int o = 0; o < XW; ++o) {
-          if (ox0 + oxs + o < a.Wo) {
+          bool ok = true;
+          if constexpr (GUARD) ok = ox0 + (int)((g + NG * ui) % UPR) * XW + o < a.Wo;
+          if (ok) {
             const float v = swish_folded(fmaf(dacc[ui][o], sc1, sh1), mk1);
-            op[(size_t)o * a.Cmid] = v;
+            store_uniform_base(ob + (size_t)o * cm, ooff[ui], v);
             ssum += v;
           }
         }
       }
-    }
+    };
+    if (full) store_units(std::false_type());
+    else if (dcol) store_units(std::true_type());
     if (a.se_partial) red[((ch & 1) * NG + g) * 32 + c] = ssum;
     // ---- slab ch + 1: activate -> the other E buffer (its readers, depthwise ch - 1, finished before the barrier above)
     if (more) {
-      const float mk0 = mks[(ch + 1) * 32 + li];
       float* ep = En + (size_t)(wave * 32 + 4 * lh) * ES + li;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swish_folded(acc[r], mk0);
+      for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swish_core(acc[r]);
     }
     // ---- slab ch + 2 operands -> LDS: Bs[ch & 1] (its MFMAs were issued one iteration ago), par[(ch + 2) % 3]
     {

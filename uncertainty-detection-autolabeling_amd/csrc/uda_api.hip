@@ -118,6 +118,7 @@ struct uda_ctx {
   int* d_coop_err = nullptr;
   bool coop_used = false;
   bool coop_off = false;                           // set after a barrier time-out: this handle stays on the two-launch version
+  int64_t coop_fallbacks = 0;                      // post-process runs redone with two launches per epoch after such a time-out
   unsigned long long* d_merge_keys = nullptr;
   // outputs
   float *d_oboxes = nullptr, *d_oscores = nullptr, *d_oclasses = nullptr, *d_ologits = nullptr;
@@ -859,7 +860,7 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       // deferred dropout site (plan.py): the squeezed tensor is per image, its keep-scale per sample row
       a.mask = v.mask(o.drop_site);
       a.in_div = v.div(pb, ob);
-      if (o.drop_site >= 0 && !ob.per_sample) return fail(c, "op %d: deferred dropout needs a per-sample gate", oi);
+      if (o.drop_site >= 0 && !ob.per_sample && c->model.mc_samples > 1) return fail(c, "op %d: deferred dropout needs a per-sample gate", oi);
       if (pb.per_sample != src.per_sample) return fail(c, "op %d: SE sums and source disagree on the sample axis", oi);
       launch_se(a, rows, v.stream());
       break;
@@ -1208,6 +1209,7 @@ static int finish_post(uda_ctx* c) {
       // version, and keep this handle on it.
       hipMemset(c->d_coop_err, 0, sizeof(int));
       c->coop_off = true;
+      ++c->coop_fallbacks;
       c->pfx_pending.clear();
       fprintf(stderr, "[uda] cooperative NMS: grid barrier timed out; falling back to two launches per epoch\n");
       if (c->last_post_mode == UDA_POST_GLOBAL) {
@@ -1274,6 +1276,7 @@ extern "C" int uda_run(uda_ctx_t* c, int32_t post_mode, int32_t do_post) {
 }
 
 extern "C" int64_t uda_nms_prefix_fallbacks(const uda_ctx_t* c) { return c ? c->pfx_fallbacks : -1; }
+extern "C" int64_t uda_nms_coop_fallbacks(const uda_ctx_t* c) { return c ? c->coop_fallbacks : -1; }
 
 extern "C" int uda_synchronize(uda_ctx_t* c) {
   if (!c) return 1;
@@ -1399,13 +1402,24 @@ extern "C" int uda_get_head_outputs(uda_ctx_t* c, int32_t level, float* cls, flo
   return 0;
 }
 
-extern "C" int uda_set_head_outputs(uda_ctx_t* c, int32_t level, int32_t n, const float* cls, const float* box) {
+extern "C" int uda_set_head_outputs(uda_ctx_t* c, int32_t level, int32_t n, const float* cls, int64_t cls_floats,
+                                    const float* box, int64_t box_floats) {
   if (!c) return 1;
   if (level < 0 || level >= c->model.num_levels) return fail(c, "set_head_outputs: bad level %d", level);
   if (n < 1 || n > c->model.max_images) return fail(c, "set_head_outputs: n=%d", n);
   HIPC(c, hipSetDevice(c->device));
   const uda_model_t& m = c->model;
   const size_t hw = (size_t)m.level_h[level] * m.level_w[level];
+  {   // the host buffers must hold exactly what is read from them: [T_x, n, h, w, ch] (T_x = 1 for an unstacked head)
+    const int64_t want_c = (int64_t)(m.cls_stacked ? m.mc_samples : 1) * n * (int64_t)hw * c->cls_ch;
+    const int64_t want_b = (int64_t)(m.box_stacked ? m.mc_samples : 1) * n * (int64_t)hw * c->box_ch;
+    if (cls && cls_floats != want_c)
+      return fail(c, "set_head_outputs: level %d class outputs hold %lld floats, the handle expects %lld ([%d, %d, %d, %d, %d])", level,
+                  (long long)cls_floats, (long long)want_c, m.cls_stacked ? m.mc_samples : 1, n, m.level_h[level], m.level_w[level], c->cls_ch);
+    if (box && box_floats != want_b)
+      return fail(c, "set_head_outputs: level %d box outputs hold %lld floats, the handle expects %lld ([%d, %d, %d, %d, %d])", level,
+                  (long long)box_floats, (long long)want_b, m.box_stacked ? m.mc_samples : 1, n, m.level_h[level], m.level_w[level], c->box_ch);
+  }
   struct { const float* src; float* dst; int T; size_t ch; } jobs[2] = {
       {cls, c->d_cls[level], m.cls_stacked ? m.mc_samples : 1, (size_t)c->cls_ch},
       {box, c->d_box[level], m.box_stacked ? m.mc_samples : 1, (size_t)c->box_ch}};
@@ -1417,6 +1431,26 @@ extern "C" int uda_set_head_outputs(uda_ctx_t* c, int32_t level, int32_t n, cons
         HIPC(c, hipMemcpy(j.dst + ((size_t)i * j.T + t) * per, j.src + ((size_t)t * n + i) * per,
                           per * sizeof(float), hipMemcpyHostToDevice));
   }
+  c->n_images = n;
+  return 0;
+}
+
+extern "C" int uda_head_outputs_device(uda_ctx_t* c, int32_t level, int32_t which, void** dev_ptr, int64_t* floats_per_row,
+                                       int32_t* rows_per_image) {
+  if (!c || !dev_ptr) return c ? fail(c, "head_outputs_device: NULL argument") : 1;
+  if (level < 0 || level >= c->model.num_levels) return fail(c, "head_outputs_device: bad level %d", level);
+  if (which != 0 && which != 1) return fail(c, "head_outputs_device: which must be 0 (class) or 1 (box)");
+  const uda_model_t& m = c->model;
+  const int64_t hw = (int64_t)m.level_h[level] * m.level_w[level];
+  *dev_ptr = which ? (void*)c->d_box[level] : (void*)c->d_cls[level];
+  if (floats_per_row) *floats_per_row = hw * (which ? c->box_ch : c->cls_ch);
+  if (rows_per_image) *rows_per_image = (which ? m.box_stacked : m.cls_stacked) ? m.mc_samples : 1;
+  return 0;
+}
+
+extern "C" int uda_set_num_images(uda_ctx_t* c, int32_t n) {
+  if (!c) return 1;
+  if (n < 1 || n > c->model.max_images) return fail(c, "set_num_images: n=%d outside [1, %d]", n, c->model.max_images);
   c->n_images = n;
   return 0;
 }
@@ -1574,6 +1608,7 @@ extern "C" int uda_nms(uda_ctx_t* c, const float* boxes, const float* scores, in
     if (e) {           // barrier time-out: redo with the two-launch version (see finish_post)
       hipMemset(c->d_coop_err, 0, sizeof(int));
       c->coop_off = true;
+      ++c->coop_fallbacks;
       fprintf(stderr, "[uda] cooperative NMS: grid barrier timed out; falling back to two launches per epoch\n");
       run_nms(a, d_scores, max_out, c->stream);
       HIPC(c, hipStreamSynchronize(c->stream));

@@ -1,25 +1,30 @@
 """ServingDriver-shaped boundary over the HIP C-ABI library.
 
-Drop-in for the members of the reference's `infer_lib.ServingDriver`
-(src/infer_lib.py:118-296, 299-350, 416-491) that its callers use
-(inspector.py:161-169; validate_model.py:155; infer_model.py:581,787;
-calibrate_model.py:89; utils_extra.py:130-133):
+Drop-in for the reference's `infer_lib` driver classes (src/infer_lib.py:118-491) as their
+callers use them (inspector.py:161-169; validate_model.py:155; infer_model.py:581,787;
+calibrate_model.py:89; utils_extra.py:130-133) - same class names, same positional
+arguments, same members:
 
     driver = ServingDriver.create(model_dir, debug, saved_model_dir, model_name,
-                                  batch_size, only_network, model_params)
+                                  batch_size, only_network, model_params)       # :154-163
+    driver = KerasDriver(ckpt_path, debug, model_name, batch_size, only_network, model_params)        # :416-440
+    driver = SavedModelDriver(saved_model_dir, model_name, batch_size, only_network, model_params)    # :299-311
     boxes, scores, classes, valid_len[, logits] = driver.serve(uint8_images)
     cls_outputs, box_outputs = driver.predict(float_images)      # only_network=True
     driver.benchmark(images, bm_runs=10)
+    driver.visualize(image, boxes, classes, scores, uncertainty=None)
 
 Output layout = `postprocess_global` (src/postprocess.py:610-621):
 boxes [N,100,4(+4 aleatoric)(+4 epistemic)], scores [N,100], classes [N,100] or
 [N,100,1+C], valid_len [N] int32, logits [N,100,C] when `enable_softmax`.
 Arrays are fresh numpy arrays owned by the caller; errors are Python exceptions.
 
-Weights: there is no TF checkpoint reader here.  `model_dir` / `saved_model_dir`
-name an `.npz` weight set with the reference's variable names (weights.py); "_"
-(the reference's "running test: do not load any ckpt", utils_keras.py:142-144)
-or an empty path draws a random-init set.
+Weights: there is no TF runtime here, so the path argument (`ckpt_path` / `saved_model_dir`)
+names an `.npz` weight set with the reference's variable names (weights.py), or a TF2
+checkpoint prefix / directory read by `ckpt_reader` (no TensorFlow needed); "_" (the
+reference's "running test: do not load any ckpt", utils_keras.py:142-144) or an empty path
+draws a random-init set.  Keyword-only extras (device, chunk_images, weights, post_mode) are
+the build's additions and never positional, so the reference's call expressions bind unchanged.
 """
 import ctypes as C
 import time
@@ -27,7 +32,6 @@ import time
 import numpy as np
 
 from . import capi, hparams_config, plan as plan_mod, weights as weights_mod
-from .dataset_data import get_label_map
 
 
 def _ptr(a):
@@ -35,56 +39,61 @@ def _ptr(a):
 
 
 class ServingDriver:
-    """One GPU, one handle, synchronous calls (same threading contract as the reference)."""
+    """One GPU, one handle, synchronous calls (same threading contract as the reference).
+
+    `__init__(model_name, batch_size=1, only_network=False, model_params=None)` is the reference's
+    base-class signature (infer_lib.py:165-192); callers construct `KerasDriver` / `SavedModelDriver`
+    or go through `create`."""
 
     @classmethod
     def create(cls, model_dir, debug, saved_model_dir, *args, **kwargs):
-        path = saved_model_dir or model_dir
-        return cls(path, debug, *args, **kwargs)
+        """infer_lib.py:154-163: a saved-model path selects SavedModelDriver (".tflite": TfliteDriver), else KerasDriver."""
+        if saved_model_dir:
+            if str(saved_model_dir).endswith("tflite"):
+                return TfliteDriver(saved_model_dir, *args, **kwargs)
+            return SavedModelDriver(saved_model_dir, *args, **kwargs)
+        return KerasDriver(model_dir, debug, *args, **kwargs)
 
-    def __init__(self, weights_path, debug=False, model_name="efficientdet-d0", batch_size=1,
-                 only_network=False, model_params=None, device=0, chunk_images=None,
-                 weights=None, post_mode="global"):
+    def __init__(self, model_name, batch_size=1, only_network=False, model_params=None, *, weights_path=None,
+                 weights=None, device=0, chunk_images=None, post_mode="global", debug=False, post_only=False):
         self.model_name = model_name
-        self.batch_size = int(batch_size or 1)
-        self.only_network = bool(only_network)
+        self.batch_size = batch_size
+        self.only_network = only_network
         self.debug = debug
         self.params = hparams_config.get_detection_config(model_name).as_dict()
         if model_params:
-            cfg = hparams_config.Config(self.params)
-            cfg.update(dict(model_params))
-            self.params = cfg.as_dict()
+            self.params.update(model_params)          # a plain dict update, as the reference does (:186-187)
         self.params.update(dict(is_training_bn=False))
-        self.label_map = get_label_map(self.params.get("label_map", None))
+        self.label_map = self.params.get("label_map", None)
         if self.params["nms_configs"].get("pyfunc", False):
             raise ValueError("nms_configs.pyfunc=True selects the numpy NMS path (nms_np), "
                              "which is dead in the reference (postprocess.py:806) and not served here")
+        self._cap = int(batch_size or 1)              # images one uda_run holds (batch_size None/0 = the reference's dynamic batch)
 
-        if weights is None:
-            if weights_path and str(weights_path).endswith(".npz"):
-                weights = weights_mod.load_weights(weights_path)
-            else:  # "_" / "" : test mode, random init
-                weights = weights_mod.init_weights(self.params, seed=int(self.params.get("uda_seed", 0)))
+        if weights is None and not post_only:
+            weights = weights_mod.resolve_weights(weights_path, self.params)
         self.weights = weights
         if chunk_images is None:
-            chunk_images = min(self.batch_size, int(self.params.get("uda_chunk_images", 16)))
-        self.plan = plan_mod.Plan(self.params, weights, chunk_images=chunk_images, max_images=self.batch_size)
+            chunk_images = min(self._cap, int(self.params.get("uda_chunk_images", 16)))
+        self.plan = plan_mod.Plan(self.params, weights, chunk_images=chunk_images, max_images=self._cap, post_only=post_only)
         self._post_mode = capi.POST_PER_CLASS if post_mode == "per_class" else capi.POST_GLOBAL
         self._lib = capi.load()
         m, bufs, ops, sites, blob, anchors = self.plan.to_c(self._post_mode)
         self._keep = (m, bufs, ops, sites, blob, anchors)
         handle = C.c_void_p()
-        rc = self._lib.uda_create(C.byref(m), bufs, len(bufs), ops, len(ops), sites, _ptr(blob), blob.size,
+        rc = self._lib.uda_create(C.byref(m), bufs, len(bufs), ops, len(self.plan.ops), sites, _ptr(blob), blob.size,
                                   _ptr(anchors), int(device), C.byref(handle))
         if rc != 0:
             raise capi.UdaError("uda_create failed: %s" % self._lib.uda_last_error(None).decode())
         self._h = handle
+        self.device = int(device)
         self.image_size = hparams_config.parse_image_size(self.params["image_size"])
         self.T = self.plan.T
         self.M = int(self.params["nms_configs"]["max_output_size"])
         self.num_classes = int(self.params["num_classes"])
         self._seed_counter = int(self.params.get("uda_dropout_seed", 0))
         self._fixed_seed = None
+        self._run_id = 0                              # bumped by every call that rewrites the resident head outputs
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -137,8 +146,8 @@ class ServingDriver:
             raise ValueError("images must be [N, h, w, 3], got %s" % (a.shape,))
         if a.dtype != np.uint8:
             raise ValueError("serve() takes uint8 images, got %s" % a.dtype)
-        if a.shape[0] > self.batch_size:
-            raise ValueError("batch of %d images exceeds batch_size=%d" % (a.shape[0], self.batch_size))
+        if a.shape[0] > self._cap:
+            raise ValueError("batch of %d images exceeds batch_size=%d" % (a.shape[0], self._cap))
         return np.ascontiguousarray(a)
 
     def _mode(self, post_mode):
@@ -196,8 +205,10 @@ class ServingDriver:
         a = self._as_u8_batch(image_arrays)
         n, h, w = a.shape[:3]
         self._next_seed()
+        self._run_id += 1
         self._ck(self._lib.uda_set_images_u8(self._h, _ptr(a), n, h, w), "uda_set_images_u8")
         self._ck(self._lib.uda_run(self._h, mode, 1), "uda_run")
+        self._last_n = n
         return self._collect(n, mode)
 
     def class_probs(self, n):
@@ -221,24 +232,33 @@ class ServingDriver:
             probs, ent = self.class_probs(n)
         return pp.unpack_detections(self.params, det, probs, ent)
 
+    def predict_resident(self, image_arrays):
+        """The raw network on float32 [N,H,W,3] inputs; the head outputs stay in the handle (`device_heads`)."""
+        a = np.ascontiguousarray(image_arrays, dtype=np.float32)
+        H, W = self.image_size
+        if a.ndim != 4 or a.shape[1:] != (H, W, 3):
+            raise ValueError("predict() takes float images [N,%d,%d,3], got %s" % (H, W, a.shape))
+        if a.shape[0] > self._cap:
+            raise ValueError("batch of %d images exceeds batch_size=%d" % (a.shape[0], self._cap))
+        self._next_seed()
+        self._run_id += 1
+        self._ck(self._lib.uda_predict(self._h, _ptr(a), a.shape[0]), "uda_predict")
+        self._last_n = a.shape[0]
+        return a.shape[0]
+
     def predict(self, image_arrays):
         """only_network: float32 [N,H,W,3] -> (cls_outputs[levels], box_outputs[levels]) with the
         reference's shapes ([N,h,w,ch], or [T,N,h,w,ch] for a head that is MC-stacked);
         otherwise identical to serve()."""
         if not self.only_network:
             return self.serve(image_arrays)
-        a = np.ascontiguousarray(image_arrays, dtype=np.float32)
-        H, W = self.image_size
-        if a.ndim != 4 or a.shape[1:] != (H, W, 3):
-            raise ValueError("predict() takes float images [N,%d,%d,3], got %s" % (H, W, a.shape))
-        if a.shape[0] > self.batch_size:
-            raise ValueError("batch of %d images exceeds batch_size=%d" % (a.shape[0], self.batch_size))
-        self._next_seed()
-        self._ck(self._lib.uda_predict(self._h, _ptr(a), a.shape[0]), "uda_predict")
-        return self.head_outputs(a.shape[0])
+        return self.head_outputs(self.predict_resident(image_arrays))
 
     def head_outputs(self, n):
-        """Raw head outputs of the last run in the reference's layout."""
+        """Raw head outputs of the last run in the reference's layout: [N,h,w,ch], or [T,N,h,w,ch] for a head the
+        reference stacks (its own or the global dropout rate is non-zero, efficientdet_keras.py:1026-1049).  A head
+        the reference stacks but whose T samples are identical here (all its upstream rates are zero: one copy on
+        the device) is broadcast to the stacked shape."""
         p = self.plan
         A = len(self.params["aspect_ratios"]) * self.params["num_scales"]
         cls_ch = A * self.num_classes
@@ -250,28 +270,76 @@ class ServingDriver:
             c = np.empty((tc, n, h, w, cls_ch), np.float32)
             b = np.empty((tb, n, h, w, box_ch), np.float32)
             self._ck(self._lib.uda_get_head_outputs(self._h, lvl, _ptr(c), _ptr(b)), "uda_get_head_outputs")
-            # the reference stacks a head iff its (or the global) rate is non-zero
-            cls_out.append(c if p.cls_stacked else c[0])
-            box_out.append(b if p.box_stacked else b[0])
+            for out, arr, stacked, t_dev in ((cls_out, c, p.cls_stacked, tc), (box_out, b, p.box_stacked, tb)):
+                if stacked and self.T > 1:
+                    out.append(arr if t_dev == self.T else np.broadcast_to(arr, (self.T,) + arr.shape[1:]))
+                else:
+                    out.append(arr[0])
         return cls_out, box_out
+
+    def _head_array(self, arr, stacked_dev, lvl, ch, what):
+        """One level of injected head outputs -> contiguous float32 [T_dev, n, h, w, ch]; raises on any other shape
+        (the C side reads exactly T_dev * n * h * w * ch floats)."""
+        h, w = self.plan.level_hw[lvl]
+        a = np.asarray(arr, dtype=np.float32)
+        t_dev = self.T if stacked_dev else 1
+        if a.ndim == 4:
+            a = a[None]
+        if a.ndim != 5 or a.shape[2:] != (h, w, ch):
+            raise ValueError("%s outputs of level %d must be [(T,) N, %d, %d, %d], got %s" % (what, lvl, h, w, ch, np.shape(arr)))
+        if a.shape[0] != t_dev:
+            if t_dev == 1 and a.shape[0] == self.T:
+                # stacked by the reference's rules, one copy on the device (identical samples): they must agree
+                if not all(np.array_equal(a[0], a[t]) for t in range(1, a.shape[0])):
+                    raise ValueError("%s outputs of level %d carry %d different samples, but this configuration has no "
+                                     "dropout upstream of that head" % (what, lvl, a.shape[0]))
+                a = a[:1]
+            else:
+                raise ValueError("%s outputs of level %d carry %d samples on axis 0, the handle expects %d"
+                                 % (what, lvl, a.shape[0], t_dev))
+        return np.ascontiguousarray(a)
 
     def postprocess(self, cls_outputs, box_outputs, image_scales=None, post_mode=None):
         """`ServingDriver._postprocess` = postprocess_global on given head outputs (infer_lib.py:263-267);
-        post_mode="per_class" = postprocess_per_class (eval.py:117-123 via generate_detections)."""
+        post_mode="per_class" = postprocess_per_class (eval.py:117-123 via generate_detections).  Head outputs that
+        are still resident in this handle (`DeviceHeads` of its last run) are not uploaded again."""
         mode = self._mode(post_mode)
         p = self.plan
-        n = cls_outputs[0].shape[-4]
-        for lvl in range(len(p.level_hw)):
-            c = np.ascontiguousarray(cls_outputs[lvl], dtype=np.float32)
-            b = np.ascontiguousarray(box_outputs[lvl], dtype=np.float32)
-            if c.ndim == 4:
-                c = c[None]
-            if b.ndim == 4:
-                b = b[None]
-            self._ck(self._lib.uda_set_head_outputs(self._h, lvl, n, _ptr(c), _ptr(b)), "uda_set_head_outputs")
+        resident = (isinstance(cls_outputs, DeviceHeads) and isinstance(box_outputs, DeviceHeads)
+                    and cls_outputs.driver is self and cls_outputs.run_id == self._run_id == box_outputs.run_id)
+        if resident:
+            n = cls_outputs.n
+        else:
+            if len(cls_outputs) != len(p.level_hw) or len(box_outputs) != len(p.level_hw):
+                raise ValueError("expected %d pyramid levels of head outputs" % len(p.level_hw))
+            A = len(self.params["aspect_ratios"]) * self.params["num_scales"]
+            cls_ch, box_ch = A * self.num_classes, A * (8 if self.params["loss_attenuation"] else 4)
+            cs = [self._head_array(cls_outputs[l], p.cls_stacked_dev, l, cls_ch, "class") for l in range(len(p.level_hw))]
+            bs = [self._head_array(box_outputs[l], p.box_stacked_dev, l, box_ch, "box") for l in range(len(p.level_hw))]
+            n = cs[0].shape[1]
+            if n > self._cap or any(x.shape[1] != n for x in cs + bs):
+                raise ValueError("head outputs hold %s images, the handle at most %d" % (sorted({x.shape[1] for x in cs + bs}), self._cap))
+            self._run_id += 1
+            for lvl, (c, b) in enumerate(zip(cs, bs)):
+                self._ck(self._lib.uda_set_head_outputs(self._h, lvl, n, _ptr(c), c.size, _ptr(b), b.size), "uda_set_head_outputs")
         s = None if image_scales is None else np.ascontiguousarray(image_scales, dtype=np.float32)
+        if s is not None and s.shape != (n,):
+            raise ValueError("image_scales must have shape (%d,), got %s" % (n, s.shape))
         self._ck(self._lib.uda_postprocess_heads(self._h, n, _ptr(s), mode), "uda_postprocess_heads")
+        self._last_n = n
         return self._collect(n, mode)
+
+    def device_heads(self, n):
+        """(cls_outputs, box_outputs) of the last run as lazy sequences that stay on the device until indexed."""
+        return DeviceHeads(self, n, 0), DeviceHeads(self, n, 1)
+
+    def head_outputs_device(self, level, which):
+        """(device address, floats per row, rows per image) of the handle's head-output buffer (capi.DevArray wraps it
+        for torch / RCCL): rows are [image][sample]."""
+        ptr, fl, rows = C.c_void_p(), C.c_int64(), C.c_int32()
+        self._ck(self._lib.uda_head_outputs_device(self._h, int(level), int(which), C.byref(ptr), C.byref(fl), C.byref(rows)),
+                 "uda_head_outputs_device")
+        return ptr.value, fl.value, rows.value
 
     # ------------------------------------------------------------------ debug / parity accessors
     def preprocessed(self):
@@ -284,12 +352,12 @@ class ServingDriver:
 
     def preprocessed_scales(self, n):
         """(None, image scales [n]) of the last uint8 batch (host-side copy kept by the handle)."""
-        scales = np.empty((max(n, self.batch_size),), np.float32)
+        scales = np.empty((max(n, self._cap),), np.float32)
         self._ck(self._lib.uda_get_preprocessed(self._h, None, _ptr(scales)), "uda_get_preprocessed")
         return None, scales[:n]
 
     def _n_last(self):
-        return getattr(self, "_last_n", self.batch_size)
+        return getattr(self, "_last_n", self._cap)
 
     def read_buffer(self, name, n_chunk):
         """Activation `name` (plan.buffer_names) of the last chunk: [rows, H, W, C]."""
@@ -341,6 +409,11 @@ class ServingDriver:
         candidate set (identical results either way; include/uda_hip.h uda_nms_prefix_fallbacks)."""
         return int(self._lib.uda_nms_prefix_fallbacks(self._h))
 
+    def nms_coop_fallbacks(self):
+        """Post-process runs redone with two launches per epoch because the single-launch NMS grid timed out
+        (include/uda_hip.h uda_nms_coop_fallbacks); 0 in normal operation."""
+        return int(self._lib.uda_nms_coop_fallbacks(self._h))
+
     # ------------------------------------------------------------------ resident-input fast path (bench)
     def stage_images(self, image_arrays):
         """Upload uint8 images once (the PCIe leg); `run_resident` then re-runs the path on them."""
@@ -353,6 +426,7 @@ class ServingDriver:
 
     def run_resident(self, sync=True):
         self._next_seed()
+        self._run_id += 1
         self._ck(self._lib.uda_run(self._h, -1, 1), "uda_run")
         if sync:
             self._ck(self._lib.uda_synchronize(self._h), "uda_synchronize")
@@ -372,28 +446,95 @@ class ServingDriver:
         return ms.value, cnt.value
 
     # ------------------------------------------------------------------ benchmark (infer_lib.py:206-230)
-    def benchmark(self, image_arrays, bm_runs=10, trace_filename=None):
-        """3 warm-up calls, `bm_runs` timed calls of predict(); prints per-batch latency and FPS."""
+    def _benchmark(self, image_arrays, test_func, bm_runs=10, trace_filename=None):
+        """3 warm-up calls, `bm_runs` timed calls; prints per-batch latency and FPS (infer_lib.py:206-230)."""
         for _ in range(3):
-            self.predict(image_arrays)
+            test_func(image_arrays)
         start = time.perf_counter()
         for _ in range(bm_runs):
-            self.predict(image_arrays)
+            test_func(image_arrays)
         end = time.perf_counter()
         inference_time = (end - start) / bm_runs
         print("Per batch inference time: ", inference_time)
         print("FPS: ", (self.batch_size or 1) / inference_time)
         if trace_filename:
-            print("trace_filename is ignored: profile with rocprofv3 (see DESIGN.md)")
+            # the reference writes a TF profiler trace of one more call; here: per-op-kind device time of one more call
+            kinds = list(range(1, 9)) + [capi.PROF_AGGREGATE, capi.PROF_NMS, capi.PROF_PREPROCESS]
+            self.profile_enable(kinds)
+            test_func(image_arrays)
+            self.synchronize()
+            import json
+            with open(trace_filename, "w") as f:
+                json.dump({str(k): dict(zip(("ms", "launches"), self.profile_read(k))) for k in kinds}, f)
+            self.profile_enable([])
         return inference_time
 
+    def benchmark(self, image_arrays, bm_runs=10, trace_filename=None):
+        return self._benchmark(image_arrays, self.predict, bm_runs, trace_filename)
+
     def visualize(self, image, boxes, classes, scores, uncertainty=None, **kwargs):
-        raise NotImplementedError("host-side drawing (visualize/vis_utils.py) is outside the hot path")
+        """Visualize prediction on image (infer_lib.py:194-204): host drawing, not on the hot path."""
+        from .visualize import visualize_image
+        return visualize_image(image, boxes, np.asarray(classes).astype(int), scores, self.label_map, uncertainty, **kwargs)
 
 
-# the reference's concrete driver names resolve to the same implementation
-KerasDriver = ServingDriver
-SavedModelDriver = ServingDriver
+class KerasDriver(ServingDriver):
+    """infer_lib.py:416-491: `KerasDriver(ckpt_path, debug, model_name, batch_size, only_network, model_params)`."""
+
+    def __init__(self, ckpt_path, debug, *args, **kwargs):
+        kwargs.setdefault("weights_path", ckpt_path)
+        super().__init__(*args, **kwargs)
+        self.debug = debug
+
+    def export(self, *args, **kwargs):
+        raise NotImplementedError("SavedModel / TFLite / TensorRT export is TensorFlow tooling outside the hot path "
+                                  "(infer_lib.py:493-616); save the weight set with weights.save_weights instead")
+
+
+class SavedModelDriver(ServingDriver):
+    """infer_lib.py:299-350: `SavedModelDriver(saved_model_dir_or_frozen_graph, model_name, batch_size, only_network,
+    model_params)`.  The path names a weight set here (module docstring): there is no TF graph to load."""
+
+    def __init__(self, saved_model_dir_or_frozen_graph, *args, **kwargs):
+        kwargs.setdefault("weights_path", saved_model_dir_or_frozen_graph)
+        super().__init__(*args, **kwargs)
+
+
+class TfliteDriver(ServingDriver):
+    """infer_lib.py:353-413.  TFLite flatbuffers are not served by the HIP path."""
+
+    def __init__(self, tflite_path, *args, **kwargs):
+        raise ValueError("a .tflite model (%s) cannot be served by the HIP path: pass a checkpoint / .npz weight set" % (tflite_path,))
+
+
+class DeviceHeads:
+    """The five per-level head outputs of a driver's last run, left on the device.
+
+    Behaves as the list the reference's model returns (len 5, indexable, iterable; elements [N,h,w,ch] or
+    [T,N,h,w,ch]); the download happens on first access.  `ServingDriver.postprocess` and
+    `postprocess.generate_detections` recognise it and post-process in place, so the eval flow
+    `cls, box = mc_eval(model, images, config); generate_detections(config, cls, box, ...)` (eval.py:108-123)
+    never moves the 700 MB of head outputs through the host."""
+
+    def __init__(self, driver, n, which):
+        self.driver, self.n, self.which, self.run_id = driver, int(n), int(which), driver._run_id
+        self._host = None
+
+    def _fetch(self):
+        if self._host is None:
+            if self.run_id != self.driver._run_id:
+                raise RuntimeError("these head outputs were overwritten by a later run of the driver")
+            self._host = self.driver.head_outputs(self.n)[self.which]
+        return self._host
+
+    def __len__(self):
+        return len(self.driver.plan.level_hw)
+
+    def __getitem__(self, i):
+        return self._fetch()[i]
+
+    def __iter__(self):
+        return iter(self._fetch())
 
 
 class EnsembleDriver:
@@ -412,14 +553,14 @@ class EnsembleDriver:
         params = dict(model_params or {})
         if params.get("mc_dropout"):
             raise ValueError("ensemble members are deterministic networks: mc_dropout must be off")
-        self.members = [ServingDriver("_", False, model_name, batch_size=batch_size, model_params=params, weights=w,
+        self.members = [ServingDriver(model_name, batch_size=batch_size, model_params=params, weights=w,
                                       device=device, chunk_images=chunk_images) for w in member_weights]
         M = len(self.members)
         if M < 2:
             raise ValueError("an ensemble needs at least two members")
         # the aggregator only post-processes: it is planned as an M-sample MC model of the same geometry
         post_params = dict(params, mc_dropout=True, mc_dropoutrate=1e-9, mc_dropoutsamp=M)
-        self.post = ServingDriver("_", False, model_name, batch_size=batch_size, model_params=post_params,
+        self.post = ServingDriver(model_name, batch_size=batch_size, model_params=post_params,
                                   weights=member_weights[0], device=device, chunk_images=1)
         self.params = self.post.params
         self.batch_size = batch_size
@@ -432,6 +573,7 @@ class EnsembleDriver:
             drv._ck(lib.uda_set_images_u8(drv._h, _ptr(a), n, h, w), "uda_set_images_u8")
             drv._ck(lib.uda_run(drv._h, -1, 0), "uda_run")
             self.post._ck(lib.uda_copy_heads(self.post._h, drv._h, n, m), "uda_copy_heads")
+        self.post._run_id += 1
         _, scales = self.members[0].preprocessed_scales(n)
         mode = self.post._mode(post_mode)
         s = np.ascontiguousarray(scales, dtype=np.float32)

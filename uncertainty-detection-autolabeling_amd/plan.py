@@ -73,6 +73,10 @@ def mbx_supported(cin, cmid, k, stride):
     import os
     if not (int(os.environ.get("UDA_FUSE_MBX", "1")) and cin % 8 == 0 and cmid % 4 == 0 and k in (3, 5)):
         return False
+    if int(os.environ.get("UDA_PW_TERMS", "3")) == 6:
+        # six cross terms = float32-equivalent products EVERYWHERE: the fused MBConv kernels carry two bf16 pieces per
+        # operand (three terms), so under this switch the expands run as stand-alone six-term 1x1 convs + depthwise
+        return False
     if mbx_deep(cin):       # mirror of mbxd_supported: stride 1, 16-deep k-steps of Cin + 1 in {6, 8, 13, 14}, split-bf16 path on
         return (int(os.environ.get("UDA_FUSE_MBXD", "1")) and int(os.environ.get("UDA_PW_TERMS", "3")) != 0
                 and int(os.environ.get("UDA_MBX_BF16", "1")) and stride == 1 and (cin + 1 + 15) // 16 in (6, 8, 13, 14)
@@ -96,8 +100,9 @@ class _Buf:
 class Plan:
     """bufs / ops / drop sites / weight blob / anchors ready for `uda_create`."""
 
-    def __init__(self, config, weights, chunk_images=1, max_images=1):
+    def __init__(self, config, weights, chunk_images=1, max_images=1, post_only=False):
         self.cfg = dict(config)
+        self.post_only = bool(post_only)
         self.w = weights
         self.T = arch.mc_flags(self.cfg)[2]
         self.cls_stacked, self.box_stacked, _ = arch.mc_flags(self.cfg)
@@ -112,9 +117,25 @@ class Plan:
         self.fuse_sep = bool(int(os.environ.get("UDA_FUSE_SEP", "1"))) and int(os.environ.get("UDA_PW_TERMS", "3")) != 0
         self.fuse_proj = (bool(int(os.environ.get("UDA_FUSE_PROJ", "1"))) and int(os.environ.get("UDA_PW_TERMS", "3")) != 0
                           and bool(int(os.environ.get("UDA_MBX_BF16", "1"))) and bool(int(os.environ.get("UDA_FUSE_MBX", "1"))))
+        if self.post_only:
+            self._post_only_layout()
+            return
         self._build_sites()
         self._lower()
         self._plan_memory()
+
+    def _post_only_layout(self):
+        """A handle that only post-processes injected head outputs (postprocess.generate_detections on arrays that
+        came from elsewhere, ensemble aggregation): no ops, no weights, no arena - just the pyramid geometry and
+        which heads carry the sample axis (the reference's stacking rule, efficientdet_keras.py:1026-1049)."""
+        cfg = self.cfg
+        fs = get_feat_sizes(cfg["image_size"], cfg["max_level"])
+        self.level_hw = [tuple(fs[l]) for l in range(cfg["min_level"], cfg["max_level"] + 1)]
+        self.cls_stacked_dev = bool(self.cls_stacked and self.T > 1)
+        self.box_stacked_dev = bool(self.box_stacked and self.T > 1)
+        self._buf(1, 1, 4, False, name="unused")
+        self.arena_floats = ALIGN
+        self.fpn_out, self.head_out = [], {"class": [], "box": []}
 
     # ------------------------------------------------------------------ weights
     def _pack(self, arr):
@@ -542,7 +563,7 @@ class Plan:
             bufs[i].H, bufs[i].W, bufs[i].C = b.H, b.W, b.C
             bufs[i].per_sample = int(b.per_sample)
             bufs[i].offset, bufs[i].kind, bufs[i].level = int(b.offset), b.kind, b.level
-        ops = (capi.Op * len(self.ops))()
+        ops = (capi.Op * max(1, len(self.ops)))()
         for i, o in enumerate(self.ops):
             c = ops[i]
             c.kind = o["kind"]

@@ -1,13 +1,73 @@
-"""Legacy detection row formats on top of the driver's output tuple.
+"""The reference's `postprocess` entry points on the HIP path (src/postprocess.py:472-887), same argument order.
 
-Mirrors `generate_detections_from_nms_output` / `generate_detections` / `transform_detections`
-of the reference (src/postprocess.py:743-887): pure re-packing of <=100 rows per image that the
-reference does with tf.stack on the host side of the path; the arithmetic (network, decode, NMS)
-stays on the GPU behind `ServingDriver`.
+  postprocess_global(params, cls_outputs, box_outputs, image_scales=None)      :472-621   (rows a8-a16)
+  postprocess_per_class(params, cls_outputs, box_outputs, image_scales=None)   :719-740   (row a17)
+  generate_detections(params, cls_outputs, box_outputs, image_scales, image_ids, flip=False, per_class_nms=True)  :788-871
+  generate_detections_from_nms_output / transform_detections                   :743-785, :874-887   (row a19)
+
+The arithmetic (MC aggregation, decode, NMS) runs on the GPU in a `ServingDriver` handle.  Head outputs that are
+`infer_lib.DeviceHeads` of a driver's last run (what `efficientdet_keras.EfficientDetNet` / `utils_extra.mc_eval`
+of this package return) are post-processed where they are; plain arrays are uploaded into a post-process-only
+handle that is created on first use and cached per configuration.  The legacy row formats are pure re-packing
+of <= 100 rows per image, which the reference does with tf.stack on the host side of the path.
 """
+import json
+
 import numpy as np
 
 from .hparams_config import parse_image_size
+
+CLASS_OFFSET = 1
+_POST_DRIVERS = {}
+
+
+def _params_dict(params):
+    return params.as_dict() if hasattr(params, "as_dict") else dict(params)
+
+
+def _post_driver(params, n):
+    """A post-process-only handle for `params` holding at least n images (cached)."""
+    from .infer_lib import ServingDriver
+    p = _params_dict(params)
+    key = json.dumps({k: p[k] for k in sorted(p) if k not in ("label_map",)}, sort_keys=True, default=str)
+    have = _POST_DRIVERS.get(key)
+    if have is not None and have._cap >= n:
+        return have
+    if have is not None:
+        have.close()
+    d = ServingDriver(p.get("name") or "efficientdet-d0", max(int(n), 1), False, p, post_only=True, chunk_images=1)
+    _POST_DRIVERS[key] = d
+    return d
+
+
+def _resident_driver(cls_outputs, box_outputs):
+    d = getattr(cls_outputs, "driver", None)
+    if d is not None and getattr(box_outputs, "driver", None) is d and cls_outputs.run_id == d._run_id == box_outputs.run_id:
+        return d
+    return None
+
+
+def _run(params, cls_outputs, box_outputs, image_scales, mode, driver=None):
+    d = driver or _resident_driver(cls_outputs, box_outputs)
+    if d is not None and driver is None:       # resident heads: hand over the DeviceHeads (their T = 1 view included)
+        c = getattr(cls_outputs, "heads", cls_outputs)
+        b = getattr(box_outputs, "heads", box_outputs)
+        return d.postprocess(c, b, image_scales, post_mode=mode)
+    if d is None:
+        n = np.shape(cls_outputs[0])[-4]
+        d = _post_driver(params, n)
+    return d.postprocess(cls_outputs, box_outputs, image_scales, post_mode=mode)
+
+
+def postprocess_global(params, cls_outputs, box_outputs, image_scales=None):
+    """(boxes [N,M,4(+4)(+4)], scores, classes [N,M(,1+C)], valid_len[, logits]) - src/postprocess.py:472-621."""
+    return _run(params, cls_outputs, box_outputs, image_scales, "global")
+
+
+def postprocess_per_class(params, cls_outputs, box_outputs, image_scales=None):
+    """(boxes [N,M,4], scores, classes, valid_len) - src/postprocess.py:719-740 (the reference's logits output of this
+    mode is corrupted by a variable overwrite, :659-666, and is not produced)."""
+    return _run(params, cls_outputs, box_outputs, image_scales, "per_class")
 
 
 def generate_detections_from_nms_output(nms_boxes_bs, nms_classes_bs, nms_scores_bs, image_ids,
@@ -28,19 +88,21 @@ def generate_detections_from_nms_output(nms_boxes_bs, nms_classes_bs, nms_scores
     return np.stack(cols, axis=-1).astype(np.float32)
 
 
-def generate_detections(driver, params, cls_outputs, box_outputs, image_scales, image_ids, flip=False,
-                        per_class_nms=True):
-    """The legacy interface over raw head outputs (postprocess.py:788-871): post-process on the GPU
-    (`driver.postprocess`), then pack rows.  The numpy-NMS branch (`nms_configs.pyfunc`) is dead in
-    the reference (key typo at :806) and is rejected by the driver."""
-    _, width = parse_image_size(params["image_size"])
+def generate_detections(params, cls_outputs, box_outputs, image_scales, image_ids, flip=False, per_class_nms=True,
+                        driver=None):
+    """The legacy interface over raw head outputs (src/postprocess.py:788-871; caller eval.py:117-123): post-process on
+    the GPU, then pack [id, x, y, x2, y2, score, class(, logits...)] rows.  `driver` (keyword-only use) pins the
+    handle; by default resident heads are processed in their own handle, arrays in a cached post-process handle.  The
+    numpy-NMS branch (`nms_configs.pyfunc`) is dead in the reference (key typo `enable_softnax` at :806) and is
+    rejected by the driver."""
+    p = _params_dict(params)
+    _, width = parse_image_size(p["image_size"])
     widths = np.asarray(image_scales, dtype=np.float32)[:, None] * np.float32(width)
-    out = driver.postprocess(cls_outputs, box_outputs, image_scales,
-                             post_mode="per_class" if per_class_nms else "global")
+    out = _run(p, cls_outputs, box_outputs, image_scales, "per_class" if per_class_nms else "global", driver)
     boxes, scores, classes = out[0][..., :4], out[1], out[2]
     if classes.ndim == 3:
         classes = classes[..., 0]
-    logits = out[4] if (len(out) > 4 and params["enable_softmax"]) else None
+    logits = out[4] if (len(out) > 4 and p["enable_softmax"]) else None
     return generate_detections_from_nms_output(boxes, classes, scores, image_ids, widths, flip, logits)
 
 

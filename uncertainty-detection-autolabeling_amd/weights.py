@@ -196,3 +196,19 @@ def save_weights(path, w):
 def load_weights(path):
     with np.load(path) as z:
         return {k: z[k].astype(np.float32) for k in z.files}
+
+
+def resolve_weights(path, config):
+    """The weight set a driver's path argument names (infer_lib.KerasDriver / SavedModelDriver):
+      "_" / "" / None  the reference's test mode ("do not load any ckpt", utils_keras.py:142-144): random init,
+                       seed = config["uda_seed"] (default 0)
+      *.npz            a weight set saved by `save_weights` (reference variable names)
+      anything else    a TF2 checkpoint prefix or directory (utils_keras.restore_ckpt, :125-235), read without
+                       TensorFlow by `ckpt_reader`."""
+    if path is None or str(path) in ("", "_"):
+        return init_weights(config, seed=int(config.get("uda_seed", 0)))
+    path = str(path)
+    if path.endswith(".npz"):
+        return load_weights(path)
+    from . import ckpt_reader
+    return ckpt_reader.load_checkpoint(path, config)
