@@ -201,6 +201,20 @@ enum uda_calib_mode { UDA_CALIB_TS_ALL = 0, UDA_CALIB_TS_PERCOO = 1, UDA_CALIB_I
 int uda_calibrate_box(uda_ctx_t* ctx, int32_t col0, int32_t mode, int32_t relative, int32_t n_tables,
                       const int32_t* tab_off, const double* xs, const double* ys, const float* temps, float* out);
 
+/* Calibrated class probabilities of the last global post-process (class half; CalibrateClass._perform_class_calib /
+ * calibrate_class, utils_class.py:109-272), on the device next to the logits they refine.  UDA_CLS_TS: logits / temps[c]
+ * (ts_all: the same temperature num_classes times; ts_percls: one per class), stable softmax.  UDA_CLS_ISO_ALL / _PERCLS:
+ * stable softmax, then the fitted isotonic table (1, or one per class; thresholds as in uda_calibrate_box), re-normalised to
+ * sum 1.  draws == 0: the mean logits are calibrated (model without MC class uncertainty).  draws > 0 (the reference uses 10):
+ * that many logit vectors ~ Normal(mean logits, MC std of the logits) are calibrated; probs = their mean, uncert = their
+ * population std, entropy = entropy of the mean (needs the class-std columns: MC dropout on the class head, argmax path).
+ * The draws come from the build's Philox stream with `seed` (TFP's stream cannot be reproduced).
+ * probs [n, M, num_classes], entropy [n, M], uncert [n, M, num_classes] (may be NULL). */
+enum uda_class_calib_mode { UDA_CLS_TS = 0, UDA_CLS_ISO_ALL = 1, UDA_CLS_ISO_PERCLS = 2 };
+int uda_calibrate_class(uda_ctx_t* ctx, int32_t mode, int32_t n_tables, const int32_t* tab_off, const double* xs,
+                        const double* ys, const float* temps, int32_t draws, uint64_t seed, float* probs, float* entropy,
+                        float* uncert);
+
 /* Raw head outputs of the last run, level `level`: class [T_c, n, h, w, A*C] and
  * box [T_b, n, h, w, 4A or 8A] in the reference's stacking order (T axis first; T_x = 1
  * and the axis is dropped by the caller when that head is not stacked). */

@@ -723,3 +723,46 @@ def test_box_uncertainty_calibration_matches_reference_restatement():
     with pytest.raises(ValueError):
         cal.calibrate_boxuncert(2, "albox", "nonsense")
     d.close()
+
+
+def test_class_calibration_matches_reference_restatement():
+    """SURVEY 8f.2, class half, on the device: every `_perform_class_calib` method (utils_class.py:109-187) on the selected
+    rows against the numpy restatement (pinned against sklearn in tests/test_oracle_kats.py) - without MC class
+    uncertainty (mean logits) and with it (10 Philox-normal draws per logit, mean / std of the calibrated probabilities)."""
+    from oracle import calib_ref as CR
+    from uda_amd.calibration import ClassCalibrator, IsoTable
+    from common import LOSS_ATT
+    rng = np.random.default_rng(19)
+
+    def table():
+        xs = np.sort(rng.uniform(0, 1, 14)) + np.arange(14) * 1e-4
+        return xs, np.sort(rng.uniform(0, 1, 14))
+    for over, with_unc in ((LOSS_ATT, False), (FULL_MC, True)):
+        p = make_params(**over)
+        C = p["num_classes"]
+        w = make_weights(p, cls_spread=20.0)
+        d = _driver(p, w, 2)
+        d.set_dropout_seed(5)
+        det = d.serve(make_images(2, 128, 192))
+        models = dict(ts_all=1.9, ts_percls=np.linspace(0.7, 2.2, C), iso_all=table(), iso_percls=[table() for _ in range(C)])
+        dev = dict(ts_all=1.9, ts_percls=models["ts_percls"], iso_all=IsoTable(*models["iso_all"]),
+                   iso_percls=[IsoTable(*t) for t in models["iso_percls"]])
+        cal = ClassCalibrator(d, dev, calib_method="iso_percls", draws=10, seed=77)
+        logits = det[4].reshape(-1, C)
+        unc = det[2][..., 1:].reshape(-1, C) if with_unc else None
+        for method in ("ts_all", "ts_percls", "iso_all", "iso_percls"):
+            got = cal.perform_class_calib(2, method)
+            want = CR.perform_class_calib(method, models, logits, unc, draws=10, seed=77)
+            assert len(got) == len(want) == (3 if with_unc else 2)
+            np.testing.assert_allclose(got[1].reshape(-1, C), want[1], rtol=5e-5, atol=2e-6, err_msg=method)
+            np.testing.assert_allclose(got[0].reshape(-1), want[0], rtol=1e-4, atol=1e-5, err_msg=method)
+            if with_unc:
+                np.testing.assert_allclose(got[2].reshape(-1, C), want[2], rtol=1e-3, atol=2e-6, err_msg=method)
+                assert (got[2] > 0).any()
+        full = cal.calibrate_class(2)
+        assert len(full) == (14 if with_unc else 9)             # the reference's return tuple (utils_class.py:247-272)
+        sel = cal.perform_class_calib(2, "iso_percls")
+        np.testing.assert_array_equal(full[1 if with_unc else 0], sel[0])
+        with pytest.raises(ValueError):
+            cal.perform_class_calib(2, "nonsense")
+        d.close()

@@ -282,3 +282,43 @@ def test_isotonic_table_matches_sklearn():
     got = CR.iso_predict((iso.X_thresholds_, iso.y_thresholds_), q)
     np.testing.assert_allclose(got, iso.predict(q), rtol=1e-6, atol=1e-7)
     assert got.dtype == np.float32
+
+
+def test_class_calibration_restatement_matches_sklearn_models():
+    """SURVEY 8f.2, class half (utils_class.py:109-187): the oracle's temperature / isotonic class calibration against the
+    reference's recipe executed with the REAL sklearn IsotonicRegression objects it pickles
+    (calibrate_classification.py:53-70: IsotonicRegression(y_min=0, y_max=1, out_of_bounds="clip"))."""
+    sk = pytest.importorskip("sklearn.isotonic")
+    from oracle import calib_ref as CR, unpack_ref as U
+    rng = np.random.default_rng(11)
+    C = 7
+    logits = rng.normal(0, 3, (60, C)).astype(np.float32)
+    probs = U.stable_softmax(logits)
+    onehot = (rng.uniform(size=probs.shape) < probs).astype(np.float64)
+    iso_all = sk.IsotonicRegression(y_min=0, y_max=1, out_of_bounds="clip").fit(probs.flatten(), onehot.flatten())
+    iso_cls = [sk.IsotonicRegression(y_min=0, y_max=1, out_of_bounds="clip").fit(probs[:, i], onehot[:, i]) for i in range(C)]
+    tab = lambda m: (m.X_thresholds_, m.y_thresholds_)
+    models = dict(ts_all=1.7, ts_percls=np.linspace(0.8, 2.4, C), iso_all=tab(iso_all), iso_percls=[tab(m) for m in iso_cls])
+    test = rng.normal(0, 3, (40, C)).astype(np.float32)
+    # the reference's recipe, literally, with the sklearn objects
+    want = {}
+    want["ts_all"] = U.stable_softmax(test / np.float32(1.7))
+    want["ts_percls"] = U.stable_softmax(test / models["ts_percls"].astype(np.float32))
+    p = U.stable_softmax(test)
+    post = iso_all.predict(p.flatten()).reshape(p.shape)
+    want["iso_all"] = post / np.stack([np.sum(post, axis=-1)] * C, axis=-1)
+    post = np.stack([iso_cls[i].predict(p[:, i]) for i in range(C)], axis=1)
+    want["iso_percls"] = post / np.stack([np.sum(post, axis=-1)] * C, axis=-1)
+    for method, w in want.items():
+        ent, prob = CR.perform_class_calib(method, models, test)
+        np.testing.assert_allclose(prob, w, rtol=2e-6, atol=1e-7, err_msg=method)
+        went = -np.sum(w * np.nan_to_num(np.log2(np.maximum(w, 10 ** -7))), axis=1)
+        np.testing.assert_allclose(ent, went, rtol=1e-5, atol=1e-6, err_msg=method)
+        np.testing.assert_allclose(prob.sum(1), 1.0, rtol=1e-5)
+    # sampling leg: the Philox normal stream is standard normal, and the sampled calibration returns mean / std over the draws
+    z = CR.philox_normal(7, np.arange(200000, dtype=np.uint32), np.uint32(3), np.uint32(1), 0x5A)
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01 and abs(((z ** 3).mean())) < 0.03
+    unc = np.abs(rng.normal(0, 0.3, test.shape)).astype(np.float32)
+    ent, prob, su = CR.perform_class_calib("ts_all", models, test, unc, draws=10, seed=5)
+    assert prob.shape == test.shape and su.shape == test.shape and (su > 0).all() and ent.shape == (40,)
+    np.testing.assert_allclose(prob.sum(1), 1.0, rtol=1e-5)

@@ -238,5 +238,5 @@ def test_prediction_data_records_round_trip(tmp_path):
     r0 = back[0]
     assert list(r0)[:6] == ["image_name", "score_thresh", "top_5scores", "det_score", "bbox", "class"]
     assert r0["image_name"] == "000001.jpg" and r0["uncalib_albox"][1] == 0.0 and "uncalib_mcbox" not in r0
-    assert r0["logits"] == [float(v) for v in np.around(un["logits"][0, 0], 4)] and len(r0["iso_all_albox"]) == 4
+    assert r0["logits"] == [float(str(v)) for v in np.around(un["logits"][0, 0], 4)] and len(r0["iso_all_albox"]) == 4
     assert isinstance(r0["entropy"], float) and len(r0["probab"]) == C and len(r0["uncalib_mcclass"]) == C

@@ -24,6 +24,7 @@ RS_NONE, RS_NEAREST_UP, RS_MAXPOOL = 0, 1, 2
 DECODE_PLAIN, DECODE_LNORM, DECODE_FALSEDEC = 0, 1, 2
 POST_GLOBAL, POST_PER_CLASS = 0, 1
 CALIB_TS_ALL, CALIB_TS_PERCOO, CALIB_ISO_ALL, CALIB_ISO_PERCOO, CALIB_ISO_PERCLSCOO = 0, 1, 2, 3, 4
+CLS_TS, CLS_ISO_ALL, CLS_ISO_PERCLS = 0, 1, 2
 PROF_AGGREGATE, PROF_NMS, PROF_PREPROCESS = 16, 17, 18
 
 
@@ -84,6 +85,7 @@ _SIGNATURES = {
     "uda_detection_cols": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "uda_get_class_probs": (C.c_int, [_P, _P, _P]),
     "uda_calibrate_box": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
+    "uda_calibrate_class": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_uint64, _P, _P, _P]),
     "uda_serve": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "uda_get_head_outputs": (C.c_int, [_P, C.c_int32, _P, _P]),
     "uda_set_head_outputs": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int64, _P, C.c_int64]),

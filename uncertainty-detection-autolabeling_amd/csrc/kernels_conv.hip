@@ -703,23 +703,6 @@ void launch_fuse(const FuseArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------ Philox masks
 // counter = (c >> 2, row, site, 0), key = (seed lo, seed hi); word c & 3 of the 4 outputs;
 // u = (word >> 8) * 2^-24; keep iff u >= rate; scale = 1/(1-rate).   (DESIGN.md "dropout stream")
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
 __global__ __launch_bounds__(256) void philox_kernel(float* masks, const int64_t* site_off,
                                                      const int32_t* site_ch, const float* site_rate,
                                                      int rows, uint32_t row_base, int max_c4, uint64_t seed) {

@@ -2269,6 +2269,80 @@ void launch_calib(const CalibArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(calib_kernel, dim3((a.rows + 127) / 128), dim3(128), 0, s, a);
 }
 
+// ------------------------------------------------------------------------------------ class calibration (row f2)
+// CalibrateClass._perform_class_calib (utils_class.py:109-187) on the selected rows: temperature scaling of the logits
+// (one temperature or one per class) followed by the stable softmax, or isotonic regression of the softmax
+// probabilities (one table or one per class) followed by re-normalisation to sum 1; entropy -sum p log2(max(p, 1e-7)).
+// With MC class uncertainty the reference draws 10 logit vectors from Normal(mean logits, MC std), calibrates each,
+// and returns mean / population std of the calibrated probabilities and the entropy of the mean; the draws come from
+// the build's Philox stream (philox_normal: counter (class, row, draw), tag 0x5A) instead of TFP's.
+__device__ __forceinline__ void class_calib_one(const ClsCalibArgs& a, const float* z, float* p) {
+  const int C = a.C;
+  if (a.mode == UDA_CLS_TS) {
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) { p[c] = z[c] / a.temps[c]; mx = fmaxf(mx, p[c]); }
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) { p[c] = expf(p[c] - mx); s = s + p[c]; }
+    for (int c = 0; c < C; ++c) p[c] = p[c] / s;
+    return;
+  }
+  float mx = -INFINITY;
+  for (int c = 0; c < C; ++c) mx = fmaxf(mx, z[c]);
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) { p[c] = expf(z[c] - mx); s = s + p[c]; }
+  float t = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const int tb = a.mode == UDA_CLS_ISO_ALL ? 0 : c;
+    const int m = a.tab_off[tb + 1] - a.tab_off[tb];
+    p[c] = iso_predict(a.xs + a.tab_off[tb], a.ys + a.tab_off[tb], m, p[c] / s);
+    t = t + p[c];
+  }
+  for (int c = 0; c < C; ++c) p[c] = p[c] / t;
+}
+
+constexpr int CLS_MAX = 128;
+__global__ __launch_bounds__(64) void class_calib_kernel(ClsCalibArgs a) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= a.rows) return;
+  const int C = a.C;
+  const float* lg = a.logits + (size_t)r * C;
+  float z[CLS_MAX], p[CLS_MAX];
+  float* out = a.probs + (size_t)r * C;
+  if (a.draws <= 0) {
+    for (int c = 0; c < C; ++c) z[c] = lg[c];
+    class_calib_one(a, z, p);
+    for (int c = 0; c < C; ++c) out[c] = p[c];
+  } else {
+    const float* sg = a.classes + (size_t)r * a.cls_cols + 1;
+    float mean[CLS_MAX], sq[CLS_MAX];
+    for (int c = 0; c < C; ++c) { mean[c] = 0.f; sq[c] = 0.f; }
+    for (int d = 0; d < a.draws; ++d) {
+      for (int c = 0; c < C; ++c) z[c] = lg[c] + sg[c] * (float)philox_normal(a.seed, (uint32_t)c, (uint32_t)r, (uint32_t)d, 0x5Au);
+      class_calib_one(a, z, p);
+      for (int c = 0; c < C; ++c) mean[c] = mean[c] + p[c];
+    }
+    for (int c = 0; c < C; ++c) mean[c] = mean[c] / (float)a.draws;
+    for (int d = 0; d < a.draws; ++d) {           // second pass over the same draws: population std around the mean
+      for (int c = 0; c < C; ++c) z[c] = lg[c] + sg[c] * (float)philox_normal(a.seed, (uint32_t)c, (uint32_t)r, (uint32_t)d, 0x5Au);
+      class_calib_one(a, z, p);
+      for (int c = 0; c < C; ++c) { const float dl = p[c] - mean[c]; sq[c] = sq[c] + dl * dl; }
+    }
+    for (int c = 0; c < C; ++c) {
+      out[c] = mean[c];
+      if (a.uncert) a.uncert[(size_t)r * C + c] = sqrtf(sq[c] / (float)a.draws);
+      p[c] = mean[c];
+    }
+  }
+  float h = 0.f;
+  for (int c = 0; c < C; ++c) h = h + p[c] * log2f(fmaxf(p[c], 1e-7f));
+  a.entropy[r] = -h;
+}
+
+void launch_class_calib(const ClsCalibArgs& a, hipStream_t s) {
+  if (a.rows <= 0) return;
+  hipLaunchKernelGGL(class_calib_kernel, dim3((a.rows + 63) / 64), dim3(64), 0, s, a);
+}
+
 // ------------------------------------------------------------------------------------ numpy NMS family (row a18)
 // nms_np.hard_nms / diou_nms / soft_nms (reference src/nms_np.py:30-192): boxes x1,y1,x2,y2 with the +1 pixel
 // convention.  One block per problem (a class of an image); T = double for the float64 arrays the family functions

@@ -1369,6 +1369,68 @@ extern "C" int uda_calibrate_box(uda_ctx_t* c, int32_t col0, int32_t mode, int32
   return 0;
 }
 
+extern "C" int uda_calibrate_class(uda_ctx_t* c, int32_t mode, int32_t n_tables, const int32_t* tab_off, const double* xs,
+                                   const double* ys, const float* temps, int32_t draws, uint64_t seed, float* probs,
+                                   float* entropy, float* uncert) {
+  if (!c || !probs || !entropy) return c ? fail(c, "calibrate_class: NULL output") : 1;
+  const uda_model_t& m = c->model;
+  if (c->last_post_mode != UDA_POST_GLOBAL || !m.enable_softmax)
+    return fail(c, "calibrate_class: needs the logits of the global post-process (enable_softmax)");
+  if (mode < UDA_CLS_TS || mode > UDA_CLS_ISO_PERCLS) return fail(c, "calibrate_class: unknown mode %d", mode);
+  const int C = m.num_classes;
+  if (C > 128) return fail(c, "calibrate_class: more than 128 classes");
+  if (mode == UDA_CLS_TS && !temps) return fail(c, "calibrate_class: temperature scaling needs %d temperatures", C);
+  const int want = mode == UDA_CLS_ISO_ALL ? 1 : C;
+  if (mode != UDA_CLS_TS && (n_tables != want || !tab_off || !xs || !ys))
+    return fail(c, "calibrate_class: mode %d needs %d isotonic tables, got %d", mode, want, n_tables);
+  const int cc = cls_cols_of(m, UDA_POST_GLOBAL);
+  if (draws < 0 || draws > 1000) return fail(c, "calibrate_class: draws %d outside [0, 1000]", draws);
+  if (draws > 0 && cc != 1 + C)
+    return fail(c, "calibrate_class: sampling needs the MC std of every class logit (MC dropout on the class head, max_nms_inputs = 0)");
+  HIPC(c, hipSetDevice(c->device));
+  if (int rc = finish_post(c)) return rc;
+  const size_t rows = (size_t)c->last_n * m.max_output_size;
+  double *d_xs = nullptr, *d_ys = nullptr;
+  int32_t* d_off = nullptr;
+  float *d_t = nullptr, *d_p = nullptr, *d_e = nullptr, *d_u = nullptr;
+  hipError_t e = hipSuccess;
+  auto up = [&](auto** dst, const void* src, size_t bytes) {
+    if (e != hipSuccess) return;
+    e = hipMalloc((void**)dst, bytes ? bytes : 1);
+    if (e == hipSuccess && bytes) e = hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, c->stream);
+  };
+  if (mode != UDA_CLS_TS) {
+    for (int t = 0; t < n_tables; ++t)
+      if (tab_off[t + 1] <= tab_off[t]) return fail(c, "calibrate_class: every isotonic table needs at least one threshold");
+    const size_t tot = (size_t)tab_off[n_tables];
+    up(&d_xs, xs, tot * sizeof(double)); up(&d_ys, ys, tot * sizeof(double)); up(&d_off, tab_off, ((size_t)n_tables + 1) * sizeof(int32_t));
+  } else {
+    up(&d_t, temps, (size_t)C * sizeof(float));
+  }
+  if (e == hipSuccess) e = hipMalloc((void**)&d_p, rows * C * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_e, rows * sizeof(float));
+  if (e == hipSuccess && uncert) e = hipMalloc((void**)&d_u, rows * C * sizeof(float));
+  if (e == hipSuccess) {
+    ClsCalibArgs k{};
+    k.logits = c->d_ologits; k.classes = c->d_oclasses; k.probs = d_p; k.entropy = d_e; k.uncert = d_u;
+    k.xs = d_xs; k.ys = d_ys; k.tab_off = d_off; k.temps = d_t;
+    k.rows = (int)rows; k.C = C; k.cls_cols = cc; k.mode = mode; k.draws = draws; k.seed = seed;
+    launch_class_calib(k, c->stream);
+    e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(probs, d_p, rows * C * sizeof(float), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(entropy, d_e, rows * sizeof(float), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && uncert) {
+    if (draws > 0) e = hipMemcpy(uncert, d_u, rows * C * sizeof(float), hipMemcpyDeviceToHost);
+    else memset(uncert, 0, rows * C * sizeof(float));
+  }
+  void* fr[] = {d_xs, d_ys, d_off, d_t, d_p, d_e, d_u};
+  for (void* p : fr) if (p) hipFree(p);
+  if (e != hipSuccess) return fail(c, "calibrate_class: %s", hipGetErrorString(e));
+  return 0;
+}
+
 extern "C" int uda_serve(uda_ctx_t* c, const uint8_t* images, int32_t n, int32_t h, int32_t w,
                          float* boxes, float* scores, float* classes, int32_t* valid, float* logits) {
   int rc = uda_set_images_u8(c, images, n, h, w);

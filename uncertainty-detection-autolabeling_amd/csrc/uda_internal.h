@@ -7,6 +7,38 @@
 
 namespace uda {
 
+// ---------------------------------------------------------------- counter-based random stream (shared with oracle/philox_ref.py)
+#ifdef __HIPCC__
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// One standard-normal draw per (i0, i1, i2) of stream `tag`: words of Philox4x32-10(counter = (i0, i1, i2, tag), key = seed),
+// u1 = ((w0 >> 8) + 0.5) 2^-24 in (0, 1), u2 = (w1 >> 8) 2^-24, z = sqrt(-2 ln u1) cos(2 pi u2) in float64 (Box-Muller).
+// Used where the reference draws from TFP distributions (class-calibration logit samples, utils_class.py:121-123; the
+// `sample` decode, utils_box.py:162-184): TF's stream cannot be reproduced, so the build defines this one.
+__device__ __forceinline__ double philox_normal(uint64_t seed, uint32_t i0, uint32_t i1, uint32_t i2, uint32_t tag) {
+  uint32_t w[4];
+  philox4x32_10(i0, i1, i2, tag, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+  const double u1 = ((double)(w[0] >> 8) + 0.5) * 5.9604644775390625e-08;
+  const double u2 = (double)(w[1] >> 8) * 5.9604644775390625e-08;
+  return sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
+}
+#endif
+
 // ---------------------------------------------------------------- kernel argument blocks
 struct StemArgs {
   const float* in;    // [rows, H, W, 3]
@@ -325,5 +357,22 @@ struct CalibArgs {
 };
 void launch_calib(const CalibArgs& a, hipStream_t s);
 void launch_probs(const float* logits, float* probs, float* entropy, int rows, int C, hipStream_t s);
+
+struct ClsCalibArgs {
+  const float* logits;    // [rows, C] mean logits of the selected rows
+  const float* classes;   // [rows, cls_cols]: column 0 class id, columns 1..C the MC std of the logits (draws > 0)
+  float* probs;           // [rows, C]
+  float* entropy;         // [rows]
+  float* uncert;          // [rows, C] std of the calibrated probabilities over the draws, or null
+  const double* xs;       // isotonic tables (concatenated thresholds), 1 (all) or C (per class)
+  const double* ys;
+  const int32_t* tab_off; // [n_tables + 1]
+  const float* temps;     // [C] temperature divisors (device)
+  int rows, C, cls_cols;
+  int mode;               // uda_class_calib_mode
+  int draws;              // 0: calibrate the mean logits; > 0: that many normal draws per logit (the reference uses 10)
+  uint64_t seed;
+};
+void launch_class_calib(const ClsCalibArgs& a, hipStream_t s);
 
 }  // namespace uda
