@@ -198,7 +198,7 @@ def main():
         det = drv._collect(a.batch)
         if dist is not None:
             from uda_amd.dist import all_gather_detections
-            det = all_gather_detections(det, device=tdev)
+            det = all_gather_detections(det, device=tdev, counts=[a.batch] * world)
         return det
 
     # warm-up; the last warm-up step also ranks the kernel kinds by device time.  The very first call of a handle is

@@ -98,7 +98,8 @@ typedef struct uda_drop_site {
 } uda_drop_site_t;
 
 /* ---- model / post-processing description ---------------------------------------------------- */
-enum uda_decode { UDA_DECODE_PLAIN = 0, UDA_DECODE_LNORM = 1, UDA_DECODE_FALSEDEC = 2 };
+enum uda_decode { UDA_DECODE_PLAIN = 0, UDA_DECODE_LNORM = 1, UDA_DECODE_FALSEDEC = 2,
+                  UDA_DECODE_SAMPLE = 3 /* utils_box.py:162-184: moments of decode_nsamples decoded Normal draws (Philox stream) */ };
 enum uda_post_mode { UDA_POST_GLOBAL = 0, UDA_POST_PER_CLASS = 1 };
 
 typedef struct uda_model {
@@ -126,7 +127,7 @@ typedef struct uda_model {
   int32_t max_images;               /* capacity of one uda_run */
   int64_t arena_floats;             /* per-chunk arena size */
   int32_t n_drop_sites;
-  int32_t reserved;
+  int32_t decode_nsamples;          /* UDA_DECODE_SAMPLE: draws per (anchor, MC sample); config `decode_nsamples` (100) */
 } uda_model_t;
 
 typedef struct uda_ctx uda_ctx_t;

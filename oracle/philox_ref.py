@@ -56,3 +56,14 @@ def make_masks(sites, seed, N, T, first_image=0):
     in the global batch (image shards)."""
     return {name: site_mask(seed, s, rate, N * T, ch, first_image * T).reshape(N, T, ch)
             for s, (name, ch, rate) in enumerate(sites)}
+
+
+def normal2(seed, i0, i1, i2, tag):
+    """Both Box-Muller values of Philox4x32-10(counter = (i0, i1, i2, tag), key = seed), float64, vectorised
+    (csrc/uda_internal.h philox_normal2): u1 = ((w0 >> 8) + 0.5) 2^-24, u2 = (w1 >> 8) 2^-24,
+    z0 = sqrt(-2 ln u1) cos(2 pi u2), z1 = ... sin(2 pi u2)."""
+    w = philox4x32_10(i0, i1, i2, np.uint32(tag), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    u1 = ((w[0] >> np.uint32(8)).astype(np.float64) + 0.5) * 2.0 ** -24
+    u2 = (w[1] >> np.uint32(8)).astype(np.float64) * 2.0 ** -24
+    r, th = np.sqrt(-2.0 * np.log(u1)), 2.0 * np.pi * u2
+    return r * np.cos(th), r * np.sin(th)

@@ -145,8 +145,13 @@ def decode_box_outputs(pred, anchors):
     return np.stack([yc - h / two, xc - w / two, yc + h / two, xc + w / two], axis=-1).astype(np.float32)
 
 
-def decode_uncert(pred, sigma, anchors, method="l-norm"):
-    """float64 inside, cast back to float32 (utils_box.py:122-137,268-271)."""
+DECODE_SEED_XOR = 0x5DEC0DE5A3B1E5          # csrc/uda_api.hip run_candidates: decode_seed = dropout seed ^ this
+
+
+def decode_uncert(pred, sigma, anchors, method="l-norm", sample=None):
+    """float64 inside, cast back to float32 (utils_box.py:122-137,268-271).  method "sample" (:162-184): moments over
+    `nsamples` decoded Normal draws; the draws come from the build's Philox stream instead of TFP's
+    (sample = dict(nsamples, seed, id0 [..] anchor index, id1 [..] global sample row), broadcastable to pred[..., 0])."""
     a = anchors.astype(np.float64)
     ya, xa = (a[..., 0] + a[..., 2]) / 2, (a[..., 1] + a[..., 3]) / 2
     ha, wa = a[..., 2] - a[..., 0], a[..., 3] - a[..., 1]
@@ -179,8 +184,26 @@ def decode_uncert(pred, sigma, anchors, method="l-norm"):
         dxmin = np.abs(dxc - dw / 2.0)
         dymax = dyc + dh / 2.0
         dxmax = dxc + dw / 2.0
+    elif method == "sample":
+        from . import philox_ref
+        S = int(sample["nsamples"])
+        shape = np.broadcast(ty, ya).shape
+        id0 = np.broadcast_to(np.asarray(sample["id0"], np.uint32), shape)
+        id1 = np.broadcast_to(np.asarray(sample["id1"], np.uint32), shape)
+        sc = [np.sqrt(v) for v in (dty, dtx, dth, dtw)]
+        corners = np.empty((S,) + shape + (4,), np.float64)
+        for s_ in range(S):
+            zy, zx = philox_ref.normal2(sample["seed"], id0, id1, np.uint32(2 * s_), 0xD5)
+            zh, zw = philox_ref.normal2(sample["seed"], id0, id1, np.uint32(2 * s_ + 1), 0xD5)
+            sy, sx, sh, sw = ty + sc[0] * zy, tx + sc[1] * zx, th + sc[2] * zh, tw + sc[3] * zw
+            ws, hs = np.exp(sw) * wa, np.exp(sh) * ha
+            ycs, xcs = sy * ha + ya, sx * wa + xa
+            corners[s_] = np.stack([ycs - hs / 2.0, xcs - ws / 2.0, ycs + hs / 2.0, xcs + ws / 2.0], -1)
+        mean = corners.mean(0)
+        var = ((corners - mean) ** 2).mean(0)          # tf.nn.moments: population variance
+        return mean.astype(np.float32), np.sqrt(var).astype(np.float32)
     else:
-        raise ValueError("decode method %r needs TFP sampling (not restated)" % method)
+        raise ValueError("unknown decode method %r" % method)
     coords = np.stack([yc - h / 2.0, xc - w / 2.0, yc + h / 2.0, xc + w / 2.0], -1).astype(np.float32)
     unc = np.sqrt(np.stack([dymin, dxmin, dymax, dxmax], -1)).astype(np.float32)
     return coords, unc
@@ -267,7 +290,7 @@ def nms_params(params):
 
 
 # ------------------------------------------------------------------ pre-NMS (a8-a14)
-def pre_nms(params, cls_outputs, box_outputs):
+def pre_nms(params, cls_outputs, box_outputs, decode_seed=0, first_image=0):
     """-> dict(boxes [N,K,4], scores [N,K], classes [N,K] int32, logits [N,K,C],
                u_cls [N,K,C]|None, u_al [N,K,4]|None, u_ep [N,K,4]|None, indices [N,K])"""
     C = params["num_classes"]
@@ -320,17 +343,23 @@ def pre_nms(params, cls_outputs, box_outputs):
     scores = sigmoid32(top_logit)
     method = params["uncert_adjust_method"]
     u_al = u_ep = None
+
+    def samp(t, T):      # ids of the Philox normal stream of the "sample" decode: (anchor, global sample row)
+        if method != "sample":
+            return None
+        rows = ((np.arange(N, dtype=np.int64) + first_image) * T + t).astype(np.uint32)[:, None]
+        return dict(nsamples=params.get("decode_nsamples", 100), seed=int(decode_seed) ^ DECODE_SEED_XOR, id0=indices.astype(np.uint32), id1=rows)
     if stacked_b:
         T = box_all.shape[0]
         if loss_att:
-            dec = [decode_uncert(box_all[t], sig_all[t], anc, method) for t in range(T)]
+            dec = [decode_uncert(box_all[t], sig_all[t], anc, method, samp(t, T)) for t in range(T)]
             boxes_t = np.stack([d[0] for d in dec])
             u_al = seq_mean(np.stack([d[1] for d in dec]))
         else:
             boxes_t = np.stack([decode_box_outputs(box_all[t], anc) for t in range(T)])
         boxes, u_ep = seq_mean_std(boxes_t)
     elif loss_att:
-        boxes, u_al = decode_uncert(box_all, sig_all, anc, method)
+        boxes, u_al = decode_uncert(box_all, sig_all, anc, method, samp(0, 1))
     else:
         boxes = decode_box_outputs(box_all, anc)
     return dict(boxes=boxes, scores=scores, classes=classes, logits=logits.astype(np.float32),
@@ -338,11 +367,11 @@ def pre_nms(params, cls_outputs, box_outputs):
 
 
 # ------------------------------------------------------------------ global mode (a16)
-def postprocess_global(params, cls_outputs, box_outputs, image_scales=None):
+def postprocess_global(params, cls_outputs, box_outputs, image_scales=None, decode_seed=0, first_image=0):
     """Returns the reference's output tuple:
     (boxes [N,M,4(+4 al)(+4 ep)], scores [N,M], classes [N,M] or [N,M,1+C], valid_len [N]
      [, logits [N,M,C] if enable_softmax])"""
-    p = pre_nms(params, cls_outputs, box_outputs)
+    p = pre_nms(params, cls_outputs, box_outputs, decode_seed, first_image)
     sigma2, iou_thr, score_thr = nms_params(params)
     M = params["nms_configs"]["max_output_size"]
     has_unc = bool(params["loss_attenuation"] or params["mc_dropout"])

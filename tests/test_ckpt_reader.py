@@ -1,0 +1,123 @@
+"""TensorFlow-checkpoint plumbing of `utils_keras.restore_ckpt` on the HIP path (src/utils_keras.py:125-235), CPU only.
+No TensorFlow and no checkpoint file exist here: the bundle format is restated from its published layout and checked
+against this package's own writer (format parity unpinned, see ckpt_reader.py); what IS checked independently are the
+CRC-32C known answer, the LevelDB masking rule, the footer magic, and the restore rules (names, EMA shadows,
+mismatch / missing handling) the reference applies."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from common import make_params
+from uda_amd import ckpt_reader as CR, utils_keras, weights as W
+
+
+def test_crc32c_known_answers():
+    assert CR._crc32c(b"123456789") == 0xE3069283                    # the standard CRC-32C check value
+    assert CR._crc32c(b"") == 0 and CR._crc32c(bytes(32)) == 0x8A9136AA
+    assert CR._masked(0) == 0xA282EAD8                               # LevelDB: rotate right by 15, add the constant
+
+
+def test_name_based_checkpoint_round_trip(tmp_path):
+    p = make_params(loss_attenuation=True)
+    w = W.init_weights(p, seed=3)
+    prefix = CR.save_checkpoint(str(tmp_path / "model"), w, checksum=False)
+    raw = open(prefix + ".index", "rb").read()
+    assert struct.unpack("<Q", raw[-8:])[0] == 0xDB4775248B80FB57 and os.path.getsize(prefix + ".data-00000-of-00001") == sum(v.nbytes for v in w.values())
+    r = CR.BundleReader(prefix)
+    assert set(r.entries) == set(w) and r.variable_to_shape_map()["efficientnet-b0/stem/conv2d/kernel"] == (3, 3, 3, 32)
+    got = CR.load_checkpoint(prefix, p, use_ema=True, skip_mismatch=False)
+    assert set(got) == set(w)
+    for k in w:
+        np.testing.assert_array_equal(got[k], w[k], err_msg=k)
+    # the directory form goes through the `checkpoint` state file (tf.train.latest_checkpoint)
+    assert CR.latest_checkpoint(str(tmp_path)) == prefix
+    got2 = W.resolve_weights(str(tmp_path), p)
+    np.testing.assert_array_equal(got2["class_net/class-predict/bias"], w["class_net/class-predict/bias"])
+
+    class Model:
+        config = type("C", (), {"as_dict": staticmethod(lambda: p)})()
+
+        def load_weights(self, ws):
+            self.ws = ws
+    m = Model()
+    utils_keras.restore_ckpt(m, str(tmp_path), 0.9998, skip_mismatch=False)
+    np.testing.assert_array_equal(m.ws["box_net/box-0/pointwise_kernel"], w["box_net/box-0/pointwise_kernel"])
+    utils_keras.restore_ckpt(m, "_")                                 # "running test: do not load any ckpt"
+
+
+def test_restore_rules_ema_missing_and_mismatch(tmp_path):
+    p = make_params()
+    w = W.init_weights(p, seed=4)
+    k = "efficientnet-b0/blocks_1/conv2d/kernel"
+    bundle = dict(w)
+    bundle[k + "/ExponentialMovingAverage"] = w[k] * 2                 # an EMA shadow: preferred when ema_decay > 0
+    del bundle["class_net/class-predict/bias"]                          # a missing variable
+    bundle["box_net/box-predict/bias"] = np.zeros(7, np.float32)        # a shape mismatch
+    prefix = CR.save_checkpoint(str(tmp_path / "ckpt-3"), bundle, checksum=False)
+    got = CR.load_checkpoint(prefix, p, use_ema=True, skip_mismatch=True)
+    np.testing.assert_array_equal(got[k], w[k] * 2)
+    np.testing.assert_array_equal(CR.load_checkpoint(prefix, p, use_ema=False)[k], w[k])
+    ref = W.init_weights(p, seed=0)                                     # skipped variables keep their initial value
+    np.testing.assert_array_equal(got["class_net/class-predict/bias"], ref["class_net/class-predict/bias"])
+    np.testing.assert_array_equal(got["box_net/box-predict/bias"], ref["box_net/box-predict/bias"])
+    with pytest.raises((KeyError, ValueError)):
+        CR.load_checkpoint(prefix, p, use_ema=True, skip_mismatch=False)
+
+
+def test_tf2_object_graph_checkpoint_names(tmp_path):
+    """A TF2 checkpoint stores variables under object-path keys and the variable names in the serialized
+    TrackableObjectGraph (`full_name`): build such a bundle with the wire-format primitives and resolve it."""
+    arrays = {"a/b/kernel": np.arange(6, dtype=np.float32).reshape(2, 3), "a/bn/gamma": np.ones(4, np.float32)}
+    keys = {"a/b/kernel": "model/layer-0/kernel/.ATTRIBUTES/VARIABLE_VALUE", "a/bn/gamma": "model/layer-1/gamma/.ATTRIBUTES/VARIABLE_VALUE"}
+    node = lambda full, key: CR._field(1, 2, CR._field(2, 2, CR._field(1, 2, b"VARIABLE_VALUE") + CR._field(2, 2, (full + ":0").encode())
+                                                      + CR._field(3, 2, key.encode())))
+    graph = b"".join(node(f, k) for f, k in keys.items())
+    prefix = CR.save_checkpoint(str(tmp_path / "ckpt-1"), {keys[n]: a for n, a in arrays.items()}, checksum=True)
+    # append the string tensor by hand: rewrite the bundle with the graph entry (dtype 7, scalar: varint length, 4-byte crc, bytes)
+    r = CR.BundleReader(prefix)
+    data = open(prefix + ".data-00000-of-00001", "rb").read()
+    payload = CR._enc_varint(len(graph)) + b"\0\0\0\0" + graph
+    open(prefix + ".data-00000-of-00001", "wb").write(data + payload)
+    entry = CR._field(1, 0, 7) + CR._field(2, 2, b"") + CR._field(4, 0, len(data)) + CR._field(5, 0, len(payload))
+    pairs = [(b"", CR._field(1, 0, 1))] + sorted([(k.encode(), v) for k, v in
+                                                  [("_CHECKPOINTABLE_OBJECT_GRAPH", entry)] + [(kk, _entry_bytes(r, kk)) for kk in r.entries]])
+    _write_index(prefix, pairs)
+    r2 = CR.BundleReader(prefix)
+    names = r2.name_map()
+    assert names == keys
+    for n, a in arrays.items():
+        np.testing.assert_array_equal(r2.get_tensor(names[n]), a)
+
+
+def _entry_bytes(reader, key):
+    e = reader.entries[key]
+    shape = b"".join(CR._field(2, 2, CR._field(1, 0, int(d))) for d in e["shape"])
+    out = CR._field(1, 0, e["dtype"]) + CR._field(2, 2, shape)
+    if e["offset"]:
+        out += CR._field(4, 0, e["offset"])
+    return out + CR._field(5, 0, e["size"])
+
+
+def _write_index(prefix, pairs):
+    out = bytearray()
+
+    def emit(block):
+        h = CR._enc_varint(len(out)) + CR._enc_varint(len(block))
+        out.extend(block + b"\x00" + struct.pack("<I", CR._masked(CR._crc32c(block + b"\x00"))))
+        return h
+    d = emit(CR._block(pairs))
+    meta = emit(CR._block([]))
+    index = emit(CR._block([(pairs[-1][0], d)]))
+    footer = meta + index
+    out.extend(footer + b"\x00" * (40 - len(footer)) + struct.pack("<Q", 0xDB4775248B80FB57))
+    open(prefix + ".index", "wb").write(bytes(out))
+
+
+def test_prefix_compressed_blocks_are_read():
+    """LevelDB blocks share key prefixes between restart points; the writer here never does, so decode one by hand."""
+    ent = lambda shared, suffix, val: CR._enc_varint(shared) + CR._enc_varint(len(suffix)) + CR._enc_varint(len(val)) + suffix + val
+    body = ent(0, b"conv/kernel", b"A") + ent(5, b"bias", b"B") + ent(0, b"dense", b"C")
+    block = body + struct.pack("<III", 0, len(body) - len(ent(0, b"dense", b"C")), 2)
+    assert CR._block_entries(block) == [(b"conv/kernel", b"A"), (b"conv/bias", b"B"), (b"dense", b"C")]

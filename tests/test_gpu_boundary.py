@@ -215,3 +215,69 @@ def test_single_launch_nms_time_out_path_is_observable(spin, expect):
     r = subprocess.run([sys.executable, "-c", COOP_WORKER % {"root": ROOT, "expect": expect}], cwd=ROOT, env=e,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "coop ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+NCCL_WORKER = r'''
+import os, sys
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch                     # torch first: the HIP library then binds to the same runtime
+import torch.distributed as dist
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+from common import LOSS_ATT, make_images, make_params, make_weights
+from uda_amd import dist as udist
+from uda_amd.infer_lib import EnsembleDriver, ServingDriver
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+local = int(os.environ.get("LOCAL_RANK", rank))
+torch.cuda.set_device(local)
+tdev = torch.device("cuda", local)
+dist.init_process_group("nccl", rank=rank, world_size=world, device_id=tdev)
+p = make_params(**LOSS_ATT)
+M = 3
+imgs = make_images(3, 100, 180, seed=44)
+ws = [make_weights(p, seed=40 + m, cls_spread=20.0) for m in range(M)]
+mine = {m: ServingDriver(p["name"], 3, False, p, weights=ws[m], device=local) for m in range(M) if udist.member_owner(m, world) == rank}
+pm = dict(p, mc_dropout=True, mc_dropoutrate=1e-9, mc_dropoutsamp=M)
+post = ServingDriver(p["name"], 3, False, pm, post_only=True, device=local, chunk_images=1)
+got = udist.serve_ensemble_striped(mine, post, imgs, M, rank, world, device=tdev)
+got2 = udist.serve_sharded(next(iter(mine.values())) if mine else ServingDriver(p["name"], 3, False, p, weights=ws[0], device=local), imgs, rank, world, device=tdev)
+for d in list(mine.values()) + [post]:
+    d.close()
+if rank == 0:
+    ens = EnsembleDriver(ws, p["name"], batch_size=3, model_params=p, device=local)
+    want = ens.serve(imgs)
+    ens.close()
+    assert len(got) == len(want)
+    for g, r in zip(got, want):
+        assert np.array_equal(g, r), "device-resident ensemble exchange differs from the single-process ensemble"
+    assert got2[0].shape[0] == 3
+    print("nccl ensemble ok", world)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def _run_nccl(world, tmp_path):
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "nccl_worker.py"
+    script.write_text(NCCL_WORKER % {"root": ROOT})
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "nccl ensemble ok %d" % world in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_ensemble_exchange_stays_on_the_device_under_rccl_world1(tmp_path):
+    """e / x1: with an RCCL (backend "nccl") process group the member heads go from the members' device buffers into the
+    aggregating handle's sample slots through torch views of the handles' own memory (no numpy hop); world size 1
+    exercises the zero-copy plumbing and the device-to-device path on the one GPU of this box."""
+    _run_nccl(1, tmp_path)
+
+
+def test_ensemble_exchange_over_rccl_two_gpus(tmp_path):
+    """The same with two ranks on two GPUs: batched point-to-point transfers over xGMI.  Skipped on a one-GPU box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _run_nccl(2, tmp_path)

@@ -176,8 +176,10 @@ def test_to_c_structures_roundtrip():
     assert anchors.shape == (sum(h * w for h, w in pl.level_hw) * 9, 4)
     for o, c in zip(pl.ops, ops):
         assert c.kind == o["kind"] and c.out == o["out"] and c.n_in == len(o["ins"]) and c.w_off == o["w_off"]
+    ms = plan_mod.Plan(dict(p, uncert_adjust_method="sample", decode_nsamples=30), pl.w).to_c()[0]
+    assert ms.decode_method == capi.DECODE_SAMPLE and ms.decode_nsamples == 30
     with pytest.raises(ValueError):
-        plan_mod.Plan(dict(p, uncert_adjust_method="sample"), pl.w).to_c()
+        plan_mod.Plan(dict(p, uncert_adjust_method="bootstrap"), pl.w).to_c()
     hard = dict(p, nms_configs=dict(p["nms_configs"], method="hard"))
     assert plan_mod.nms_params(hard) == (0.0, 0.5, float("-inf"))
     with pytest.raises(ValueError):
@@ -240,3 +242,36 @@ def test_prediction_data_records_round_trip(tmp_path):
     assert r0["image_name"] == "000001.jpg" and r0["uncalib_albox"][1] == 0.0 and "uncalib_mcbox" not in r0
     assert r0["logits"] == [float(str(v)) for v in np.around(un["logits"][0, 0], 4)] and len(r0["iso_all_albox"]) == 4
     assert isinstance(r0["entropy"], float) and len(r0["probab"]) == C and len(r0["uncalib_mcclass"]) == C
+
+
+def test_reference_block_kats_structure():
+    """The reference's own block-level known answers (src/backbone/efficientnet_model_test.py:25-248) on the host side of the
+    plan: its BlockArgs (kernel 3, 3 -> 6 filters, expand 6, stride 2, optional SE 0.8, 1 or 3 repeats) expand into the
+    table the builder uses, a single block has exactly ONE reduction endpoint (:188-248), and the first conv of an expanding
+    block is `blocks_0/conv2d/kernel` (:160-188).  (The (10, 10) logits shapes of :25-158 belong to the classifier head,
+    which `features_only` backbones do not build.)"""
+    from uda_amd import arch, weights as W
+    ref_args = dict(kernel_size=3, num_repeat=3, input_filters=3, output_filters=6, expand_ratio=6, id_skip=True, strides=[2, 2],
+                    conv_type=0, fused_conv=0, super_pixel=0)
+    blocks = arch.backbone_blocks("efficientnet-b0", {"blocks": [ref_args]})
+    assert [(b["cin"], b["cout"], b["stride"], b["expand"], b["kernel"]) for b in blocks] == [(8, 8, 2, 6, 3), (8, 8, 1, 6, 3), (8, 8, 1, 6, 3)]
+    assert [b["skip"] for b in blocks] == [False, True, True] and all(b["se"] == 0 for b in blocks)
+    assert arch.reduction_block_ids(blocks) == [2]
+    se_args = dict(ref_args, id_skip=False, se_ratio=0.8)
+    blocks = arch.backbone_blocks("efficientnet-b0", {"blocks": [se_args]})
+    assert [b["se"] for b in blocks] == [6, 6, 6] and not any(b["skip"] for b in blocks)       # max(1, int(8 * 0.8))
+    single = arch.backbone_blocks("efficientnet-b0", {"blocks": [dict(se_args, num_repeat=1)]})
+    assert len(single) == 1 and arch.reduction_block_ids(single) == [0]     # 'reduction_1' and no 'reduction_2'
+    # the same table as a block string, and the variable the reference's test looks up
+    assert (arch.backbone_blocks("efficientnet-b0", {"blocks": ["r3_k3_s22_e6_i3_o6_se0.8"]})
+            == arch.backbone_blocks("efficientnet-b0", {"blocks": [dict(se_args, id_skip=True)]}))
+    cfg = make_params(image_size="128x128")
+    cfg["backbone_config"] = {"blocks": ["r1_k3_s11_e6_i32_o16_se0.25", "r1_k3_s22_e6_i16_o24_se0.25", "r1_k5_s22_e6_i24_o40_se0.25",
+                                         "r1_k3_s22_e6_i40_o80_se0.25", "r1_k5_s22_e6_i80_o112_se0.25"]}
+    names = {n: s for n, s, _ in W.variable_specs(cfg)}
+    assert names["efficientnet-b0/blocks_0/conv2d/kernel"] == (1, 1, 32, 192) and "efficientnet-b0/blocks_5/conv2d/kernel" not in names
+    with pytest.raises(ValueError):
+        arch.backbone_blocks("efficientnet-b0", {"blocks": [dict(ref_args, fused_conv=1)]})
+    # a plan over a custom table lowers (a stride-1 stage and four stride-2 stages: the three FPN inputs are blocks 2..4)
+    pl = plan_mod.Plan(cfg, W.init_weights(cfg, 0))
+    assert pl.level_hw[0] == (16, 16) and len(pl.level_hw) == 5

@@ -59,17 +59,38 @@ def _decode(block_string):
                 se_ratio=float(opts["se"]) if "se" in opts else None)
 
 
-def backbone_blocks(backbone_name):
+def _stage_args(entry):
+    """One stage of a custom block table (`config.backbone_config.blocks`, efficientdet_keras.py:873-878): a block string
+    ("r1_k3_s11_e1_i32_o16_se0.25") or the fields of the reference's `BlockArgs` (efficientnet_model.py:56-70)."""
+    if isinstance(entry, str):
+        return _decode(entry)
+    e = entry if isinstance(entry, dict) else entry._asdict()
+    for key in ("conv_type", "fused_conv", "super_pixel"):
+        if e.get(key):
+            raise ValueError("block option %s=%r is not on the hot path (EfficientDet backbones use plain MBConv)" % (key, e[key]))
+    strides = e.get("strides", [1, 1])
+    return dict(kernel=int(e["kernel_size"]), repeat=int(e["num_repeat"]), cin=int(e["input_filters"]),
+                cout=int(e["output_filters"]), expand=int(e["expand_ratio"]),
+                stride=int(strides[0] if isinstance(strides, (list, tuple)) else strides),
+                se_ratio=float(e["se_ratio"]) if e.get("se_ratio") else None, id_skip=e.get("id_skip", True))
+
+
+def backbone_blocks(backbone_name, backbone_config=None):
     """Expanded list of MBConv blocks: dicts with kernel, stride, expand, cin, cout, se.
 
     `se` is the squeeze width max(1, int(block input filters * ratio)); the
     first block of a stage carries the stage stride and input width, the
     repeats have stride 1 and cin == cout (efficientnet_model.py:741-834,393-397).
+    `backbone_config` = {"blocks": [...]} replaces the default stage table (efficientdet_keras.py:873-878).
     """
     width, depth = EFFICIENTNET_PARAMS[backbone_name]
     blocks = []
-    for s in DEFAULT_BLOCKS:
-        a = _decode(s)
+    table = DEFAULT_BLOCKS
+    if backbone_config:
+        cfg = backbone_config if isinstance(backbone_config, dict) else backbone_config.as_dict()
+        table = cfg.get("blocks") or DEFAULT_BLOCKS
+    for s in table:
+        a = _stage_args(s)
         cin, cout = round_filters(a["cin"], width), round_filters(a["cout"], width)
         for r in range(round_repeats(a["repeat"], depth)):
             b_in = cin if r == 0 else cout
@@ -77,7 +98,7 @@ def backbone_blocks(backbone_name):
             se = max(1, int(b_in * a["se_ratio"])) if a["se_ratio"] else 0
             blocks.append(dict(kernel=a["kernel"], stride=stride, expand=a["expand"],
                                cin=b_in, cout=cout, se=se,
-                               skip=(stride == 1 and b_in == cout)))
+                               skip=(a.get("id_skip", True) and stride == 1 and b_in == cout)))
     return blocks
 
 

@@ -21,7 +21,7 @@ MAX_FUSE = 3
 OP_STEM, OP_PW, OP_DW, OP_SE, OP_FUSE, OP_POOL, OP_MBX, OP_SEP = 1, 2, 3, 4, 5, 6, 7, 8
 ACT_NONE, ACT_SWISH = 0, 1
 RS_NONE, RS_NEAREST_UP, RS_MAXPOOL = 0, 1, 2
-DECODE_PLAIN, DECODE_LNORM, DECODE_FALSEDEC = 0, 1, 2
+DECODE_PLAIN, DECODE_LNORM, DECODE_FALSEDEC, DECODE_SAMPLE = 0, 1, 2, 3
 POST_GLOBAL, POST_PER_CLASS = 0, 1
 CALIB_TS_ALL, CALIB_TS_PERCOO, CALIB_ISO_ALL, CALIB_ISO_PERCOO, CALIB_ISO_PERCLSCOO = 0, 1, 2, 3, 4
 CLS_TS, CLS_ISO_ALL, CLS_ISO_PERCLS = 0, 1, 2
@@ -61,7 +61,7 @@ class Model(C.Structure):
                 ("nms_iou_thresh", C.c_float), ("nms_score_thresh", C.c_float),
                 ("max_output_size", C.c_int32), ("max_nms_inputs", C.c_int32),
                 ("post_mode", C.c_int32), ("chunk_images", C.c_int32), ("max_images", C.c_int32),
-                ("arena_floats", C.c_int64), ("n_drop_sites", C.c_int32), ("reserved", C.c_int32)]
+                ("arena_floats", C.c_int64), ("n_drop_sites", C.c_int32), ("decode_nsamples", C.c_int32)]
 
 
 _P = C.c_void_p

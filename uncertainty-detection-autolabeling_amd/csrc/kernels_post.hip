@@ -91,6 +91,41 @@ __device__ __forceinline__ void decode_plain(const float* t, const float* an, De
   d.box[3] = xc + w / 2.0f;
 }
 
+// method "sample" (utils_box.py:162-184): S draws from Normal(loc = (ty, tx, th, tw), scale = sqrt(sigma^2)), each decoded like
+// a plain box, mean and population variance (tf.nn.moments) of the four corners over the draws, all in float64.  TFP's
+// stream cannot be reproduced: the draws come from the build's Philox normal stream (counter (anchor, sample row, 2 s + {0, 1}),
+// tag 0xD5: (y, x) from the first call, (h, w) from the second), shared with the oracle.  Welford's update keeps the variance
+// accurate at box coordinates ~1e3 with sigma ~1e-1.
+__device__ __forceinline__ void decode_sample(const float* t, const float* sg, const float* an, int S, uint64_t seed,
+                                              uint32_t id0, uint32_t id1, Dec& d) {
+  const double a0 = an[0], a1 = an[1], a2 = an[2], a3 = an[3];
+  const double ya = (a0 + a2) / 2, xa = (a1 + a3) / 2;
+  const double ha = a2 - a0, wa = a3 - a1;
+  const double ty = t[0], tx = t[1], th = t[2], tw = t[3];
+  double sc[4];
+  for (int k = 0; k < 4; ++k) { const double s = sg[k]; sc[k] = sqrt(s * s); }
+  double mean[4] = {0, 0, 0, 0}, m2[4] = {0, 0, 0, 0};
+  for (int s = 0; s < S; ++s) {
+    double zy, zx, zh, zw;
+    philox_normal2(seed, id0, id1, (uint32_t)(2 * s), 0xD5u, zy, zx);
+    philox_normal2(seed, id0, id1, (uint32_t)(2 * s + 1), 0xD5u, zh, zw);
+    const double sy = ty + sc[0] * zy, sx = tx + sc[1] * zx, sh = th + sc[2] * zh, sw = tw + sc[3] * zw;
+    const double w = exp(sw) * wa, h = exp(sh) * ha;
+    const double yc = sy * ha + ya, xc = sx * wa + xa;
+    const double v[4] = {yc - h / 2.0, xc - w / 2.0, yc + h / 2.0, xc + w / 2.0};
+    const double n = (double)(s + 1);
+    for (int k = 0; k < 4; ++k) {
+      const double dl = v[k] - mean[k];
+      mean[k] += dl / n;
+      m2[k] += dl * (v[k] - mean[k]);
+    }
+  }
+  for (int k = 0; k < 4; ++k) {
+    d.box[k] = (float)mean[k];
+    d.sig[k] = (float)sqrt(m2[k] / (double)S);
+  }
+}
+
 __device__ __forceinline__ void decode_uncert(const float* t, const float* sg, const float* an,
                                               int method, Dec& d) {
   const double a0 = an[0], a1 = an[1], a2 = an[2], a3 = an[3];
@@ -138,12 +173,13 @@ __device__ __forceinline__ void decode_uncert(const float* t, const float* sg, c
 }
 
 __device__ __forceinline__ void decode_one(const AggArgs& a, const float* bp, int A, const float* an,
-                                           Dec& d) {
+                                           Dec& d, uint32_t id0 = 0, uint32_t id1 = 0) {
   float t[4] = {bp[0], bp[1], bp[2], bp[3]};
   if (a.loss_att) {
     const float* sp = bp + 4 * A;
     float sg[4] = {sp[0], sp[1], sp[2], sp[3]};
-    decode_uncert(t, sg, an, a.decode, d);
+    if (a.decode == UDA_DECODE_SAMPLE) decode_sample(t, sg, an, a.decode_nsamples, a.decode_seed, id0, id1, d);
+    else decode_uncert(t, sg, an, a.decode, d);
   } else {
     decode_plain(t, an, d);
     d.sig[0] = d.sig[1] = d.sig[2] = d.sig[3] = 0.f;
@@ -232,7 +268,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void aggregate_kernel(AggArgs a) {
   const float an[4] = {a.anchors[ai * 4 + 0], a.anchors[ai * 4 + 1], a.anchors[ai * 4 + 2],
                        a.anchors[ai * 4 + 3]};
   Dec d;
-  decode_one(a, bbase, a.A, an, d);
+  decode_one(a, bbase, a.A, an, d, (uint32_t)ai, a.row_base + (uint32_t)n * (uint32_t)a.Tb);
   if (a.Tb == 1) {
     for (int k = 0; k < 4; ++k) a.boxes[(size_t)gid * 4 + k] = d.box[k];
     if (a.u_al) for (int k = 0; k < 4; ++k) a.u_al[(size_t)gid * 4 + k] = d.sig[k];
@@ -245,7 +281,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void aggregate_kernel(AggArgs a) {
   float ss[4] = {d.sig[0], d.sig[1], d.sig[2], d.sig[3]};
   for (int k = 0; k < 4; ++k) pb[k * AGG_BLOCK] = d.box[k];
   for (int t = 1; t < a.Tb; ++t) {
-    decode_one(a, bbase + t * bstride, a.A, an, d);
+    decode_one(a, bbase + t * bstride, a.A, an, d, (uint32_t)ai, a.row_base + (uint32_t)n * (uint32_t)a.Tb + (uint32_t)t);
     for (int k = 0; k < 4; ++k) {
       sb[k] = sb[k] + d.box[k];
       ss[k] = ss[k] + d.sig[k];
@@ -357,7 +393,7 @@ __global__ __launch_bounds__(128) void aggregate_reg_kernel(AggArgs a) {
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     Dec d;
-    decode_one(a, bbase + t * bstride, a.A, an, d);
+    decode_one(a, bbase + t * bstride, a.A, an, d, (uint32_t)ai, a.row_base + (uint32_t)n * (uint32_t)T + (uint32_t)t);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       sb[k] = t ? sb[k] + d.box[k] : d.box[k];

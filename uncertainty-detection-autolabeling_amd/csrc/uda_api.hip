@@ -331,6 +331,8 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
     return fail(nullptr, "uda_create: max_output_size %d outside [1, 128]", model->max_output_size);
   if (model->chunk_images < 1 || model->max_images < 1 || model->mc_samples < 1)
     return fail(nullptr, "uda_create: chunk_images/max_images/mc_samples must be >= 1");
+  if (model->decode_method == UDA_DECODE_SAMPLE && (model->decode_nsamples < 1 || model->decode_nsamples > 4096))
+    return fail(nullptr, "uda_create: decode_nsamples %d outside [1, 4096]", model->decode_nsamples);
   if (model->mc_samples > 96)      // the aggregate kernel parks T logits + 4 T box corners per candidate in LDS
     return fail(nullptr, "uda_create: mc_samples %d > 96 unsupported", model->mc_samples);
   int ndev = 0;
@@ -1073,6 +1075,9 @@ static int run_candidates(uda_ctx* c, int i0, int n, hipStream_t st) {
   a.Tb = Tb;
   a.loss_att = m.loss_attenuation;
   a.decode = m.decode_method;
+  a.decode_nsamples = m.decode_nsamples;
+  a.decode_seed = c->seed ^ 0x5DEC0DE5A3B1E5ull;
+  a.row_base = (uint32_t)((c->image_offset + i0) * Tb);
   a.boxes = c->d_cboxes + (size_t)i0 * K * 4; a.scores = c->d_cscores + (size_t)i0 * K;
   a.classes = c->d_cclasses + (size_t)i0 * K; a.logits = c->d_clogits + (size_t)i0 * K * C;
   a.u_cls = c->d_ucls ? c->d_ucls + (size_t)i0 * K * uc : nullptr;

@@ -37,6 +37,16 @@ __device__ __forceinline__ double philox_normal(uint64_t seed, uint32_t i0, uint
   const double u2 = (double)(w[1] >> 8) * 5.9604644775390625e-08;
   return sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
 }
+// both Box-Muller values of one Philox call: z0 = r cos(2 pi u2), z1 = r sin(2 pi u2)
+__device__ __forceinline__ void philox_normal2(uint64_t seed, uint32_t i0, uint32_t i1, uint32_t i2, uint32_t tag, double& z0, double& z1) {
+  uint32_t w[4];
+  philox4x32_10(i0, i1, i2, tag, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+  const double u1 = ((double)(w[0] >> 8) + 0.5) * 5.9604644775390625e-08;
+  const double u2 = (double)(w[1] >> 8) * 5.9604644775390625e-08;
+  const double r = sqrt(-2.0 * log(u1)), th = 6.283185307179586476925286766559 * u2;
+  z0 = r * cos(th);
+  z1 = r * sin(th);
+}
 #endif
 
 // ---------------------------------------------------------------- kernel argument blocks
@@ -215,6 +225,9 @@ struct AggArgs {
   float* u_al;           // [n, A_tot, 4] or null
   float* u_ep;           // [n, A_tot, 4] or null
   int park_all, cls_slots;   // set by launch_aggregate: LDS parking layout of the class logits
+  int decode_nsamples;       // UDA_DECODE_SAMPLE: draws per (candidate, MC sample)
+  uint64_t decode_seed;      //   seed of the Philox normal stream
+  uint32_t row_base;         //   global sample-row index of image 0 of this range: (image offset + i0) * Tb
 };
 void launch_aggregate(const AggArgs& a, hipStream_t s);
 // mean logits of every (anchor, class): out [n, A_tot*C]   (input of the top-k pre-selection)

@@ -46,19 +46,26 @@ def unpack_detections(packed, layout):
     return tuple(out)
 
 
-def all_gather_detections(det, device=None, group=None):
+def all_gather_detections(det, device=None, group=None, counts=None):
     """Every rank gets the detections of all images, in global image order.  Ranks may own
     different numbers of images (ragged shards are padded to the largest shard for the
-    collective and trimmed afterwards)."""
+    collective and trimmed afterwards).  `counts` = images per rank when the caller knows them
+    (contiguous shards of a known batch: `shard_range`), which saves the size exchange - one
+    collective and one host synchronisation per step; otherwise the sizes are gathered first."""
     import torch
     import torch.distributed as dist
     packed, layout = pack_detections(det)
     world = dist.get_world_size(group)
     dev = torch.device(device) if device is not None else torch.device("cpu")
-    n_local = torch.tensor([packed.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local, group=group)
-    counts = [int(c.item()) for c in counts]
+    if counts is None:
+        n_local = torch.tensor([packed.shape[0]], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros_like(n_local) for _ in range(world)]
+        dist.all_gather(sizes, n_local, group=group)
+        counts = [int(c.item()) for c in sizes]
+    else:
+        counts = [int(c) for c in counts]
+        if len(counts) != world or counts[dist.get_rank(group)] != packed.shape[0]:
+            raise ValueError("counts %s do not describe this rank's %d images" % (counts, packed.shape[0]))
     n_max = max(counts)
     buf = np.zeros((n_max,) + packed.shape[1:], np.float32)
     buf[:packed.shape[0]] = packed
@@ -78,7 +85,8 @@ def serve_sharded(driver, images, rank, world, device=None, group=None):
         det = driver.serve(images[start:stop])
     else:  # more ranks than images: this rank contributes an empty shard
         det = driver.empty_detections()
-    return all_gather_detections(det, device=device, group=group)
+    counts = [shard_range(len(images), r, world)[1] - shard_range(len(images), r, world)[0] for r in range(world)]
+    return all_gather_detections(det, device=device, group=group, counts=counts)
 
 
 # ---------------------------------------------------------------------------------------------- ensemble striping
@@ -151,6 +159,73 @@ def reshard_member_heads(owned, n_members, n_total, rank, world, device=None, gr
     return outs[:n_cls], outs[n_cls:]
 
 
+class DevArray:
+    """Zero-copy view of a device buffer owned by a HIP handle for torch (`torch.as_tensor(DevArray(...), device=...)`):
+    float32, C-contiguous, exposed through `__cuda_array_interface__` (version 2)."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = dict(shape=tuple(int(v) for v in shape), typestr="<f4", data=(int(ptr), False),
+                                             version=2, strides=None)
+
+
+def _head_tensor(torch, drv, level, which, dev):
+    """The handle's head-output buffer of (level, which) as a torch tensor [capacity, rows_per_image, floats_per_row]."""
+    ptr, per, rows = drv.head_outputs_device(level, which)
+    return torch.as_tensor(DevArray(ptr, (drv._cap, rows, per)), device=dev)
+
+
+def reshard_member_heads_device(member_drivers, post_driver, n_members, n_total, rank, world, device, group=None):
+    """The ensemble exchange of `reshard_member_heads` WITHOUT a host hop: the members' head outputs are sent
+    straight out of their handles' device buffers and land in the sample slots of the aggregating handle - batched
+    point-to-point transfers over RCCL (every GPU pair uses its own xGMI link), 707 MB per member at BASELINE configs[3]
+    that never cross PCIe.  Shards that stay on the rank are device-to-device copies."""
+    import torch
+    import torch.distributed as dist
+    dev = torch.device(device)
+    a, b = shard_range(n_total, rank, world)
+    mine = sorted(member_drivers)
+    assert mine == [m for m in range(n_members) if member_owner(m, world) == rank], "member ownership must be round-robin"
+    for drv in member_drivers.values():
+        drv.synchronize()                       # the members' heads are complete before torch's stream reads them
+    post_driver.synchronize()
+    levels = len(post_driver.plan.level_hw)
+    ops, pending, keep = [], [], []
+    for lvl in range(levels):
+        for which in (0, 1):
+            dst = _head_tensor(torch, post_driver, lvl, which, dev)           # [cap, M, per]
+            assert dst.shape[1] == n_members, "the aggregating handle must stack %d samples" % n_members
+            srcs = {m: _head_tensor(torch, member_drivers[m], lvl, which, dev)[:, 0, :] for m in mine}   # [cap, per]
+            for j in range(world):                                            # what this rank sends
+                s, e = shard_range(n_total, j, world)
+                if e == s:
+                    continue
+                for m in mine:
+                    if j == rank:
+                        dst[:e - s, m, :].copy_(srcs[m][s:e])
+                    else:
+                        ops.append(dist.P2POp(dist.isend, srcs[m][s:e], j, group=group))
+            if b > a:
+                for r in range(world):                                        # what this rank receives
+                    if r == rank:
+                        continue
+                    for m in (mm for mm in range(n_members) if member_owner(mm, world) == r):
+                        t = torch.empty((b - a, dst.shape[2]), dtype=torch.float32, device=dev)
+                        ops.append(dist.P2POp(dist.irecv, t, r, group=group))
+                        pending.append((dst, m, t))
+            keep.append((dst, srcs))
+    # every rank posts its operations in the same global order (level, head, peer, member): matching sends and receives
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    for dst, m, t in pending:
+        dst[:b - a, m, :].copy_(t)
+    torch.cuda.synchronize(dev)                 # the aggregating handle's stream may read its buffers now
+    post_driver._run_id += 1
+    if b > a:
+        post_driver._ck(post_driver._lib.uda_set_num_images(post_driver._h, b - a), "uda_set_num_images")
+    return b - a
+
+
 def serve_ensemble_striped(member_drivers, post_driver, images, n_members, rank, world, device=None, group=None,
                            post_mode=None):
     """Deep ensemble with the members striped over the ranks: member m runs on rank m % world for the whole batch,
@@ -166,9 +241,15 @@ def serve_ensemble_striped(member_drivers, post_driver, images, n_members, rank,
         a8 = drv._as_u8_batch(images)
         drv._ck(drv._lib.uda_set_images_u8(drv._h, a8.ctypes.data, n, a8.shape[1], a8.shape[2]), "uda_set_images_u8")
         drv._ck(drv._lib.uda_run(drv._h, -1, 0), "uda_run")
-        owned[m] = drv.head_outputs(n)
+        owned[m] = drv
         _, scales = drv.preprocessed_scales(n)
-    cls_lv, box_lv = reshard_member_heads(owned, n_members, n, rank, world, device=device, group=group)
+    import torch.distributed as dist
+    on_device = dist.get_backend(group) == "nccl" and device is not None
+    if on_device:
+        reshard_member_heads_device(owned, post_driver, n_members, n, rank, world, device, group=group)
+    else:       # CPU process group (gloo: tests): through host arrays
+        owned = {m: drv.head_outputs(n) for m, drv in owned.items()}
+        cls_lv, box_lv = reshard_member_heads(owned, n_members, n, rank, world, device=device, group=group)
     a, b = shard_range(n, rank, world)
     if scales is None:      # a rank without a member: the image scale depends only on the raw size (dataloader.py:123-135)
         h, w = np.asarray(images).shape[1:3]
@@ -176,7 +257,11 @@ def serve_ensemble_striped(member_drivers, post_driver, images, n_members, rank,
         s = min(np.float32(H) / np.float32(h), np.float32(W) / np.float32(w))
         scales = np.full((n,), np.float32(1.0) / np.float32(s), np.float32)
     if b > a:
-        det = post_driver.postprocess(cls_lv, box_lv, np.asarray(scales, np.float32)[a:b], post_mode=post_mode)
+        sc = np.asarray(scales, np.float32)[a:b]
+        if on_device:
+            cls_lv, box_lv = post_driver.device_heads(b - a)      # resident: post-processed where the exchange left them
+        det = post_driver.postprocess(cls_lv, box_lv, sc, post_mode=post_mode)
     else:
         det = post_driver.empty_detections()
-    return all_gather_detections(det, device=device, group=group)
+    counts = [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
+    return all_gather_detections(det, device=device, group=group, counts=counts)

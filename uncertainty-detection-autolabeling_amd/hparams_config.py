@@ -29,31 +29,69 @@ def _eval_str(val):
         return val
 
 
+def _wrap(value):
+    """Nested dicts become Config nodes; everything else is stored by value."""
+    return Config(value) if isinstance(value, dict) else copy.deepcopy(value)
+
+
+def _plain(value):
+    return value.as_dict() if isinstance(value, Config) else copy.deepcopy(value)
+
+
+def _merge(node, updates, allow_new_keys):
+    """Recursive update of a Config node from a plain mapping: existing sub-configs are merged key by key, leaves are
+    replaced, unknown keys raise unless `allow_new_keys` (the override rules of the reference's Config)."""
+    for key, value in (updates or {}).items():
+        store = node._store
+        if key not in store:
+            if not allow_new_keys:
+                raise KeyError("Key `{}` does not exist for overriding.".format(key))
+            store[key] = _wrap(value)
+            continue
+        current = store[key]
+        if isinstance(current, Config) and isinstance(value, (dict, Config)):
+            _merge(current, _plain(value), allow_new_keys)
+        else:
+            store[key] = _wrap(value)
+
+
 class Config:
-    """A dict-like config whose members are reachable as attributes and items."""
+    """A config tree whose members are reachable as attributes and items.
+
+    Values live in one ordered mapping per node (`_store`); attribute and item access are two views of it.  The public
+    behaviour - `update` (new keys allowed), `override` from a dict / another Config / a ``.yaml`` path / an
+    ``"a.b=1,c=2*3"`` string (unknown keys refused unless asked), `as_dict`, `get`, `keys` - is the reference's."""
+
+    __slots__ = ("_store",)
 
     def __init__(self, config_dict=None):
+        object.__setattr__(self, "_store", {})
         if config_dict:
             self.update(config_dict)
 
-    # attribute / item plumbing -------------------------------------------
-    def __setattr__(self, k, v):
-        self.__dict__[k] = Config(v) if isinstance(v, dict) else copy.deepcopy(v)
-
-    def __getattr__(self, k):
+    # attribute / item views ------------------------------------------------------
+    def __getattr__(self, name):
         try:
-            return self.__dict__[k]
-        except KeyError as e:
-            raise AttributeError(k) from e
+            return object.__getattribute__(self, "_store")[name]
+        except KeyError:
+            raise AttributeError(name) from None
 
-    def __getitem__(self, k):
-        return self.__dict__[k]
+    def __setattr__(self, name, value):
+        self._store[name] = _wrap(value)
 
-    def __setitem__(self, k, v):
-        self.__setattr__(k, v)
+    __setitem__ = __setattr__
 
-    def __contains__(self, k):
-        return k in self.__dict__
+    def __getitem__(self, name):
+        return self._store[name]
+
+    def __contains__(self, name):
+        return name in self._store
+
+    def __iter__(self):
+        return iter(self._store)
+
+    def __len__(self):
+        return len(self._store)
 
     def __repr__(self):
         return repr(self.as_dict())
@@ -61,52 +99,44 @@ class Config:
     def __deepcopy__(self, memo):
         return Config(self.as_dict())
 
-    def get(self, k, default=None):
-        return self.__dict__.get(k, default)
+    def __getstate__(self):
+        return self.as_dict()
+
+    def __setstate__(self, state):
+        object.__setattr__(self, "_store", {})
+        self.update(state)
+
+    def get(self, name, default=None):
+        return self._store.get(name, default)
 
     def keys(self):
-        return self.__dict__.keys()
+        return self._store.keys()
 
-    # update / override ------------------------------------------------------
-    def _update(self, config_dict, allow_new_keys):
-        if not config_dict:
-            return
-        for k, v in config_dict.items():
-            if k not in self.__dict__:
-                if not allow_new_keys:
-                    raise KeyError("Key `{}` does not exist for overriding.".format(k))
-                self.__setattr__(k, v)
-            elif isinstance(self.__dict__[k], Config) and isinstance(v, dict):
-                self.__dict__[k]._update(v, allow_new_keys)
-            elif isinstance(self.__dict__[k], Config) and isinstance(v, Config):
-                self.__dict__[k]._update(v.as_dict(), allow_new_keys)
-            else:
-                self.__setattr__(k, v)
+    def items(self):
+        return self._store.items()
 
+    # update / override ----------------------------------------------------------
     def update(self, config_dict):
-        """Update members, new keys allowed (reference `Config.update`)."""
-        self._update(config_dict, allow_new_keys=True)
+        """Merge a mapping; keys that do not exist yet are added."""
+        _merge(self, _plain(config_dict) if isinstance(config_dict, Config) else config_dict, True)
 
     def override(self, config_dict_or_str, allow_new_keys=False):
-        """Update members from a dict, a yaml path or a `k=v,...` string."""
-        if isinstance(config_dict_or_str, str):
-            if not config_dict_or_str:
+        """Merge a dict, a Config, a yaml file or a `k=v,...` string; unknown keys are an error by default."""
+        src = config_dict_or_str
+        if isinstance(src, Config):
+            src = src.as_dict()
+        elif isinstance(src, str):
+            if not src:
                 return
-            if "=" in config_dict_or_str:
-                config_dict = self.parse_from_str(config_dict_or_str)
-            elif config_dict_or_str.endswith(".yaml"):
-                config_dict = self.parse_from_yaml(config_dict_or_str)
+            if "=" in src:
+                src = self.parse_from_str(src)
+            elif src.endswith(".yaml"):
+                src = self.parse_from_yaml(src)
             else:
-                raise ValueError(
-                    'Invalid string {}, must end with .yaml or contains "=".'.format(
-                        config_dict_or_str))
-        elif isinstance(config_dict_or_str, dict):
-            config_dict = config_dict_or_str
-        elif isinstance(config_dict_or_str, Config):
-            config_dict = config_dict_or_str.as_dict()
-        else:
-            raise ValueError("Unknown value type: {}".format(config_dict_or_str))
-        self._update(config_dict, allow_new_keys)
+                raise ValueError('Invalid string {}, must end with .yaml or contains "=".'.format(src))
+        elif not isinstance(src, dict):
+            raise ValueError("Unknown value type: {}".format(src))
+        _merge(self, src, allow_new_keys)
 
     @staticmethod
     def parse_from_yaml(path):
@@ -121,34 +151,23 @@ class Config:
     def parse_from_str(config_str):
         """'x.y=1,x.z=2,a=3*4' -> {x: {y: 1, z: 2}, a: [3, 4]}."""
         out = {}
-        if not config_str:
-            return out
-        try:
-            for kv in config_str.split(","):
-                if not kv:
-                    continue
-                key, val = kv.split("=")
-                key = key.strip()
-                if "*" in val:
-                    leaf = [_eval_str(v) for v in val.split("*")]
-                else:
-                    leaf = _eval_str(val)
-                node = out
-                parts = key.split(".")
-                for p in parts[:-1]:
-                    node = node.setdefault(p, {})
-                    if not isinstance(node, dict):
-                        raise ValueError(key)
-                node[parts[-1]] = leaf
-        except ValueError:
-            raise ValueError("Invalid config_str: {}".format(config_str))
+        for assignment in filter(None, (config_str or "").split(",")):
+            try:
+                dotted, raw = assignment.split("=")
+            except ValueError:
+                raise ValueError("Invalid config_str: {}".format(config_str)) from None
+            leaf = [_eval_str(v) for v in raw.split("*")] if "*" in raw else _eval_str(raw)
+            *parents, last = dotted.strip().split(".")
+            node = out
+            for name in parents:
+                node = node.setdefault(name, {})
+                if not isinstance(node, dict):
+                    raise ValueError("Invalid config_str: {}".format(config_str))
+            node[last] = leaf
         return out
 
     def as_dict(self):
-        d = {}
-        for k, v in self.__dict__.items():
-            d[k] = v.as_dict() if isinstance(v, Config) else copy.deepcopy(v)
-        return d
+        return {k: _plain(v) for k, v in self._store.items()}
 
 
 def default_detection_configs():

@@ -322,6 +322,8 @@ class ServingDriver:
             self._run_id += 1
             for lvl, (c, b) in enumerate(zip(cs, bs)):
                 self._ck(self._lib.uda_set_head_outputs(self._h, lvl, n, _ptr(c), c.size, _ptr(b), b.size), "uda_set_head_outputs")
+        if self.params.get("uncert_adjust_method") == "sample" and self.params.get("loss_attenuation"):
+            self._next_seed()         # the "sample" decode draws from the handle's Philox stream (seed as for MC dropout)
         s = None if image_scales is None else np.ascontiguousarray(image_scales, dtype=np.float32)
         if s is not None and s.shape != (n,):
             raise ValueError("image_scales must have shape (%d,), got %s" % (n, s.shape))

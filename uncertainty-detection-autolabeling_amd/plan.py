@@ -161,7 +161,7 @@ class Plan:
         if not cfg["mc_dropout"]:
             return
         r_bb, r_cls, r_box = arch.dropout_rates(cfg)
-        for i, b in enumerate(arch.backbone_blocks(cfg["backbone_name"])):
+        for i, b in enumerate(arch.backbone_blocks(cfg["backbone_name"], cfg.get("backbone_config"))):
             mid = b["cin"] * b["expand"]
             if b["expand"] != 1:
                 self.sites.append(("blocks_%d/expand" % i, mid, r_bb))
@@ -265,7 +265,7 @@ class Plan:
         cfg, w = self.cfg, self.w
         bb = cfg["backbone_name"]
         H, W = parse_image_size(cfg["image_size"])
-        blocks = arch.backbone_blocks(bb)
+        blocks = arch.backbone_blocks(bb, cfg.get("backbone_config"))
         img = self._buf(H, W, 3, False, kind=1, name="image")
         # ---- backbone
         sc, sh = self._bn(bb + "/stem/tpu_batch_normalization")
@@ -546,6 +546,11 @@ class Plan:
             m.decode_method = capi.DECODE_LNORM
         elif method == "falsedec":
             m.decode_method = capi.DECODE_FALSEDEC
+        elif method == "sample":
+            m.decode_method = capi.DECODE_SAMPLE
+            m.decode_nsamples = int(cfg.get("decode_nsamples", 100))
+            if not 1 <= m.decode_nsamples <= 4096:
+                raise ValueError("decode_nsamples must be in [1, 4096]")
         else:
             raise ValueError("uncert_adjust_method %r is not available on the HIP path" % method)
         m.enable_softmax = int(bool(cfg["enable_softmax"]))

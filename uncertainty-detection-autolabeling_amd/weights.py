@@ -31,7 +31,7 @@ def variable_specs(config):
     kind ∈ conv, dw, se_w, bias0, vs_dw, vs_pw, glorot, cls_bias, wsm, bn
     """
     bb = config["backbone_name"]
-    blocks = arch.backbone_blocks(bb)
+    blocks = arch.backbone_blocks(bb, config.get("backbone_config"))
     specs = []
 
     def bn(prefix, c):
