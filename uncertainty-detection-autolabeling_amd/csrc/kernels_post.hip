@@ -172,13 +172,16 @@ __device__ __forceinline__ void decode_uncert(const float* t, const float* sg, c
   d.sig[3] = (float)sqrt(dxmax);
 }
 
+// SAMPLE is a compile-time flag: the Philox / Box-Muller code of the "sample" method would otherwise cost the common
+// kernels registers (measured: aggregate_reg_kernel 0.94 -> 1.25 ms with the branch inside).
+template <bool SAMPLE = false>
 __device__ __forceinline__ void decode_one(const AggArgs& a, const float* bp, int A, const float* an,
                                            Dec& d, uint32_t id0 = 0, uint32_t id1 = 0) {
   float t[4] = {bp[0], bp[1], bp[2], bp[3]};
   if (a.loss_att) {
     const float* sp = bp + 4 * A;
     float sg[4] = {sp[0], sp[1], sp[2], sp[3]};
-    if (a.decode == UDA_DECODE_SAMPLE) decode_sample(t, sg, an, a.decode_nsamples, a.decode_seed, id0, id1, d);
+    if constexpr (SAMPLE) decode_sample(t, sg, an, a.decode_nsamples, a.decode_seed, id0, id1, d);
     else decode_uncert(t, sg, an, a.decode, d);
   } else {
     decode_plain(t, an, d);
@@ -192,6 +195,7 @@ __device__ __forceinline__ void decode_one(const AggArgs& a, const float* bp, in
 // (bit-exact) without a second trip to memory and without decoding twice.
 constexpr int AGG_BLOCK = 64;
 
+template <bool SAMPLE>
 __global__ __launch_bounds__(AGG_BLOCK) void aggregate_kernel(AggArgs a) {
   extern __shared__ float park[];          // [Tc * C + Tb * 4][AGG_BLOCK]
   const int lane = threadIdx.x;
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void aggregate_kernel(AggArgs a) {
   const float an[4] = {a.anchors[ai * 4 + 0], a.anchors[ai * 4 + 1], a.anchors[ai * 4 + 2],
                        a.anchors[ai * 4 + 3]};
   Dec d;
-  decode_one(a, bbase, a.A, an, d, (uint32_t)ai, a.row_base + (uint32_t)n * (uint32_t)a.Tb);
+  decode_one<SAMPLE>(a, bbase, a.A, an, d, (uint32_t)ai, a.row_base + (uint32_t)n * (uint32_t)a.Tb);
   if (a.Tb == 1) {
     for (int k = 0; k < 4; ++k) a.boxes[(size_t)gid * 4 + k] = d.box[k];
     if (a.u_al) for (int k = 0; k < 4; ++k) a.u_al[(size_t)gid * 4 + k] = d.sig[k];
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void aggregate_kernel(AggArgs a) {
   float ss[4] = {d.sig[0], d.sig[1], d.sig[2], d.sig[3]};
   for (int k = 0; k < 4; ++k) pb[k * AGG_BLOCK] = d.box[k];
   for (int t = 1; t < a.Tb; ++t) {
-    decode_one(a, bbase + t * bstride, a.A, an, d, (uint32_t)ai, a.row_base + (uint32_t)n * (uint32_t)a.Tb + (uint32_t)t);
+    decode_one<SAMPLE>(a, bbase + t * bstride, a.A, an, d, (uint32_t)ai, a.row_base + (uint32_t)n * (uint32_t)a.Tb + (uint32_t)t);
     for (int k = 0; k < 4; ++k) {
       sb[k] = sb[k] + d.box[k];
       ss[k] = ss[k] + d.sig[k];
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(128) void aggregate_reg_kernel(AggArgs a) {
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     Dec d;
-    decode_one(a, bbase + t * bstride, a.A, an, d, (uint32_t)ai, a.row_base + (uint32_t)n * (uint32_t)T + (uint32_t)t);
+    decode_one<false>(a, bbase + t * bstride, a.A, an, d);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       sb[k] = t ? sb[k] + d.box[k] : d.box[k];
@@ -427,7 +431,8 @@ void launch_aggregate(const AggArgs& a0, hipStream_t s) {
   AggArgs a = a0;
   static int regs = -1;
   if (regs < 0) { const char* e = getenv("UDA_AGG_REG"); regs = e ? atoi(e) : 1; }
-  if (regs && a.Tc == a.Tb && (a.Tc == 10 || a.Tc == 20)) {
+  const bool sample = a.loss_att && a.decode == UDA_DECODE_SAMPLE;      // the (slow, optional) sampling decode: LDS-parking kernel only
+  if (regs && !sample && a.Tc == a.Tb && (a.Tc == 10 || a.Tc == 20)) {
     const int64_t tot = (int64_t)a.n_img * a.K;
     const dim3 grid((unsigned)((tot + 127) / 128)), block(128);
     if (a.Tc == 10 && a.C == 7) hipLaunchKernelGGL((aggregate_reg_kernel<10, 7>), grid, block, 0, s, a);
@@ -440,12 +445,15 @@ void launch_aggregate(const AggArgs& a0, hipStream_t s) {
   a.park_all = (a.Tc * a.C + box_slots) * AGG_BLOCK * (int)sizeof(float) <= 48 * 1024;   // >= 3 blocks per CU
   a.cls_slots = a.Tc > 1 ? (a.park_all ? a.Tc * a.C : a.Tc) : 0;
   const size_t lds = (size_t)(a.cls_slots + box_slots) * AGG_BLOCK * sizeof(float);
-  static size_t attr_lds = 64 * 1024;
-  if (lds > attr_lds) {
-    hipFuncSetAttribute((const void*)aggregate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_lds = lds;
+  static size_t attr_lds[2] = {64 * 1024, 64 * 1024};
+  if (lds > attr_lds[sample]) {
+    if (sample) hipFuncSetAttribute((const void*)aggregate_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    else hipFuncSetAttribute((const void*)aggregate_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_lds[sample] = lds;
   }
-  hipLaunchKernelGGL(aggregate_kernel, dim3((unsigned)((total + AGG_BLOCK - 1) / AGG_BLOCK)), dim3(AGG_BLOCK), lds, s, a);
+  const dim3 grid((unsigned)((total + AGG_BLOCK - 1) / AGG_BLOCK));
+  if (sample) hipLaunchKernelGGL(aggregate_kernel<true>, grid, dim3(AGG_BLOCK), lds, s, a);
+  else hipLaunchKernelGGL(aggregate_kernel<false>, grid, dim3(AGG_BLOCK), lds, s, a);
 }
 
 // ------------------------------------------------------------------------------------ top-k pre-selection
