@@ -29,7 +29,7 @@ rows = list(csv.DictReader(open(stats)))
 with open(os.path.join(out, tag + "_summary.md"), "w") as f:
     f.write("# %s profile summary (MI355X, `python bench.py`, BASELINE configs[1])\n\n" % tag)
     f.write("bench line: **%.1f %s**, %.2f ms/step, p50 %.2f ms; roofline %s\n\n" % (
-        b["value"], b["unit"], b["ms_per_step"], b["p50_serve_latency_ms"], json.dumps(b["roofline"])))
+        b["value"], b["unit"], b["ms_per_step"], b.get("p50_step_ms", b.get("p50_serve_latency_ms", 0.0)), json.dumps(b["roofline"])))
     f.write("cpu_baseline: %s\n\n" % json.dumps(b.get("cpu_baseline")))
     f.write("## rocprofv3 --kernel-trace --stats (3 timed + 1 warm-up step; `%s_kernel_stats.csv`)\n\n" % tag)
     f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")

@@ -142,6 +142,10 @@ struct MbxArgs {
   const float* w0t;       // [32][32] projection kernel^T x BN scale (mbxb_pack_proj)
   const float* sh0f;      // [32] projection BN shift
   int c0, g_div;
+  // block order of launches whose input is shared by the in_div samples of an image (mbxb_kernel): 1-D grid, the
+  // in_div blocks of one tile adjacent and on ONE XCD (ids = tile slot + 8 t), so that the shared tile is fetched into
+  // that XCD's L2 once instead of once per sample; 0 = plain (tiles_x, tiles_y, rows) grid
+  int remap_T, tiles_x, tiles_y;
 };
 void mbxb_pack_proj(const float* w0, const float* sc, const float* sh, int c0, int cout, float* out);
 size_t mbx_par_floats(int Cmid, int k);
