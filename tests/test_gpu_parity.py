@@ -152,7 +152,8 @@ def _rand_boxes(rng, n, span=400.0, tied=False):
                                               (50, False, 0.25, 0.001), (3000, False, 0.25, 0.001),
                                               (3000, True, 0.25, 0.001), (5000, True, 0.0, float("-inf")),
                                               (2500, False, 0.0, 0.3), (20000, True, 0.25, 0.001),
-                                              (777, False, 0.5, 0.2)])
+                                              (777, False, 0.5, 0.2), (3000, False, 0.3, 0.001),      # scale = -0.5 / 0.3: not a power of two
+                                              (3000, True, 0.15, 0.001)])
 def test_nms_kernel_bit_exact(n, tied, sigma, thr):
     from oracle import post_ref as P
     p = make_params()
