@@ -273,3 +273,47 @@ def test_sample_decode_matches_oracle(name, over, nsamp):
     assert not np.array_equal(d.candidates(2)["boxes"], cand["boxes"])
     d.close()
     d2.close()
+
+
+TOPK_WORKER = r"""
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import numpy as np
+from common import FULL_MC, PLAIN, make_images, make_params, make_weights
+from uda_amd.infer_lib import KerasDriver
+from oracle import effdet_ref as E, philox_ref as R, post_ref as P, preprocess_ref as PP
+TOPK = dict(nms_configs=dict(method="gaussian", iou_thresh=None, score_thresh=0.0, sigma=None, pyfunc=False, max_nms_inputs=500,
+                             max_output_size=100))
+for over, quant in ((dict(PLAIN, **TOPK), True), (dict(FULL_MC, **TOPK), False)):
+    p = make_params(**over)
+    w = make_weights(p, seed=23)
+    x, scales = PP.preprocess(make_images(2, 128, 192, seed=24), (128, 192), p["mean_rgb"], p["stddev_rgb"])
+    sites = E.dropout_sites(p)
+    masks = R.make_masks(sites, 0, 2, p["mc_dropoutsamp"]) if sites else None
+    rcls, rbox = E.forward(w, p, x, masks)
+    if quant:
+        rcls = [np.round(c * 4) / 4 for c in rcls]              # thousands of exact ties: the index rule decides
+    want = P.pre_nms(p, rcls, rbox)
+    d = KerasDriver("_", False, p["name"], 2, False, p, weights=w)
+    d.postprocess(rcls, rbox, scales)
+    got = d.candidates(2)
+    for key in ("classes", "scores", "boxes"):
+        assert np.array_equal(got[key], want[key]), (key, quant)
+    for mode in ("global", "per_class"):
+        g = d.postprocess(rcls, rbox, scales, post_mode=mode)
+        r = (P.postprocess_global if mode == "global" else P.postprocess_per_class)(p, rcls, rbox, scales)
+        for a, b in zip(g, r):
+            assert np.array_equal(a, b), (mode, quant)
+    d.close()
+print("topk ok")
+"""
+
+
+@pytest.mark.parametrize("multi", ["2", "0"], ids=["multi-block", "one-block-per-image"])
+def test_topk_selection_paths_bit_exact(multi):
+    """a10: both top-k implementations - the device-wide radix select on 53-bit composite keys (forced for a short list with
+    UDA_TOPK_MULTI=2; taken by itself from 65 536 values per image, i.e. by the D2 tests above) and the one-block-per-image
+    kernel - give the oracle's candidates, exact ties included (value descending, ties -> lower flat index)."""
+    e = dict(os.environ, UDA_TOPK_MULTI=multi)
+    r = subprocess.run([sys.executable, "-c", TOPK_WORKER % {"root": ROOT}], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "topk ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

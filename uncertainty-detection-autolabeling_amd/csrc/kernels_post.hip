@@ -603,8 +603,134 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* vals, i
   for (int j = threadIdx.x; j < k; j += blockDim.x) out[j] = (int32_t)(0xFFFFFFFFu - (uint32_t)keys[j]);
 }
 
-void launch_topk(const float* vals, int n_img, int L, int k, int32_t* out_idx, hipStream_t s) {
-  hipLaunchKernelGGL(topk_kernel, dim3(n_img), dim3(TOPK_THREADS), 0, s, vals, L, k, out_idx);
+// ---- the same selection spread over the device (an image of D2 at 1024 x 1024 has 1.37 M (anchor, class) values and a
+// batch share of 2 images: one block per image left 254 CUs idle for 4.4 ms).  Every value gets a DISTINCT 53-bit composite
+// key (order-preserving value bits << 21 | 2^21 - 1 - index): the k largest composites are exactly "value descending, ties ->
+// lower index".  Radix select, 5 digits (11, 11, 11, 10, 10 bits): per digit one grid-wide histogram pass (LDS histogram per
+// block, merged with atomics) - every block first re-derives the digits chosen so far from the previous histograms, so there
+// is no separate pick launch; then one compaction pass (everything >= the k-th composite, appended in any order) and the
+// bitonic sort of the k keys, one block per image.
+constexpr int TK2_LEVELS = 5;
+__device__ __constant__ int TK2_BITS[TK2_LEVELS] = {11, 11, 11, 10, 10};
+__device__ __forceinline__ unsigned long long topk_comp(float v, int i) {
+  return ((unsigned long long)ord32(v) << 21) | (unsigned long long)(0x1FFFFFu - (uint32_t)i);
+}
+// digits chosen on levels < level (deterministic, identical in every block): prefix of the k-th largest composite and how many
+// elements of the current prefix class are still to be taken
+__device__ __forceinline__ void topk2_resolve(const unsigned* hist_img /*[levels][2048]*/, int level, int k, unsigned long long* prefix, int* need,
+                                              unsigned* sh /*[2048] scratch*/) {
+  unsigned long long pre = 0;
+  int rem = k;
+  for (int l = 0; l < level; ++l) {
+    const int nb = 1 << TK2_BITS[l];
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) sh[i] = hist_img[l * 2048 + i];
+    __syncthreads();
+    int b = nb - 1;                      // every thread walks the (<= 2048) bins itself: no broadcast, no extra barrier
+    for (; b > 0; --b) {
+      const int c = (int)sh[b];
+      if (c >= rem) break;
+      rem -= c;
+    }
+    pre = (pre << TK2_BITS[l]) | (unsigned long long)b;
+    __syncthreads();
+  }
+  *prefix = pre;
+  *need = rem;
+}
+
+__global__ __launch_bounds__(256) void topk2_hist_kernel(const float* vals, int L, int k, unsigned* hist /*[n_img][levels][2048]*/, int level) {
+  __shared__ unsigned sh[2048];
+  const int img = blockIdx.y;
+  const float* v = vals + (size_t)img * L;
+  unsigned* hist_img = hist + (size_t)img * TK2_LEVELS * 2048;
+  unsigned long long prefix;
+  int need;
+  topk2_resolve(hist_img, level, k, &prefix, &need, sh);
+  int used = 0;
+  for (int l = 0; l < level; ++l) used += TK2_BITS[l];
+  const int bits = TK2_BITS[level], shift = 53 - used - bits, nb = 1 << bits;
+  for (int i = threadIdx.x; i < nb; i += 256) sh[i] = 0;
+  __syncthreads();
+  const int per = (L + gridDim.x - 1) / gridDim.x;
+  const int lo = blockIdx.x * per, hi = min(L, lo + per);
+  for (int i = lo + threadIdx.x; i < hi; i += 256) {
+    const unsigned long long key = topk_comp(v[i], i);
+    if (level == 0 || (key >> (shift + bits)) == prefix) atomicAdd(&sh[(unsigned)(key >> shift) & (nb - 1)], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nb; i += 256)
+    if (sh[i]) atomicAdd(&hist_img[level * 2048 + i], sh[i]);
+}
+
+__global__ __launch_bounds__(256) void topk2_collect_kernel(const float* vals, int L, int k, const unsigned* hist, unsigned long long* keys /*[n_img][P]*/,
+                                                            int* count /*[n_img]*/, int P) {
+  __shared__ unsigned sh[2048];
+  const int img = blockIdx.y;
+  const float* v = vals + (size_t)img * L;
+  unsigned long long kth;
+  int need;
+  topk2_resolve(hist + (size_t)img * TK2_LEVELS * 2048, TK2_LEVELS, k, &kth, &need, sh);   // all 53 bits: the k-th largest composite itself
+  const int per = (L + gridDim.x - 1) / gridDim.x;
+  const int lo = blockIdx.x * per, hi = min(L, lo + per);
+  for (int i = lo + threadIdx.x; i < hi; i += 256) {
+    const unsigned long long key = topk_comp(v[i], i);
+    if (key >= kth) {
+      const int pos = atomicAdd(&count[img], 1);
+      if (pos < P) keys[(size_t)img * P + pos] = key;
+    }
+  }
+}
+
+__global__ __launch_bounds__(TOPK_THREADS) void topk2_sort_kernel(const unsigned long long* keys_in, const int* count, int k, int P, int32_t* out_idx) {
+  __shared__ unsigned long long keys[TOPK_MAX];
+  const int img = blockIdx.x;
+  const int n = min(count[img], P);
+  for (int i = threadIdx.x; i < P; i += blockDim.x) keys[i] = i < n ? keys_in[(size_t)img * P + i] : 0ull;
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < P / 2; t += blockDim.x) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long x = keys[lo], y = keys[hi];
+        if ((x < y) == desc) { keys[lo] = y; keys[hi] = x; }
+      }
+      __syncthreads();
+    }
+  }
+  int32_t* out = out_idx + (size_t)img * k;
+  for (int j = threadIdx.x; j < k; j += blockDim.x) out[j] = (int32_t)(0x1FFFFFu - (uint32_t)(keys[j] & 0x1FFFFFull));
+}
+
+size_t topk_workspace_bytes(int n_img, int k) {
+  int P = 1;
+  while (P < k) P <<= 1;
+  return (size_t)n_img * (TK2_LEVELS * 2048 * sizeof(unsigned) + sizeof(int) * 4 + (size_t)P * sizeof(unsigned long long)) + 256;
+}
+
+void launch_topk(const float* vals, int n_img, int L, int k, int32_t* out_idx, void* ws, hipStream_t s) {
+  static int multi = -1;
+  if (multi < 0) { const char* e = getenv("UDA_TOPK_MULTI"); multi = e ? atoi(e) : 1; }
+  // few images per launch and a long value list: spread each image over the device; many images: one block each is enough
+  // (UDA_TOPK_MULTI=2: also for short lists - test hook; 0: never)
+  if (!multi || !ws || L > (1 << 21) || (L < (1 << 16) && multi != 2) || n_img > 64 || k > TOPK_MAX) {
+    hipLaunchKernelGGL(topk_kernel, dim3(n_img), dim3(TOPK_THREADS), 0, s, vals, L, k, out_idx);
+    return;
+  }
+  int P = 1;
+  while (P < k) P <<= 1;
+  unsigned* hist = (unsigned*)ws;
+  int* count = (int*)(hist + (size_t)n_img * TK2_LEVELS * 2048);
+  unsigned long long* keys = (unsigned long long*)(((uintptr_t)(count + 4 * n_img) + 255) & ~(uintptr_t)255);
+  hipMemsetAsync(ws, 0, (size_t)n_img * (TK2_LEVELS * 2048 * sizeof(unsigned) + sizeof(int) * 4), s);
+  int nblk = (1024 + n_img - 1) / n_img;            // about 1024 blocks in all
+  if (nblk > (L + 4095) / 4096) nblk = (L + 4095) / 4096;
+  if (nblk < 1) nblk = 1;
+  for (int level = 0; level < TK2_LEVELS; ++level)
+    hipLaunchKernelGGL(topk2_hist_kernel, dim3(nblk, n_img), dim3(256), 0, s, vals, L, k, hist, level);
+  hipLaunchKernelGGL(topk2_collect_kernel, dim3(nblk, n_img), dim3(256), 0, s, vals, L, k, hist, keys, count, P);
+  hipLaunchKernelGGL(topk2_sort_kernel, dim3(n_img), dim3(TOPK_THREADS), 0, s, keys, count, k, P, out_idx);
 }
 
 // ------------------------------------------------------------------------------------ NMS (NonMaxSuppressionV5)

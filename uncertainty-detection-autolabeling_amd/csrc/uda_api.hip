@@ -94,6 +94,7 @@ struct uda_ctx {
   int Kc = 0;                  // candidates per image: A_tot, or max_nms_inputs on the top-k path
   float* d_clsmean = nullptr;  // [max_images, A_tot*C]  (top-k path)
   int32_t* d_cand_flat = nullptr;  // [max_images, Kc]   (top-k path)
+  void* d_topk_ws = nullptr;       // scratch of the multi-block top-k selection
   // nms workspaces: [0] global mode (one problem per image), [1] per-class mode (images*classes problems)
   struct NmsWs {
     float *stale = nullptr, *tent = nullptr, *ub = nullptr, *sel_score = nullptr, *sel_box = nullptr;
@@ -217,6 +218,7 @@ extern "C" void uda_destroy(uda_ctx_t* c) {
   for (void* p : ptrs)
     if (p) hipFree(p);
   free_prefix_ws(c->pfx);
+  if (c->d_topk_ws) hipFree(c->d_topk_ws);
   if (c->d_coop_bar) hipFree(c->d_coop_bar);
   if (c->d_coop_err) hipFree(c->d_coop_err);
   for (auto& w : c->ws) {
@@ -547,6 +549,7 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
     c->Kc = m.max_nms_inputs;
     CK(dalloc(&c->d_clsmean, N * (size_t)c->A_tot * m.num_classes));
     CK(dalloc(&c->d_cand_flat, N * (size_t)c->Kc));
+    CK(hipMalloc(&c->d_topk_ws, topk_workspace_bytes((int)N, c->Kc)));
   } else {
     c->Kc = c->A_tot;
   }
@@ -1088,7 +1091,7 @@ static int run_candidates(uda_ctx* c, int i0, int n, hipStream_t st) {
     float* cm = c->d_clsmean + (size_t)i0 * c->A_tot * C;
     int32_t* cf = c->d_cand_flat + (size_t)i0 * K;
     launch_class_mean(a, cm, st);
-    launch_topk(cm, n, c->A_tot * m.num_classes, c->Kc, cf, st);
+    launch_topk(cm, n, c->A_tot * m.num_classes, c->Kc, cf, c->d_topk_ws, st);
     a.cand_flat = cf;
   }
   launch_aggregate(a, st);

@@ -237,7 +237,9 @@ void launch_aggregate(const AggArgs& a, hipStream_t s);
 // mean logits of every (anchor, class): out [n, A_tot*C]   (input of the top-k pre-selection)
 void launch_class_mean(const AggArgs& a, float* out, hipStream_t s);
 // per image: the k largest of vals[n][0..L) -> flat indices, value descending, ties -> lower index
-void launch_topk(const float* vals, int n_img, int L, int k, int32_t* out_idx, hipStream_t s);
+// ws: scratch of topk_workspace_bytes(n_img, k) bytes for the multi-block selection (null: one block per image)
+void launch_topk(const float* vals, int n_img, int L, int k, int32_t* out_idx, void* ws, hipStream_t s);
+size_t topk_workspace_bytes(int n_img, int k);
 
 struct PreprocArgs {
   const uint8_t* in;   // [n, h, w, 3]

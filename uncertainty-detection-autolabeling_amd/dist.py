@@ -67,12 +67,22 @@ def all_gather_detections(det, device=None, group=None, counts=None):
         if len(counts) != world or counts[dist.get_rank(group)] != packed.shape[0]:
             raise ValueError("counts %s do not describe this rank's %d images" % (counts, packed.shape[0]))
     n_max = max(counts)
-    buf = np.zeros((n_max,) + packed.shape[1:], np.float32)
-    buf[:packed.shape[0]] = packed
+    if packed.shape[0] == n_max:
+        buf = packed
+    else:
+        buf = np.zeros((n_max,) + packed.shape[1:], np.float32)
+        buf[:packed.shape[0]] = packed
     t = torch.from_numpy(buf).to(dev)
-    outs = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(outs, t, group=group)
-    full = np.concatenate([o.cpu().numpy()[:c] for o, c in zip(outs, counts)], axis=0)
+    # one collective into one tensor and ONE copy back (not a device-to-host copy per rank)
+    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=dev)
+    if hasattr(dist, "all_gather_into_tensor") and dist.get_backend(group) != "gloo":
+        dist.all_gather_into_tensor(out, t, group=group)
+    else:
+        parts = [out[r] for r in range(world)]
+        dist.all_gather(parts, t, group=group)
+    host = out.cpu().numpy()
+    full = host.reshape((world * n_max,) + packed.shape[1:]) if all(c == n_max for c in counts) else \
+        np.concatenate([host[r, :c] for r, c in enumerate(counts)], axis=0)
     return unpack_detections(full, layout)
 
 
