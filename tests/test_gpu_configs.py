@@ -73,7 +73,9 @@ from common import FULL_MC, MC_NO_ATT, make_images, make_params, make_weights
 from uda_amd.infer_lib import KerasDriver, ServingDriver
 from oracle import effdet_ref as E, philox_ref as R, post_ref as P, preprocess_ref as PP
 for over, spread in ((dict(FULL_MC, mc_dropoutsamp=10), 1.0), (dict(FULL_MC, mc_dropoutsamp=20, num_classes=10), 1.0),
-                     (dict(FULL_MC, mc_dropoutsamp=10), 20.0), (dict(MC_NO_ATT, mc_dropoutsamp=10), 20.0)):
+                     (dict(FULL_MC, mc_dropoutsamp=10), 20.0), (dict(MC_NO_ATT, mc_dropoutsamp=10), 20.0),
+                     (dict(FULL_MC, mc_dropoutsamp=30), 1.0), (dict(FULL_MC, mc_dropoutsamp=10, num_classes=10), 20.0),
+                     (dict(MC_NO_ATT, mc_dropoutsamp=20), 1.0)):
     p = make_params(**over)
     w = make_weights(p, seed=11, cls_spread=spread)
     x, scales = PP.preprocess(make_images(2, 100, 180, seed=12), (128, 192), p["mean_rgb"], p["stddev_rgb"])
@@ -96,8 +98,10 @@ print("aggregate ok")
 
 @pytest.mark.parametrize("env", [dict(UDA_AGG_REG="0"), dict()], ids=["lds-parking", "registers"])
 def test_aggregate_kernel_variants_bit_exact(env):
-    """T=10/C=7 and T=20/C=10 (BASELINE configs[1] / [2]) through the LDS-parking aggregate kernel
-    (UDA_AGG_REG=0) and through the default choice; the switch is read once per process."""
+    """T=10/C=7, T=20/C=10, T=30/C=7 (BASELINE configs[1] / [2] / [4]) and neighbours through the LDS-parking aggregate kernel
+    (UDA_AGG_REG=0: all classes parked, or one class at a time for T=30) and through the default choice (register kernels:
+    all logits in registers for T=10/C=7, two streaming passes for the other common (T, C)); the switch is read once per
+    process."""
     e = dict(os.environ)
     e.update(env)
     r = subprocess.run([sys.executable, "-c", AGG_WORKER % {"root": ROOT}], cwd=ROOT, env=e, capture_output=True,

@@ -427,6 +427,107 @@ __global__ __launch_bounds__(128) void aggregate_reg_kernel(AggArgs a) {
   }
 }
 
+// The register kernel for the other common (T, C): the class statistics are computed in two STREAMING passes over the
+// sample axis (sample-major: the C logits of an anchor are contiguous, so consecutive loads of a wave touch the same lines;
+// the class-major loop of aggregate_reg_kernel<T, 0> re-fetched every line C times through a thrashing L1: 6.3 ms for
+// T = 20 / C = 10 on 32 images) - pass 1 the sums, pass 2 the squared deviations - with 3 C registers instead of T C; the T
+// decoded boxes stay in registers as before.  Same arithmetic order (bit-exact).
+template <int T, int C>
+__global__ __launch_bounds__(128) void aggregate_reg2_kernel(AggArgs a) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)a.n_img * a.K) return;
+  const int n = (int)(gid / a.K);
+  int ai = (int)(gid % a.K), fixed_c = -1;
+  if (a.cand_flat) {
+    const int flat = a.cand_flat[gid];
+    ai = flat / C;
+    fixed_c = flat % C;
+  }
+  int lvl = 0;
+  while (lvl + 1 < a.lv.num_levels && ai >= a.lv.a_off[lvl + 1]) ++lvl;
+  const int loc = ai - a.lv.a_off[lvl];
+  const int p = loc / a.A, al = loc % a.A;
+  const int hw = a.lv.hw[lvl];
+  const int cch = a.A * C;
+  const float* cbase = a.lv.cls[lvl] + ((size_t)n * T * hw + p) * cch + al * C;
+  const size_t cstride = (size_t)hw * cch;
+  const float fT = (float)T;
+  float m[C], v[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) m[c] = cbase[c];
+  for (int t = 1; t < T; ++t) {
+    const float* x = cbase + t * cstride;
+#pragma unroll
+    for (int c = 0; c < C; ++c) m[c] = m[c] + x[c];
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) { m[c] = m[c] / fT; v[c] = 0.f; }
+  if (a.u_cls) {
+    for (int t = 0; t < T; ++t) {
+      const float* x = cbase + t * cstride;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float dlt = x[c] - m[c];
+        v[c] = v[c] + dlt * dlt;
+      }
+    }
+  }
+  float best = -INFINITY;
+  int best_c = 0;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float sd = a.u_cls ? sqrtf(v[c] / fT) : 0.f;
+    a.logits[(size_t)gid * C + c] = m[c];
+    if (fixed_c < 0) {
+      if (a.u_cls) a.u_cls[(size_t)gid * C + c] = sd;
+      if (m[c] > best) { best = m[c]; best_c = c; }
+    } else if (c == fixed_c) {
+      if (a.u_cls) a.u_cls[gid] = sd;
+      best = m[c];
+      best_c = c;
+    }
+  }
+  a.scores[gid] = (float)(1.0 / (1.0 + exp(-(double)best)));
+  a.classes[gid] = best_c;
+
+  const int bch = a.A * (a.loss_att ? 8 : 4);
+  const float* bbase = a.lv.box[lvl] + ((size_t)n * T * hw + p) * bch + al * 4;
+  const size_t bstride = (size_t)hw * bch;
+  const float an[4] = {a.anchors[ai * 4 + 0], a.anchors[ai * 4 + 1], a.anchors[ai * 4 + 2], a.anchors[ai * 4 + 3]};
+  float bxs[T * 4];
+  float sb[4], ss[4];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    Dec d;
+    decode_one<false>(a, bbase + t * bstride, a.A, an, d);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sb[k] = t ? sb[k] + d.box[k] : d.box[k];
+      ss[k] = t ? ss[k] + d.sig[k] : d.sig[k];
+      bxs[t * 4 + k] = d.box[k];
+    }
+  }
+  float mb[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    mb[k] = sb[k] / fT;
+    a.boxes[(size_t)gid * 4 + k] = mb[k];
+    if (a.u_al) a.u_al[(size_t)gid * 4 + k] = ss[k] / fT;
+  }
+  if (a.u_ep) {
+    float vv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float dlt = bxs[t * 4 + k] - mb[k];
+        vv[k] = vv[k] + dlt * dlt;
+      }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a.u_ep[(size_t)gid * 4 + k] = sqrtf(vv[k] / fT);
+  }
+}
+
 void launch_aggregate(const AggArgs& a0, hipStream_t s) {
   AggArgs a = a0;
   static int regs = -1;
@@ -436,8 +537,18 @@ void launch_aggregate(const AggArgs& a0, hipStream_t s) {
     const int64_t tot = (int64_t)a.n_img * a.K;
     const dim3 grid((unsigned)((tot + 127) / 128)), block(128);
     if (a.Tc == 10 && a.C == 7) hipLaunchKernelGGL((aggregate_reg_kernel<10, 7>), grid, block, 0, s, a);
+    else if (a.Tc == 10 && a.C == 10) hipLaunchKernelGGL((aggregate_reg2_kernel<10, 10>), grid, block, 0, s, a);
+    else if (a.Tc == 20 && a.C == 7) hipLaunchKernelGGL((aggregate_reg2_kernel<20, 7>), grid, block, 0, s, a);
+    else if (a.Tc == 20 && a.C == 10) hipLaunchKernelGGL((aggregate_reg2_kernel<20, 10>), grid, block, 0, s, a);
     else if (a.Tc == 10) hipLaunchKernelGGL((aggregate_reg_kernel<10, 0>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((aggregate_reg_kernel<20, 0>), grid, block, 0, s, a);
+    return;
+  }
+  if (regs && !sample && a.Tc == a.Tb && a.Tc == 30 && (a.C == 7 || a.C == 10)) {      // configs[4]: T = 30
+    const int64_t tot = (int64_t)a.n_img * a.K;
+    const dim3 grid((unsigned)((tot + 127) / 128)), block(128);
+    if (a.C == 7) hipLaunchKernelGGL((aggregate_reg2_kernel<30, 7>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((aggregate_reg2_kernel<30, 10>), grid, block, 0, s, a);
     return;
   }
   const int64_t total = (int64_t)a.n_img * a.K;
