@@ -25,56 +25,9 @@
 
 #include <type_traits>
 
-#include "uda_internal.h"
+#include "mfma_common.h"
 
 namespace uda {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ float sigmoidf_b(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-__device__ __forceinline__ float swishf_b(float x) { return x * sigmoidf_b(x); }
-
-// swish with the exponent scale folded into the producer: y = -log2(e) * x comes out of the GEMM / BN (weights,
-// shift and BN scale are pre-multiplied on the host or when they are staged), k = -keep_scale / log2(e):
-//   x * sigmoid(x) * keep_scale = y * k / (1 + 2^y)        (v_exp, v_add, v_rcp, 2 v_mul: 5 VALU instead of 7)
-constexpr float UDA_NEG_LN2 = -0.6931471805599453f;
-__device__ __forceinline__ float swish_folded(float y, float k) {
-  return (y * k) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y));
-}
-
-// the same without the constant factor: y / (1 + 2^y) = swish(x) / (-ln 2) for y = -log2(e) x.  The fused MBConv kernels
-// store THIS as the expanded activation and fold (-ln 2) x (dropout keep-scale of the channel) into the BN scale that
-// follows the depthwise convolution (a per-channel factor commutes with a depthwise convolution): one multiply less per
-// expanded element.
-__device__ __forceinline__ float swish_core(float y) { return y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y)); }
-
-// Store through a UNIFORM base (scalar register pair) plus a 32-bit per-lane byte offset: global_store_dword v, v, s[..].
-// The base is made opaque so that the address is not re-associated into per-lane 64-bit pointers (which the compiler
-// then hoists out of the slab loop: 2 registers per output, spilled at the occupancy these kernels need).
-typedef __attribute__((address_space(1))) char uda_gchar;
-typedef __attribute__((address_space(1))) float uda_gfloat;
-__device__ __forceinline__ void store_uniform_base(float* base, unsigned byte_off, float v) {
-  // (written as one instruction: left to the compiler the scalar base is copied into a register pair per lane and the
-  // 64-bit add comes back.  vmcnt stays conservative: an outstanding store the compiler does not know of only makes a
-  // later counted wait cover more operations, never fewer - memory operations retire in order.)
-  uda_gchar* g = (uda_gchar*)base;
-  asm volatile("global_store_dword %0, %1, %2" : : "v"(byte_off), "v"(v), "s"(g) : "memory");
-}
-
-// two floats -> packed bf16 pair (round to nearest even; v_cvt_pk_bf16_f32), element 0 in the low half
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-  const f32x2 v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ float bf16_lo_f32(unsigned p) { return __uint_as_float(p << 16); }
-__device__ __forceinline__ float bf16_hi_f32(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
-
-constexpr int PWB_BK = 32;         // k per staged chunk = 2 MFMA k-steps of 16
-constexpr int PWB_AROW = 80;       // bytes per A image row: 32 bf16 + 16 pad
-constexpr int PWB_STG = 68;        // epilogue staging row stride (floats)
 
 template <int MT, int NT, int WM, int WN, int PARTS, int OCC>
 __global__ __launch_bounds__(256, OCC) void pwb_kernel(PwArgs a) {
@@ -424,250 +377,6 @@ void launch_pwb(const PwArgs& a, int rows, hipStream_t s) {
   }
 }
 
-// ---------------------------------------------------------------- fused separable convolution
-// SeparableConv2D of the BiFPN nodes and of the class / box heads (efficientdet_keras.py:207-227,421-446,
-// 584-626): depthwise 3x3 stride 1 (TF SAME, no bias / BN / activation) feeding the 1x1 convolution
-// (+ bias, BN, swish, MC-dropout keep-scale).  The depthwise result never goes to HBM: the block computes it
-// for its 8 x 16 pixel tile and all C channels on the VALU (3-row sliding window per thread, every input element
-// fetched once per block column), splits it into bf16 pieces and writes it straight into the LDS image the MFMA
-// stage reads as its A operand.  One barrier between the two stages; epilogue as in pwb_kernel.
-constexpr int SEP_TH = 8, SEP_TW = 16;
-
-template <int NT, int PARTS, int OCC>     // NT = 32-column tiles of the 1x1 output handled per block (each wave: all of them)
-__global__ __launch_bounds__(256, OCC) void sep_kernel(SepArgs a) {
-  constexpr int BM = SEP_TH * SEP_TW;      // 128 pixels = 4 MFMA row tiles, one per wave
-  extern __shared__ __attribute__((aligned(16))) unsigned char slds[];
-  const int C = a.C, C4 = C >> 2;
-  const int KS = (C + 15) >> 4;            // MFMA k-steps
-  const int arow = KS * 32 + 16;           // bytes per A image row: KS * 16 bf16 + 16 pad (conflict-free ds_read_b128)
-  unsigned char* As = slds;                // [PARTS][BM][arow]
-  uint4* Bs = (uint4*)(slds + (size_t)PARTS * BM * arow);   // [KS][NT][PARTS][64 lanes] x 16 B
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, b_in = b / a.in_div;
-  const int tiles_x = (a.W + SEP_TW - 1) / SEP_TW;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-  const int oy0 = ty * SEP_TH, ox0 = tx * SEP_TW;
-  const int nt0 = blockIdx.y * NT, n0 = nt0 * 32;
-  const int NTL = (a.Cout + 31) >> 5;
-
-  // ---- B: all k-steps of this block's column tiles, requested first (in flight during the depthwise stage)
-  const uint4* Wp = (const uint4*)a.wsplit;
-  const int b_total = KS * NT * PARTS * 64;
-  constexpr int B_MAX = 8;                 // uint4 per thread: K <= 128, NT <= 4, PARTS = 2 -> 8 * 4 * 2 * 64 / 256 = 16 (two rounds)
-  for (int f0 = tid; f0 < b_total; f0 += 256 * B_MAX) {
-    uint4 rb[B_MAX];
-#pragma unroll
-    for (int i = 0; i < B_MAX; ++i) {
-      const int f = f0 + 256 * i;
-      int q = f >> 6;
-      const int part = q % PARTS; q /= PARTS;
-      const int nt = q % NT, ks = q / NT;
-      rb[i] = make_uint4(0u, 0u, 0u, 0u);
-      if (f < b_total && nt0 + nt < NTL) rb[i] = Wp[(((size_t)ks * NTL + (nt0 + nt)) * PARTS + part) * 64 + (f & 63)];
-    }
-#pragma unroll
-    for (int i = 0; i < B_MAX; ++i) {
-      const int f = f0 + 256 * i;
-      if (f < b_total) Bs[f] = rb[i];
-    }
-  }
-
-  // ---- depthwise 3x3: unit = (channel quad q, tile column x); 8 output rows with a 3-row register window
-  const float* inb = a.in + (size_t)b_in * a.H * a.W * C;
-  for (int u = tid; u < SEP_TW * C4; u += 256) {
-    const int q = u % C4, x = u / C4;
-    float4 wk[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) wk[t] = *(const float4*)(a.wd + (size_t)t * C + 4 * q);
-    const int gx = ox0 + x;
-    // all (8 + 2) x 3 input quads of the unit are requested up front: 30 independent 16-byte loads in flight,
-    // one exposed memory latency per unit instead of one per output row
-    float4 win[SEP_TH + 2][3];
-#pragma unroll
-    for (int r = 0; r < SEP_TH + 2; ++r) {
-      const int iy = oy0 - 1 + r;
-      const bool rowok = iy >= 0 && iy < a.H;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int ix = gx - 1 + j;
-        win[r][j] = (rowok && ix >= 0 && ix < a.W) ? *(const float4*)(inb + ((size_t)iy * a.W + ix) * C + 4 * q)
-                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-#pragma unroll
-    for (int ry = 0; ry < SEP_TH; ++ry) {
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const float4 v = win[ry + ky][kx];
-          const float4 w = wk[ky * 3 + kx];
-          acc.x = fmaf(v.x, w.x, acc.x);
-          acc.y = fmaf(v.y, w.y, acc.y);
-          acc.z = fmaf(v.z, w.z, acc.z);
-          acc.w = fmaf(v.w, w.w, acc.w);
-        }
-      // split into bf16 pieces -> A image row m = ry * 16 + x, channels 4q .. 4q + 3
-      const int m = ry * SEP_TW + x;
-      float r0 = acc.x, r1 = acc.y, r2 = acc.z, r3 = acc.w;
-#pragma unroll
-      for (int p = 0; p < PARTS; ++p) {
-        const unsigned u0 = pack_bf16(r0, r1), u1 = pack_bf16(r2, r3);
-        *(uint2*)(As + (size_t)(p * BM + m) * arow + q * 8) = make_uint2(u0, u1);
-        if (p + 1 < PARTS) {
-          r0 -= bf16_lo_f32(u0); r1 -= bf16_hi_f32(u0);
-          r2 -= bf16_lo_f32(u1); r3 -= bf16_hi_f32(u1);
-        }
-      }
-    }
-  }
-  // channels beyond C inside the last k-step (C % 16 == 8): zero them once
-  if (C & 15) {
-    for (int e = tid; e < PARTS * BM; e += 256) *(uint4*)(As + (size_t)e * arow + (C >> 3) * 16) = make_uint4(0u, 0u, 0u, 0u);
-  }
-  __syncthreads();
-
-  // ---- 1x1 on the matrix cores: wave w owns pixel rows [32 w, 32 w + 32) and all NT column tiles
-  f32x16 acc[NT];
-#pragma unroll
-  for (int n = 0; n < NT; ++n)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-  for (int ks = 0; ks < KS; ++ks) {
-    bf16x8 af[PARTS];
-#pragma unroll
-    for (int p = 0; p < PARTS; ++p)
-      af[p] = *(const bf16x8*)(As + (size_t)(p * BM + wave * 32 + li) * arow + ks * 32 + lh * 16);
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      bf16x8 bf[PARTS];
-#pragma unroll
-      for (int p = 0; p < PARTS; ++p) bf[p] = __builtin_bit_cast(bf16x8, Bs[((ks * NT + n) * PARTS + p) * 64 + lane]);
-      if constexpr (PARTS == 3) {
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[n], 0, 0, 0);
-      }
-      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[n], 0, 0, 0);
-      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[n], 0, 0, 0);
-      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[n], 0, 0, 0);
-    }
-  }
-  __syncthreads();      // the staging tile below aliases the A / B images
-
-  // tile row m -> output pixel
-  auto pixel_of = [&](int m, size_t& pix) -> bool {
-    const int y = oy0 + (m >> 4), x = ox0 + (m & 15);
-    pix = (size_t)y * a.W + x;
-    return y < a.H && x < a.W;
-  };
-  const size_t out_base = (size_t)b * a.H * a.W;
-
-  if ((a.Cout & 3) != 0) {
-    // scalar epilogue (class head: 9 * 7 = 63 channels)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int col = n0 + n * 32 + li;
-      if (col >= a.Cout) continue;
-      const float bias = a.bias ? a.bias[col] : 0.f;
-      const float sc = a.bn_scale ? a.bn_scale[col] : 1.f;
-      const float sh = a.bn_scale ? a.bn_shift[col] : 0.f;
-      const float mk = a.mask ? a.mask[(size_t)b * a.Cout + col] : 1.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        size_t pix;
-        if (!pixel_of(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, pix)) continue;
-        float v = fmaf(acc[n][r] + bias, sc, sh);
-        if (a.act == UDA_ACT_SWISH) v = swishf_b(v);
-        v *= mk;
-        a.out[(out_base + pix) * a.Cout + col] = v;
-      }
-    }
-    return;
-  }
-
-  float* stg = (float*)slds + wave * 32 * PWB_STG;
-  const int rrow = lane >> 4, c4 = lane & 15;
-#pragma unroll
-  for (int p = 0; p < (NT + 1) / 2; ++p) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int n = 2 * p + q;
-      if (n < NT) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * PWB_STG + q * 32 + li] = acc[n][r];
-      }
-    }
-    __syncthreads();
-    const int col = n0 + 2 * p * 32 + 4 * c4;
-    const bool colok = (col < a.Cout) && (2 * p * 32 + 4 * c4 < NT * 32);
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f);
-    float4 sh = make_float4(0.f, 0.f, 0.f, 0.f), mk = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (colok) {
-      if (a.bias) bias = *(const float4*)(a.bias + col);
-      if (a.bn_scale) {
-        sc = *(const float4*)(a.bn_scale + col);
-        sh = *(const float4*)(a.bn_shift + col);
-      }
-      if (a.mask) mk = *(const float4*)(a.mask + (size_t)b * a.Cout + col);
-    }
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = it * 4 + rrow;
-      size_t pix;
-      if (colok && pixel_of(wave * 32 + row, pix)) {
-        float4 v = *(const float4*)(stg + row * PWB_STG + 4 * c4);
-        v.x = fmaf(v.x + bias.x, sc.x, sh.x);
-        v.y = fmaf(v.y + bias.y, sc.y, sh.y);
-        v.z = fmaf(v.z + bias.z, sc.z, sh.z);
-        v.w = fmaf(v.w + bias.w, sc.w, sh.w);
-        if (a.act == UDA_ACT_SWISH) {
-          v.x = swishf_b(v.x); v.y = swishf_b(v.y); v.z = swishf_b(v.z); v.w = swishf_b(v.w);
-        }
-        v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
-        *(float4*)(a.out + (out_base + pix) * a.Cout + col) = v;
-      }
-    }
-    __syncthreads();
-  }
-}
-
-bool sep_supported(int C, int Cout) { return C % 8 == 0 && C >= 16 && C <= 128 && Cout >= 1; }
-
-template <int NT>
-static void launch_sep_nt(const SepArgs& a, int rows, int gy, hipStream_t s) {
-  const int KS = (a.C + 15) / 16, arow = KS * 32 + 16;
-  size_t lds = (size_t)a.wparts * 128 * arow + (size_t)KS * NT * a.wparts * 1024;
-  const size_t stg = 4 * 32 * PWB_STG * 4;
-  if (lds < stg) lds = stg;
-  const dim3 grid(((a.W + SEP_TW - 1) / SEP_TW) * ((a.H + SEP_TH - 1) / SEP_TH), gy, rows);
-  auto go = [&](auto kern) {
-    static size_t attr_lds = 64 * 1024;
-    if (lds > attr_lds) {
-      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_lds = lds;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
-  };
-  static int occ = -1;
-  if (occ < 0) { const char* e = getenv("UDA_SEP_OCC"); occ = e ? atoi(e) : 3; }   // 3 blocks per CU: measured 14 % faster than 2
-  if (a.wparts == 3) go(sep_kernel<NT, 3, 2>);
-  else if (occ >= 3 && NT <= 2) go(sep_kernel<NT, 2, 3>);
-  else go(sep_kernel<NT, 2, 2>);
-}
-
-void launch_sep(const SepArgs& a, int rows, hipStream_t s) {
-  const int ntl = (a.Cout + 31) / 32;
-  // all columns in one block when they fit four 32-column tiles, else blocks of three
-  if (ntl == 1) launch_sep_nt<1>(a, rows, 1, s);
-  else if (ntl == 2) launch_sep_nt<2>(a, rows, 1, s);
-  else if (ntl == 3) launch_sep_nt<3>(a, rows, 1, s);
-  else if (ntl == 4) launch_sep_nt<4>(a, rows, 1, s);
-  else launch_sep_nt<3>(a, rows, (ntl + 2) / 3, s);
-}
-
 // ---------------------------------------------------------------- fused MBConv front half, split-bf16 expand
 // expand 1x1 + BN + swish + dropout -> depthwise kxk / stride s (TF SAME) + BN + swish + dropout + SE tile
 // sums, one output tile per block, 32 expanded channels at a time (backbone/efficientnet_model.py:446-464).
@@ -681,6 +390,19 @@ void launch_sep(const SepArgs& a, int rows, hipStream_t s) {
 //   E  : the expanded + activated 32-channel slab [pixel][33] in LDS; the depthwise stage reads it with a
 //        sliding window along x, writes the output tile (128-byte channel segments) and the SE tile sums.
 // Two barriers per 32-channel slab (E complete / E free); the SE reduction rides on the second one.
+// E transposed (5x5 stride 1, every fused MBConv variant): the 32-channel slab is kept [channel][pixel] with a channel pitch
+// of MBX_ET_PITCH floats instead of [pixel][channel].  The accumulator of the expand MFMA holds 4 x 4 CONSECUTIVE pixels of
+// one channel per lane and the input tile is 20 pixels wide, so a group of 4 never straddles a tile row: the activation is
+// stored with 4 ds_write_b128 instead of 16 ds_write_b32, and the depthwise stage reads the 12-pixel window of a tap row with
+// 3 ds_read_b128 instead of 12 ds_read_b32 - half the LDS-array cycles (256 instead of 128 B/clk) and a quarter of the LDS
+// instructions of the phase that bounds the deep 5x5 blocks.  Pitch 260 = 4 x 65 (odd): the 16 lanes of a ds_read_b128 group
+// (16 different channels) land on 16 different 16-byte slots of the bank row, and the 8 lanes of a ds_write_b128 group on 8.
+constexpr int MBX_ET_PITCH = 260;
+#ifndef UDA_MBX_ET
+#define UDA_MBX_ET 1
+#endif
+__host__ __device__ constexpr bool mbx_et(int k, int s) { return UDA_MBX_ET && k == 5 && s == 1; }
+
 namespace {
 struct MbxCfgB { int th, tw; };
 __host__ __device__ constexpr MbxCfgB mbxb_cfg(int k, int s) {
@@ -719,6 +441,9 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
   constexpr int NG = NW * 2;                  // depthwise thread groups (32 channels each)
   constexpr int MTW = (NMT + NW - 1) / NW;    // pixel slices per wave
   constexpr int ES = 32;
+  // 5x5 stride 1: E is kept TRANSPOSED, [channel][pixel] with a channel pitch of CP floats (see mbx_et above)
+  constexpr bool ET = mbx_et(K, S);
+  constexpr int CP = MBX_ET_PITCH;
   // depthwise units: XW consecutive outputs of one row; NUNIT units over the NG thread groups
   constexpr int XW = (S == 1) ? 8 : (K == 3 ? 6 : 5);
   constexpr int UPR = TW / XW;                // units per output row
@@ -726,8 +451,8 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
   static_assert(TW % XW == 0 && NUNIT % NG == 0, "units must tile the output tile and the thread groups");
   constexpr int NCOL = (XW - 1) * S + K;
   extern __shared__ __attribute__((aligned(16))) float mlds[];
-  float* E = mlds;                            // [NPP][ES]
-  float* red = E + (size_t)NPP * ES;          // [NG][32]
+  float* E = mlds;                            // [NPP][ES]  (ET: [32][CP])
+  float* red = E + (ET ? (size_t)32 * CP : (size_t)NPP * ES);          // [NG][32]
   constexpr int NPAR = (K * K + 2) * 32;      // per slab: depthwise taps [K*K][32] | BN scale | BN shift (host-packed, a.wpar)
   float* par = red + NG * 32;                 // [2][NPAR]
   constexpr bool B_LDS = KSF <= 2;            // packed expand weights of a slab: LDS image (else registers, one slab ahead)
@@ -863,13 +588,14 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
   for (int ui = 0; ui < UPT; ++ui) {
     const int u = g + NG * ui;
     const int orow = u / UPR, oxs = (u % UPR) * XW;
-    eoff[ui] = ((orow * S) * IW + oxs * S) * ES + c;
+    eoff[ui] = ET ? c * CP + (orow * S) * IW + oxs * S : ((orow * S) * IW + oxs * S) * ES + c;
     ooff[ui] = (unsigned)((orow * a.Wo + oxs) * a.Cmid + c) * 4u;      // bytes
   }
   float* const obase = a.out + (((size_t)b * a.Ho + oy0) * a.Wo + ox0) * a.Cmid;
   const unsigned cm = (unsigned)a.Cmid;
-  // a tile that lies inside the output and whose slabs are whole takes the unguarded path (block-uniform decision)
-  const bool full = (oy0 + TH <= a.Ho) && (ox0 + TW <= a.Wo) && ((a.Cmid & 31) == 0);
+  // a tile that lies inside the output takes the unguarded path (block-uniform decision; the channel guard of a last,
+  // partial slab is one exec mask around the whole stage)
+  const bool full = (oy0 + TH <= a.Ho) && (ox0 + TW <= a.Wo);
 
   // Per-slab operands - packed expand weights (LDS image Bs), depthwise taps + BN scale / shift (LDS, one contiguous
   // host-packed block per slab), the two dropout scales (registers) - are requested while the PREVIOUS slab's expand
@@ -958,9 +684,17 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t][ks], bl[ks], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t][ks], bh[ks], acc, 0, 0, 0);
         }
-        float* ep = E + (size_t)(mt * 32 + 4 * lh) * ES + li;
+        if constexpr (ET) {
+          float* ep = E + li * CP + mt * 32 + 4 * lh;      // registers 4q .. 4q+3 = pixels 8q .. 8q+3 of this lane half
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swish_core(acc[r]);
+          for (int q = 0; q < 4; ++q)
+            *(float4*)(ep + 8 * q) = make_float4(swish_core(acc[4 * q]), swish_core(acc[4 * q + 1]), swish_core(acc[4 * q + 2]),
+                                                 swish_core(acc[4 * q + 3]));
+        } else {
+          float* ep = E + (size_t)(mt * 32 + 4 * lh) * ES + li;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swish_core(acc[r]);
+        }
       }
     }
     __syncthreads();
@@ -1010,8 +744,17 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
 #pragma unroll
         for (int ky = 0; ky < K; ++ky) {
           float rowv[NCOL];
+          if constexpr (ET) {
+            static_assert(!ET || NCOL % 4 == 0, "whole 16-byte reads");
 #pragma unroll
-          for (int j = 0; j < NCOL; ++j) rowv[j] = eu[(ky * IW + j) * ES];
+            for (int jj = 0; jj < NCOL / 4; ++jj) {
+              const float4 v = *(const float4*)(eu + ky * IW + 4 * jj);
+              rowv[4 * jj] = v.x; rowv[4 * jj + 1] = v.y; rowv[4 * jj + 2] = v.z; rowv[4 * jj + 3] = v.w;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) rowv[j] = eu[(ky * IW + j) * ES];
+          }
 #pragma unroll
           for (int kx = 0; kx < K; ++kx) {
 #pragma unroll
@@ -1033,8 +776,10 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    if (full) dw_units(std::false_type());
-    else if (dcol) dw_units(std::true_type());
+    if (dcol) {                  // (lane-varying only in a last, partial slab: Cmid = 144, 240)
+      if (full) dw_units(std::false_type());
+      else dw_units(std::true_type());
+    }
     if (a.se_partial) red[g * 32 + c] = ssum;
     __syncthreads();   // E may be rewritten; red[] of this slab and the next slab's operands (written after the first barrier) are complete
     if (a.se_partial && g == 0 && dcol) {
@@ -1066,7 +811,8 @@ static void launch_mbxb_t(const MbxArgs& a, int rows, hipStream_t s) {
   constexpr int TH = mbxb_cfg(K, S).th, TW = mbxb_cfg(K, S).tw;
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
   constexpr int NPP = (IH * IW + 31) / 32 * 32;
-  const size_t lds = ((size_t)NPP * 32 + 8 * 32 + 2 * (K * K + 2) * 32) * sizeof(float) + (size_t)KSF * 2 * 64 * sizeof(uint4);
+  const size_t lds = ((mbx_et(K, S) ? (size_t)32 * MBX_ET_PITCH : (size_t)NPP * 32) + 8 * 32 + 2 * (K * K + 2) * 32) * sizeof(float) +
+                     (size_t)KSF * 2 * 64 * sizeof(uint4);
   dim3 grid((a.Wo + TW - 1) / TW, (a.Ho + TH - 1) / TH, rows);
   MbxArgs b = a;
   static int remap = -1;
@@ -1124,6 +870,8 @@ __global__ __launch_bounds__(512, (KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a
   constexpr int NPP = 256;
   constexpr int NG = NW * 2;                  // depthwise thread groups (32 channels each)
   constexpr int ES = 33;
+  constexpr bool ET = mbx_et(K, 1);           // 5x5: E transposed, [channel][pixel] (see mbx_et); 32 * CP <= NPP * ES floats
+  constexpr int CP = MBX_ET_PITCH;
   constexpr int XW = (K == 3) ? 4 : 8;        // outputs per unit along x
   constexpr int UPR = TW / XW;                // units per output row
   constexpr int NUNIT = TH * UPR;             // 48 (3x3) / 16 (5x5) units over 16 groups
@@ -1193,7 +941,7 @@ __global__ __launch_bounds__(512, (KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a
   const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
   constexpr int B_PER = (BSLAB + 511) / 512;  // uint4 of the next slab per thread
   // loop-invariant addressing of the depthwise stage (see mbxb_kernel): E window offsets, output offsets relative to the
-  // block's uniform output base, and the block-uniform "whole tile, whole slabs" decision for the unguarded path
+  // block's uniform output base, and the block-uniform "whole tile" decision for the unguarded path
   constexpr int UPT = NUNIT / NG;
   static_assert(NUNIT % NG == 0, "units must tile the thread groups");
   int eoff[UPT];
@@ -1202,12 +950,12 @@ __global__ __launch_bounds__(512, (KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a
   for (int ui = 0; ui < UPT; ++ui) {
     const int u = g + NG * ui;
     const int orow = u / UPR, oxs = (u % UPR) * XW;
-    eoff[ui] = (orow * IW + oxs) * ES + c;
+    eoff[ui] = ET ? c * CP + orow * IW + oxs : (orow * IW + oxs) * ES + c;
     ooff[ui] = (unsigned)((orow * a.Wo + oxs) * a.Cmid + c) * 4u;      // bytes
   }
   float* const obase = a.out + (((size_t)b * a.Ho + oy0) * a.Wo + ox0) * a.Cmid;
   const unsigned cm = (unsigned)a.Cmid;
-  const bool full = (oy0 + TH <= a.Ho) && (ox0 + TW <= a.Wo) && ((a.Cmid & 31) == 0);
+  const bool full = (oy0 + TH <= a.Ho) && (ox0 + TW <= a.Wo);
 
   for (int ch = 0; ch < NCH; ++ch) {
     const int col = ch * 32 + c;
@@ -1247,9 +995,17 @@ __global__ __launch_bounds__(512, (KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh, acc, 0, 0, 0);
       }
-      float* ep = E + (size_t)(wave * 32 + 4 * lh) * ES + li;
+      if constexpr (ET) {
+        float* ep = E + li * CP + wave * 32 + 4 * lh;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swish_core(acc[r]);
+        for (int q = 0; q < 4; ++q)
+          *(float4*)(ep + 8 * q) = make_float4(swish_core(acc[4 * q]), swish_core(acc[4 * q + 1]), swish_core(acc[4 * q + 2]),
+                                               swish_core(acc[4 * q + 3]));
+      } else {
+        float* ep = E + (size_t)(wave * 32 + 4 * lh) * ES + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swish_core(acc[r]);
+      }
     }
     __syncthreads();
     // the next slab's operands are written to their LDS buffers HERE, ahead of this slab's output stores, so that no
@@ -1292,9 +1048,18 @@ __global__ __launch_bounds__(512, (KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a
 #pragma unroll KYU
         for (int ky = 0; ky < K; ++ky) {
           float rowv[NCOL];
-          const float* er = eu + ky * IW * ES;
+          if constexpr (ET) {
+            const float* er = eu + ky * IW;
 #pragma unroll
-          for (int j = 0; j < NCOL; ++j) rowv[j] = er[j * ES];
+            for (int jj = 0; jj < NCOL / 4; ++jj) {
+              const float4 v = *(const float4*)(er + 4 * jj);
+              rowv[4 * jj] = v.x; rowv[4 * jj + 1] = v.y; rowv[4 * jj + 2] = v.z; rowv[4 * jj + 3] = v.w;
+            }
+          } else {
+            const float* er = eu + ky * IW * ES;
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) rowv[j] = er[j * ES];
+          }
 #pragma unroll
           for (int kx = 0; kx < K; ++kx) {
             const float w = WK_LDS ? pcur[(ky * K + kx) * 32 + c] : wk[WK_LDS ? 0 : ky * K + kx];
@@ -1317,8 +1082,10 @@ __global__ __launch_bounds__(512, (KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    if (full) dw_units(std::false_type());
-    else if (dcol) dw_units(std::true_type());
+    if (dcol) {                  // (lane-varying only in a last, partial slab: Cmid = 144, 240)
+      if (full) dw_units(std::false_type());
+      else dw_units(std::true_type());
+    }
     if (a.se_partial) red[g * 32 + c] = ssum;
     __syncthreads();   // E may be rewritten; red[] and the next slab's operands (written after the first barrier) are complete
     if (a.se_partial && g == 0 && dcol) {
@@ -1348,6 +1115,8 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
   constexpr int NPP = 256;
   constexpr int NG = NW * 2;
   constexpr int ES = 33;
+  constexpr bool ET = mbx_et(K, 1);           // 5x5: E transposed, [channel][pixel] (see mbx_et); 32 * CP <= NPP * ES floats per buffer
+  constexpr int CP = MBX_ET_PITCH;
   constexpr int XW = (K == 3) ? 4 : 8;
   constexpr int UPR = TW / XW;
   constexpr int NUNIT = TH * UPR;
@@ -1425,12 +1194,26 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
   for (int ui = 0; ui < UPT; ++ui) {
     const int u = g + NG * ui;
     const int orow = u / UPR, oxs = (u % UPR) * XW;
-    eoff[ui] = (orow * IW + oxs) * ES + c;
+    eoff[ui] = ET ? c * CP + orow * IW + oxs : (orow * IW + oxs) * ES + c;
     ooff[ui] = (unsigned)((orow * a.Wo + oxs) * a.Cmid + c) * 4u;      // bytes
   }
   float* const obase = a.out + (((size_t)b * a.Ho + oy0) * a.Wo + ox0) * a.Cmid;
   const unsigned cm = (unsigned)a.Cmid;
-  const bool full = (oy0 + TH <= a.Ho) && (ox0 + TW <= a.Wo) && ((a.Cmid & 31) == 0);
+  const bool full = (oy0 + TH <= a.Ho) && (ox0 + TW <= a.Wo) && ((a.Cmid & 31) == 0);   // (Cin 192 / 208: whole slabs)
+  // activated accumulator -> E buffer (registers 4q .. 4q+3 of a lane = pixels 8q .. 8q+3 of its half of the slice)
+  auto e_store = [&](float* Eb, const f32x16& acc) {
+    if constexpr (ET) {
+      float* ep = Eb + li * CP + wave * 32 + 4 * lh;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(float4*)(ep + 8 * q) = make_float4(swish_core(acc[4 * q]), swish_core(acc[4 * q + 1]), swish_core(acc[4 * q + 2]),
+                                             swish_core(acc[4 * q + 3]));
+    } else {
+      float* ep = Eb + (size_t)(wave * 32 + 4 * lh) * ES + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swish_core(acc[r]);    // x (-ln 2) x dropout scale: after the depthwise
+    }
+  };
 
   // ---- slab 0: expand -> E[0] (nothing to overlap with yet)
   {
@@ -1445,9 +1228,7 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh, acc, 0, 0, 0);
     }
-    float* ep = E + (size_t)(wave * 32 + 4 * lh) * ES + li;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swish_core(acc[r]);    // x (-ln 2) x dropout scale: after the depthwise
+    e_store(E, acc);
   }
 
   for (int ch = 0; ch < NCH; ++ch) {
@@ -1508,13 +1289,22 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
     constexpr int FPM = (NF + MPS - 1) / MPS, RPM = (NCOL + MPS - 1) / MPS;
     auto e_row = [&](int st) -> const float* {
       const int ui = st / K, ky = st % K;
-      return Ec + eoff[ui] + ky * IW * ES;
+      return Ec + eoff[ui] + (ET ? ky * IW : ky * IW * ES);
     };
     float rowv[2][NCOL];
+    auto row_read4 = [&](float* dst, const float* er, int jj) {      // ET: pixels 4 jj .. 4 jj + 3 of a tap row, one ds_read_b128
+      const float4 v = *(const float4*)(er + 4 * jj);
+      dst[4 * jj] = v.x; dst[4 * jj + 1] = v.y; dst[4 * jj + 2] = v.z; dst[4 * jj + 3] = v.w;
+    };
     {
       const float* er = e_row(0);
+      if constexpr (ET) {
 #pragma unroll
-      for (int j = 0; j < NCOL; ++j) rowv[0][j] = er[j * ES];
+        for (int jj = 0; jj < NCOL / 4; ++jj) row_read4(rowv[0], er, jj);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) rowv[0][j] = er[j * ES];
+      }
     }
     bf16x8 bh_c = __builtin_bit_cast(bf16x8, bnext[lane]), bl_c = __builtin_bit_cast(bf16x8, bnext[64 + lane]);
     bf16x8 bh_n = bh_c, bl_n = bl_c;
@@ -1545,9 +1335,15 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
             dacc[ui][o] = fmaf(rowv[st & 1][o + kx], wk[ky * K + kx], dacc[ui][o]);
           }
         if (st + 1 < ROWS) {
+          if constexpr (ET) {      // the next tap row: NCOL / 4 wide reads, spread over the MFMA gaps of this step
+            constexpr int GAP = MPS / (NCOL / 4) > 0 ? MPS / (NCOL / 4) : 1;
+            if (m % GAP == 0 && m / GAP < NCOL / 4) row_read4(rowv[(st + 1) & 1], ern, m / GAP);
+            static_assert(!ET || (MPS >= NCOL / 4), "a gap per wide read");
+          } else {
 #pragma unroll
-          for (int r = m * RPM; r < (m + 1) * RPM; ++r)
-            if (r < NCOL) rowv[(st + 1) & 1][r] = ern[r * ES];
+            for (int r = m * RPM; r < (m + 1) * RPM; ++r)
+              if (r < NCOL) rowv[(st + 1) & 1][r] = ern[r * ES];
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1583,11 +1379,7 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
     else if (dcol) store_units(std::true_type());
     if (a.se_partial) red[((ch & 1) * NG + g) * 32 + c] = ssum;
     // ---- slab ch + 1: activate -> the other E buffer (its readers, depthwise ch - 1, finished before the barrier above)
-    if (more) {
-      float* ep = En + (size_t)(wave * 32 + 4 * lh) * ES + li;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2)) * ES] = swish_core(acc[r]);
-    }
+    if (more) e_store(En, acc);
     // ---- slab ch + 2 operands -> LDS: Bs[ch & 1] (its MFMAs were issued one iteration ago), par[(ch + 2) % 3]
     {
       uint4* bw = Bs + (size_t)(ch & 1) * BSLAB;

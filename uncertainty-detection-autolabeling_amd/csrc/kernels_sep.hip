@@ -1,0 +1,255 @@
+// Fused separable convolution on the bf16 matrix cores (split-precision products as in kernels_pwb.hip).
+#include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
+
+#include "mfma_common.h"
+
+namespace uda {
+
+// ---------------------------------------------------------------- fused separable convolution
+// SeparableConv2D of the BiFPN nodes and of the class / box heads (efficientdet_keras.py:207-227,421-446,
+// 584-626): depthwise 3x3 stride 1 (TF SAME, no bias / BN / activation) feeding the 1x1 convolution
+// (+ bias, BN, swish, MC-dropout keep-scale).  The depthwise result never goes to HBM: the block computes it
+// for its 8 x 16 pixel tile and all C channels on the VALU (3-row sliding window per thread, every input element
+// fetched once per block column), splits it into bf16 pieces and writes it straight into the LDS image the MFMA
+// stage reads as its A operand.  One barrier between the two stages; epilogue as in pwb_kernel.
+constexpr int SEP_TH = 8, SEP_TW = 16;
+
+template <int NT, int PARTS, int OCC>     // NT = 32-column tiles of the 1x1 output handled per block (each wave: all of them)
+__global__ __launch_bounds__(256, OCC) void sep_kernel(SepArgs a) {
+  constexpr int BM = SEP_TH * SEP_TW;      // 128 pixels = 4 MFMA row tiles, one per wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char slds[];
+  const int C = a.C, C4 = C >> 2;
+  const int KS = (C + 15) >> 4;            // MFMA k-steps
+  const int arow = KS * 32 + 16;           // bytes per A image row: KS * 16 bf16 + 16 pad (conflict-free ds_read_b128)
+  unsigned char* As = slds;                // [PARTS][BM][arow]
+  uint4* Bs = (uint4*)(slds + (size_t)PARTS * BM * arow);   // [KS][NT][PARTS][64 lanes] x 16 B
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, b_in = b / a.in_div;
+  const int tiles_x = (a.W + SEP_TW - 1) / SEP_TW;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int oy0 = ty * SEP_TH, ox0 = tx * SEP_TW;
+  const int nt0 = blockIdx.y * NT, n0 = nt0 * 32;
+  const int NTL = (a.Cout + 31) >> 5;
+
+  // ---- B: all k-steps of this block's column tiles, requested first (in flight during the depthwise stage)
+  const uint4* Wp = (const uint4*)a.wsplit;
+  const int b_total = KS * NT * PARTS * 64;
+  constexpr int B_MAX = 8;                 // uint4 per thread: K <= 128, NT <= 4, PARTS = 2 -> 8 * 4 * 2 * 64 / 256 = 16 (two rounds)
+  for (int f0 = tid; f0 < b_total; f0 += 256 * B_MAX) {
+    uint4 rb[B_MAX];
+#pragma unroll
+    for (int i = 0; i < B_MAX; ++i) {
+      const int f = f0 + 256 * i;
+      int q = f >> 6;
+      const int part = q % PARTS; q /= PARTS;
+      const int nt = q % NT, ks = q / NT;
+      rb[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (f < b_total && nt0 + nt < NTL) rb[i] = Wp[(((size_t)ks * NTL + (nt0 + nt)) * PARTS + part) * 64 + (f & 63)];
+    }
+#pragma unroll
+    for (int i = 0; i < B_MAX; ++i) {
+      const int f = f0 + 256 * i;
+      if (f < b_total) Bs[f] = rb[i];
+    }
+  }
+
+  // ---- depthwise 3x3: unit = (channel quad q, tile column x); 8 output rows with a 3-row register window
+  const float* inb = a.in + (size_t)b_in * a.H * a.W * C;
+  for (int u = tid; u < SEP_TW * C4; u += 256) {
+    const int q = u % C4, x = u / C4;
+    float4 wk[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wk[t] = *(const float4*)(a.wd + (size_t)t * C + 4 * q);
+    const int gx = ox0 + x;
+    // all (8 + 2) x 3 input quads of the unit are requested up front: 30 independent 16-byte loads in flight,
+    // one exposed memory latency per unit instead of one per output row
+    float4 win[SEP_TH + 2][3];
+#pragma unroll
+    for (int r = 0; r < SEP_TH + 2; ++r) {
+      const int iy = oy0 - 1 + r;
+      const bool rowok = iy >= 0 && iy < a.H;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int ix = gx - 1 + j;
+        win[r][j] = (rowok && ix >= 0 && ix < a.W) ? *(const float4*)(inb + ((size_t)iy * a.W + ix) * C + 4 * q)
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int ry = 0; ry < SEP_TH; ++ry) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const float4 v = win[ry + ky][kx];
+          const float4 w = wk[ky * 3 + kx];
+          acc.x = fmaf(v.x, w.x, acc.x);
+          acc.y = fmaf(v.y, w.y, acc.y);
+          acc.z = fmaf(v.z, w.z, acc.z);
+          acc.w = fmaf(v.w, w.w, acc.w);
+        }
+      // split into bf16 pieces -> A image row m = ry * 16 + x, channels 4q .. 4q + 3
+      const int m = ry * SEP_TW + x;
+      float r0 = acc.x, r1 = acc.y, r2 = acc.z, r3 = acc.w;
+#pragma unroll
+      for (int p = 0; p < PARTS; ++p) {
+        const unsigned u0 = pack_bf16(r0, r1), u1 = pack_bf16(r2, r3);
+        *(uint2*)(As + (size_t)(p * BM + m) * arow + q * 8) = make_uint2(u0, u1);
+        if (p + 1 < PARTS) {
+          r0 -= bf16_lo_f32(u0); r1 -= bf16_hi_f32(u0);
+          r2 -= bf16_lo_f32(u1); r3 -= bf16_hi_f32(u1);
+        }
+      }
+    }
+  }
+  // channels beyond C inside the last k-step (C % 16 == 8): zero them once
+  if (C & 15) {
+    for (int e = tid; e < PARTS * BM; e += 256) *(uint4*)(As + (size_t)e * arow + (C >> 3) * 16) = make_uint4(0u, 0u, 0u, 0u);
+  }
+  __syncthreads();
+
+  // ---- 1x1 on the matrix cores: wave w owns pixel rows [32 w, 32 w + 32) and all NT column tiles
+  f32x16 acc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+  for (int ks = 0; ks < KS; ++ks) {
+    bf16x8 af[PARTS];
+#pragma unroll
+    for (int p = 0; p < PARTS; ++p)
+      af[p] = *(const bf16x8*)(As + (size_t)(p * BM + wave * 32 + li) * arow + ks * 32 + lh * 16);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      bf16x8 bf[PARTS];
+#pragma unroll
+      for (int p = 0; p < PARTS; ++p) bf[p] = __builtin_bit_cast(bf16x8, Bs[((ks * NT + n) * PARTS + p) * 64 + lane]);
+      if constexpr (PARTS == 3) {
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[n], 0, 0, 0);
+      }
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[n], 0, 0, 0);
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[n], 0, 0, 0);
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[n], 0, 0, 0);
+    }
+  }
+  __syncthreads();      // the staging tile below aliases the A / B images
+
+  // tile row m -> output pixel
+  auto pixel_of = [&](int m, size_t& pix) -> bool {
+    const int y = oy0 + (m >> 4), x = ox0 + (m & 15);
+    pix = (size_t)y * a.W + x;
+    return y < a.H && x < a.W;
+  };
+  const size_t out_base = (size_t)b * a.H * a.W;
+
+  if ((a.Cout & 3) != 0) {
+    // scalar epilogue (class head: 9 * 7 = 63 channels)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int col = n0 + n * 32 + li;
+      if (col >= a.Cout) continue;
+      const float bias = a.bias ? a.bias[col] : 0.f;
+      const float sc = a.bn_scale ? a.bn_scale[col] : 1.f;
+      const float sh = a.bn_scale ? a.bn_shift[col] : 0.f;
+      const float mk = a.mask ? a.mask[(size_t)b * a.Cout + col] : 1.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        size_t pix;
+        if (!pixel_of(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, pix)) continue;
+        float v = fmaf(acc[n][r] + bias, sc, sh);
+        if (a.act == UDA_ACT_SWISH) v = swishf_b(v);
+        v *= mk;
+        a.out[(out_base + pix) * a.Cout + col] = v;
+      }
+    }
+    return;
+  }
+
+  float* stg = (float*)slds + wave * 32 * PWB_STG;
+  const int rrow = lane >> 4, c4 = lane & 15;
+#pragma unroll
+  for (int p = 0; p < (NT + 1) / 2; ++p) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int n = 2 * p + q;
+      if (n < NT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * PWB_STG + q * 32 + li] = acc[n][r];
+      }
+    }
+    __syncthreads();
+    const int col = n0 + 2 * p * 32 + 4 * c4;
+    const bool colok = (col < a.Cout) && (2 * p * 32 + 4 * c4 < NT * 32);
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 sh = make_float4(0.f, 0.f, 0.f, 0.f), mk = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (colok) {
+      if (a.bias) bias = *(const float4*)(a.bias + col);
+      if (a.bn_scale) {
+        sc = *(const float4*)(a.bn_scale + col);
+        sh = *(const float4*)(a.bn_shift + col);
+      }
+      if (a.mask) mk = *(const float4*)(a.mask + (size_t)b * a.Cout + col);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 4 + rrow;
+      size_t pix;
+      if (colok && pixel_of(wave * 32 + row, pix)) {
+        float4 v = *(const float4*)(stg + row * PWB_STG + 4 * c4);
+        v.x = fmaf(v.x + bias.x, sc.x, sh.x);
+        v.y = fmaf(v.y + bias.y, sc.y, sh.y);
+        v.z = fmaf(v.z + bias.z, sc.z, sh.z);
+        v.w = fmaf(v.w + bias.w, sc.w, sh.w);
+        if (a.act == UDA_ACT_SWISH) {
+          v.x = swishf_b(v.x); v.y = swishf_b(v.y); v.z = swishf_b(v.z); v.w = swishf_b(v.w);
+        }
+        v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
+        *(float4*)(a.out + (out_base + pix) * a.Cout + col) = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+bool sep_supported(int C, int Cout) { return C % 8 == 0 && C >= 16 && C <= 128 && Cout >= 1; }
+
+template <int NT>
+static void launch_sep_nt(const SepArgs& a, int rows, int gy, hipStream_t s) {
+  const int KS = (a.C + 15) / 16, arow = KS * 32 + 16;
+  size_t lds = (size_t)a.wparts * 128 * arow + (size_t)KS * NT * a.wparts * 1024;
+  const size_t stg = 4 * 32 * PWB_STG * 4;
+  if (lds < stg) lds = stg;
+  const dim3 grid(((a.W + SEP_TW - 1) / SEP_TW) * ((a.H + SEP_TH - 1) / SEP_TH), gy, rows);
+  auto go = [&](auto kern) {
+    static size_t attr_lds = 64 * 1024;
+    if (lds > attr_lds) {
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_lds = lds;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  };
+  static int occ = -1;
+  if (occ < 0) { const char* e = getenv("UDA_SEP_OCC"); occ = e ? atoi(e) : 3; }   // 3 blocks per CU: measured 14 % faster than 2
+  if (a.wparts == 3) go(sep_kernel<NT, 3, 2>);
+  else if (occ >= 3 && NT <= 2) go(sep_kernel<NT, 2, 3>);
+  else go(sep_kernel<NT, 2, 2>);
+}
+
+void launch_sep(const SepArgs& a, int rows, hipStream_t s) {
+  const int ntl = (a.Cout + 31) / 32;
+  // all columns in one block when they fit four 32-column tiles, else blocks of three
+  if (ntl == 1) launch_sep_nt<1>(a, rows, 1, s);
+  else if (ntl == 2) launch_sep_nt<2>(a, rows, 1, s);
+  else if (ntl == 3) launch_sep_nt<3>(a, rows, 1, s);
+  else if (ntl == 4) launch_sep_nt<4>(a, rows, 1, s);
+  else launch_sep_nt<3>(a, rows, (ntl + 2) / 3, s);
+}
+
+}  // namespace uda
