@@ -1754,7 +1754,7 @@ void launch_nms_reg(const NmsArgs& a, const float* scores, hipStream_t s) {
 // blocks of a problem exchange nothing else (everything else a block reads was written by itself or is read-only;
 // on a multi-XCD part a release / acquire pair writes back and invalidates the whole L2 - measured: every load
 // after a fenced barrier missed).  The spin is bounded: a time-out raises *err and every later step falls through.
-constexpr int COOP_MAX_BPI = 8;
+constexpr int COOP_MAX_BPI = 64;     // blocks per problem: one exchange slot per lane of the polling wave
 __device__ __forceinline__ unsigned long long coop_exchange(unsigned long long* slots, int blk, int bpi, unsigned long long mine,
                                                             RegLds& S, int* err, unsigned spin_max) {
   __syncthreads();                           // `mine` may come out of LDS traffic of the whole block
@@ -1773,7 +1773,7 @@ __device__ __forceinline__ unsigned long long coop_exchange(unsigned long long* 
     }
     if (v <= 1ull) v = 0ull;
 #pragma unroll
-    for (int off = 4; off > 0; off >>= 1) {  // bpi <= 8
+    for (int off = 32; off > 0; off >>= 1) {  // bpi <= 64
       const unsigned long long o = __shfl_xor(v, off, 64);
       v = o > v ? o : v;
     }
@@ -1819,7 +1819,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
   const int n = n0 + blockIdx.x / bpi, blk = blockIdx.x % bpi, tid = threadIdx.x;   // n0: first problem of this launch
   const size_t bbase = (size_t)n * a.K;           // one problem per image (segs == 1)
   const int i0 = blk * IPT * SOLO_T;
-  unsigned long long* slots = slots_all + (size_t)n * a.M * 2 * COOP_MAX_BPI;      // [epoch][bound | winner][block]
+  unsigned long long* slots = slots_all + (size_t)n * a.M * 2 * bpi;      // [epoch][bound | winner][block]
   float st[IPT];
 #pragma unroll
   for (int j = 0; j < IPT; ++j) {
@@ -1971,7 +1971,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
 #endif
     __syncthreads();
     const unsigned long long lk = S.L;       // this block's exact lower bound
-    const unsigned long long bd = coop_exchange(slots + (size_t)(2 * k) * COOP_MAX_BPI, blk, bpi, lk, S, err, spin_max);
+    const unsigned long long bd = coop_exchange(slots + (size_t)(2 * k) * bpi, blk, bpi, lk, S, err, spin_max);
 #ifdef UDA_NMS_STATS
     const unsigned long long t2 = wall_clock64();
 #endif
@@ -2001,7 +2001,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
 #ifdef UDA_NMS_STATS
     const unsigned long long t3 = wall_clock64();
 #endif
-    const unsigned long long wk = coop_exchange(slots + (size_t)(2 * k + 1) * COOP_MAX_BPI, blk, bpi, ke, S, err, spin_max);
+    const unsigned long long wk = coop_exchange(slots + (size_t)(2 * k + 1) * bpi, blk, bpi, ke, S, err, spin_max);
 #ifdef UDA_NMS_STATS
     const unsigned long long t4 = wall_clock64();
 #endif
@@ -2060,70 +2060,95 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
   if (blk == 0 && tid == 0) a.nsel[n] = nsel;
 }
 
-constexpr int COOP_IPT = 32;
-
-// blocks per problem, or 0 when the cooperative kernel cannot take these problems
-int nms_coop_blocks(const NmsArgs& a) {
-  if (a.segs != 1 || a.M > 128 || a.K < 1) return 0;
-  const int bpi = (a.K + COOP_IPT * SOLO_T - 1) / (COOP_IPT * SOLO_T);
-  return bpi <= COOP_MAX_BPI ? bpi : 0;
-}
-
-// 64-bit words of exchange slots per problem (the caller's scratch: n_img x this)
+// 64-bit words of exchange slots per problem (the caller's scratch: n_img x this; a launch uses M x 2 x its blocks per problem)
 size_t nms_coop_slot_words(int M) { return (size_t)M * 2 * COOP_MAX_BPI; }
 
-// false = not launched (grid not co-resident on this device, or the runtime refused): the caller uses the grid version
-bool launch_nms_coop(const NmsArgs& a, const float* scores, unsigned long long* slots, int* err, hipStream_t s) {
-  const int bpi = nms_coop_blocks(a);
-  if (bpi == 0 || a.n_img <= 0) return false;
-  constexpr size_t lds = (size_t)COOP_IPT * SOLO_T * sizeof(float) + (size_t)(COOP_LIST + COOP_HEAVY) * sizeof(int) +
-                         (size_t)COOP_IPT * 32 * sizeof(unsigned);
-  // co-resident blocks of this kernel per device (occupancy x CUs), one entry per HIP device of the process
-  static int capacity_of[64];
-  static bool capacity_known[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-  if (!capacity_known[dev]) {
-    int per_cu = 0;
+template <int IPT>
+constexpr size_t coop_lds_bytes() {
+  return (size_t)IPT * SOLO_T * sizeof(float) + (size_t)(COOP_LIST + COOP_HEAVY) * sizeof(int) + (size_t)IPT * 32 * sizeof(unsigned);
+}
+
+// co-resident blocks of nms_coop_kernel<IPT> on the current device (occupancy x CUs; 0 = cannot run), cached per HIP device
+template <int IPT>
+static int coop_capacity(int dev, int* n_cu) {
+  static int capacity_of[64], cus_of[64];
+  static bool known[64];
+  if (!known[dev]) {
+    int per_cu = 0, cap = 0;
     hipDeviceProp_t prop;
-    int cap = 0;
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.cooperativeLaunch &&
-        hipFuncSetAttribute((const void*)nms_coop_kernel<COOP_IPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nms_coop_kernel<COOP_IPT>, SOLO_T, lds) == hipSuccess)
-      cap = per_cu * prop.multiProcessorCount;
+    cus_of[dev] = 0;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.cooperativeLaunch) {
+      cus_of[dev] = prop.multiProcessorCount;
+      if (hipFuncSetAttribute((const void*)nms_coop_kernel<IPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_lds_bytes<IPT>()) == hipSuccess &&
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nms_coop_kernel<IPT>, SOLO_T, coop_lds_bytes<IPT>()) == hipSuccess)
+        cap = per_cu * prop.multiProcessorCount;
+    }
     (void)hipGetLastError();
     if (const char* e = getenv("UDA_NMS_COOP_CAP")) cap = atoi(e);     // test hook: a wrong capacity must end in the time-out path, not in a hang
     capacity_of[dev] = cap;
-    capacity_known[dev] = true;
+    known[dev] = true;
   }
-  const int capacity = capacity_of[dev];
+  *n_cu = cus_of[dev];
+  return capacity_of[dev];
+}
+
+template <int IPT>
+static void coop_launch(const NmsArgs& a, const float* scores, unsigned long long* slots, int* err, int bpi, int per, unsigned spin_max, hipStream_t s) {
+  for (int n0 = 0; n0 < a.n_img; n0 += per) {
+    const int cnt = a.n_img - n0 < per ? a.n_img - n0 : per;
+    hipLaunchKernelGGL((nms_coop_kernel<IPT>), dim3((unsigned)(bpi * cnt)), dim3(SOLO_T), coop_lds_bytes<IPT>(), s, a, scores, slots, err, bpi, n0, spin_max);
+  }
+}
+
+// false = not launched (grid not co-resident on this device, or the runtime refused): the caller uses the grid version
+bool launch_nms_coop(const NmsArgs& a, const float* scores, unsigned long long* slots, int* err, hipStream_t s) {
+  if (a.segs != 1 || a.M > 128 || a.K < 1 || a.n_img <= 0) return false;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  // Candidates per thread (IPT).  An epoch is latency-bound - three scans of the block's candidates, two grid-wide steps -
+  // so a small batch is spread over more, shorter blocks: the smallest IPT with which every block of the launch still has
+  // a CU to itself; a batch that fills the device anyway takes 32 (fewest blocks per problem, most problems per launch).
+  // UDA_NMS_COOP_IPT = 4 | 8 | 16 | 32 forces one.
+  static int force = -1;
+  if (force < 0) { const char* e = getenv("UDA_NMS_COOP_IPT"); force = e ? atoi(e) : 0; }
+  const int ipts[4] = {4, 8, 16, 32};
+  int ipt = 0, bpi = 0, capacity = 0;
+  for (int i = 0; i < 4 && !ipt; ++i) {
+    const int t = ipts[i];
+    if (force && t != force) continue;
+    const int b = (a.K + t * SOLO_T - 1) / (t * SOLO_T);
+    if (b > COOP_MAX_BPI) continue;
+    int n_cu = 0;
+    const int cap = t == 4 ? coop_capacity<4>(dev, &n_cu) : t == 8 ? coop_capacity<8>(dev, &n_cu) : t == 16 ? coop_capacity<16>(dev, &n_cu) : coop_capacity<32>(dev, &n_cu);
+    if (force || t == 32 || ((long long)a.n_img * b <= n_cu && b <= cap)) { ipt = t; bpi = b; capacity = cap; }
+  }
   // polls of an exchange slot before a block gives up (UDA_NMS_COOP_SPIN: debug knob, a tiny bound forces the time-out -> redo path)
   static long long spin_env = -1;
   if (spin_env < 0) { const char* e = getenv("UDA_NMS_COOP_SPIN"); spin_env = e ? atoll(e) : (1ll << 22); if (spin_env < 0) spin_env = 0; }
   const unsigned spin_max = (unsigned)(spin_env > 0xffffffffll ? 0xffffffffll : spin_env);
   static const bool dbg = getenv("UDA_NMS_DEBUG") != nullptr;
-  if (bpi > capacity) {
+  if (!ipt || bpi > capacity) {
     if (dbg) fprintf(stderr, "[uda] cooperative NMS: %d blocks per problem > capacity %d\n", bpi, capacity);
     return false;
   }
   const int per = capacity / bpi;          // problems per launch: more problems than the device holds run in consecutive grids
-  hipMemsetAsync(slots, 0, (size_t)a.n_img * nms_coop_slot_words(a.M) * sizeof(unsigned long long), s);
+  hipMemsetAsync(slots, 0, (size_t)a.n_img * a.M * 2 * bpi * sizeof(unsigned long long), s);
   hipMemsetAsync(a.sel_idx, 0, (size_t)a.n_img * a.M * sizeof(int32_t), s);
   hipMemsetAsync(a.sel_score, 0, (size_t)a.n_img * a.M * sizeof(float), s);
   // An ordinary launch: the grid fits the device (checked above against the occupancy of this kernel), so every block
   // becomes resident as soon as whatever else runs on the device drains - other kernels never wait for this one - and the
   // bounded spin is the safety net.  (hipLaunchCooperativeKernel gives the same placement plus a formal check, but
   // rocprofv3's kernel tracing crashes at process exit after a cooperative launch, ROCm 7.2.)
-  for (int n0 = 0; n0 < a.n_img; n0 += per) {
-    const int cnt = a.n_img - n0 < per ? a.n_img - n0 : per;
-    hipLaunchKernelGGL((nms_coop_kernel<COOP_IPT>), dim3((unsigned)(bpi * cnt)), dim3(SOLO_T), lds, s, a, scores, slots, err, bpi, n0, spin_max);
-  }
+  if (ipt == 4) coop_launch<4>(a, scores, slots, err, bpi, per, spin_max, s);
+  else if (ipt == 8) coop_launch<8>(a, scores, slots, err, bpi, per, spin_max, s);
+  else if (ipt == 16) coop_launch<16>(a, scores, slots, err, bpi, per, spin_max, s);
+  else coop_launch<32>(a, scores, slots, err, bpi, per, spin_max, s);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     if (dbg) fprintf(stderr, "[uda] cooperative NMS: launch refused: %s\n", hipGetErrorString(e));
     return false;
   }
-  if (dbg) fprintf(stderr, "[uda] cooperative NMS: %d problems x %d blocks (capacity %d)\n", a.n_img, bpi, capacity);
+  if (dbg) fprintf(stderr, "[uda] cooperative NMS: %d problems x %d blocks of %d candidates per thread (capacity %d)\n", a.n_img, bpi, ipt, capacity);
 #ifdef UDA_NMS_STATS
   {
     hipStreamSynchronize(s);

@@ -1018,7 +1018,7 @@ static bool run_nms(const NmsArgs& na, const float* scores, int M, hipStream_t s
     if (coop.used) *coop.used = true;
     return false;
   }
-  // ... else (more than 8 x 32768 candidates per problem, or a grid the device cannot hold): the single-launch kernel on
+  // ... else (more than 64 x 32768 candidates per problem, or a grid the device cannot hold): the single-launch kernel on
   // the candidates that can be popped at all (score prefix), checked on the device, full set - two launches per epoch -
   // only for the problems the check rejects.
   if (pw && pw->Lcap > 0 && na.segs == 1 && na.K > pw->Lcap && M <= 128) {

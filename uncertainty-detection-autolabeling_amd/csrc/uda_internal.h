@@ -281,7 +281,6 @@ bool nms_reg_supported(const NmsArgs& a);
 void launch_nms_reg(const NmsArgs& a, const float* scores, hipStream_t s);
 
 // all epochs of large problems in one launch of a co-resident grid; slots [n_img x nms_coop_slot_words(M)] / err [1] are scratch
-int nms_coop_blocks(const NmsArgs& a);
 size_t nms_coop_slot_words(int M);
 bool launch_nms_coop(const NmsArgs& a, const float* scores, unsigned long long* slots, int* err, hipStream_t s);
 
