@@ -352,11 +352,11 @@ static void launch_pwb_cfg(const PwArgs& a, int rows, hipStream_t s) {
   const dim3 grid((a.HW + BM - 1) / BM, (a.Cout + BN - 1) / BN, rows), block(256);
   // three blocks per CU (<= 168 registers): measured 10-20 % faster than the unconstrained allocation (2 per CU)
   if (a.wparts == 3) hipLaunchKernelGGL((pwb_kernel<MT, NT, WM, WN, 3, 2>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((pwb_kernel<MT, NT, WM, WN, 2, 3>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((pwb_kernel<MT, NT, WM, WN, 2, (MT * NT > 4 ? 2 : 3)>), grid, block, 0, s, a);   // (5-6 accumulator tiles per wave: 168 registers spill)
 }
 
-// tile = 128 pixels x {32, 64, 96, 128} channels (four waves stacked along the pixels for narrow outputs,
-// 2 x 2 waves of 64 x 64 for wide ones)
+// tile = 128 pixels x {32, 64, 96, 128, 160, 192} channels (four waves stacked along the pixels for narrow outputs and
+// for 160, 2 x 2 waves of 64 x 64 / 64 x 96 for 128 / 192)
 void launch_pwb(const PwArgs& a, int rows, hipStream_t s) {
   static int shared = -1;
   if (shared < 0) { const char* e = getenv("UDA_PW_SHARED"); shared = e ? atoi(e) : 1; }
@@ -367,12 +367,29 @@ void launch_pwb(const PwArgs& a, int rows, hipStream_t s) {
   }
   static int force = -1;
   if (force < 0) { const char* e = getenv("UDA_PWB_CFG"); force = e ? atoi(e) : 0; }
+  static int wide = -1;
+  if (wide < 0) { const char* e = getenv("UDA_PWB_WIDE"); wide = e ? atoi(e) : 1; }
   int cfg = force;
-  if (cfg == 0) cfg = a.Cout <= 32 ? 1 : (a.Cout <= 64 ? 2 : (a.Cout <= 96 ? 3 : 4));
+  if (cfg == 0) {
+    cfg = a.Cout <= 32 ? 1 : (a.Cout <= 64 ? 2 : (a.Cout <= 96 ? 3 : 4));
+    if (wide && a.Cout > 128) {
+      // wide outputs: the column tile (128 / 160 / 192) that leaves the fewest idle columns in the last column block, the
+      // wider one on a tie - 192 channels: one block of 192 instead of 128 + 64 (a quarter of the MFMAs idle, the input
+      // tile read and split twice); 320: 2 x 160; 672: 4 x 192 instead of 6 x 128
+      const int bn[3] = {128, 160, 192}, id[3] = {4, 6, 5};
+      int best = 1 << 30;
+      for (int i = 0; i < 3; ++i) {
+        const int waste = (a.Cout + bn[i] - 1) / bn[i] * bn[i] - a.Cout;
+        if (waste <= best) { best = waste; cfg = id[i]; }
+      }
+    }
+  }
   switch (cfg) {
     case 1: launch_pwb_cfg<1, 1, 4, 1>(a, rows, s); break;
     case 2: launch_pwb_cfg<1, 2, 4, 1>(a, rows, s); break;
     case 3: launch_pwb_cfg<1, 3, 4, 1>(a, rows, s); break;
+    case 5: launch_pwb_cfg<2, 3, 2, 2>(a, rows, s); break;
+    case 6: launch_pwb_cfg<1, 5, 4, 1>(a, rows, s); break;
     default: launch_pwb_cfg<2, 2, 2, 2>(a, rows, s); break;
   }
 }
