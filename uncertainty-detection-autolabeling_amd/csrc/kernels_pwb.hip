@@ -423,9 +423,13 @@ __host__ __device__ constexpr bool mbx_et(int k, int s) { return UDA_MBX_ET && k
 namespace {
 struct MbxCfgB { int th, tw; };
 __host__ __device__ constexpr MbxCfgB mbxb_cfg(int k, int s) {
-  // input tile (with halo) = 8 slices of 32 pixels, two per wave: 3x3 s1 12x16 (14x18 = 252), 3x3 s2 4x12
-  // (9x25 = 225), 5x5 s2 4x10 (11x23 = 253), 5x5 s1 8x16 (12x20 = 240)
-  return s == 1 ? (k == 3 ? MbxCfgB{12, 16} : MbxCfgB{8, 16}) : (k == 3 ? MbxCfgB{4, 12} : MbxCfgB{4, 10});
+  // input tile (with halo) = 8 slices of 32 pixels, two per wave: 3x3 s1 12x16 (14x18 = 252), 3x3 s2 7x8
+  // (15x17 = 255: 224 of the 256 expanded pixels belong to the tile proper; 4x12 -> 9x25 = 225 had 192), 5x5 s2 4x10
+  // (11x23 = 253), 5x5 s1 8x16 (12x20 = 240)
+#ifndef UDA_MBXB_S2_TILE
+#define UDA_MBXB_S2_TILE 78
+#endif
+  return s == 1 ? (k == 3 ? MbxCfgB{12, 16} : MbxCfgB{8, 16}) : (k == 3 ? (UDA_MBXB_S2_TILE == 78 ? MbxCfgB{7, 8} : MbxCfgB{4, 12}) : MbxCfgB{4, 10});
 }
 }  // namespace
 
@@ -462,10 +466,10 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
   constexpr bool ET = mbx_et(K, S);
   constexpr int CP = MBX_ET_PITCH;
   // depthwise units: XW consecutive outputs of one row; NUNIT units over the NG thread groups
-  constexpr int XW = (S == 1) ? 8 : (K == 3 ? 6 : 5);
+  constexpr int XW = (S == 1) ? 8 : (K == 3 ? (TW == 8 ? 8 : 6) : 5);
   constexpr int UPR = TW / XW;                // units per output row
-  constexpr int NUNIT = TH * UPR;             // 24 (3x3 s1), 16 (5x5 s1), 8 (stride 2)
-  static_assert(TW % XW == 0 && NUNIT % NG == 0, "units must tile the output tile and the thread groups");
+  constexpr int NUNIT = TH * UPR;             // 24 (3x3 s1), 16 (5x5 s1), 8 (5x5 s2), 7 (3x3 s2: the eighth thread group idles)
+  static_assert(TW % XW == 0, "units must tile the output tile");
   constexpr int NCOL = (XW - 1) * S + K;
   extern __shared__ __attribute__((aligned(16))) float mlds[];
   float* E = mlds;                            // [NPP][ES]  (ET: [32][CP])
@@ -598,12 +602,13 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
   // orow starting at column oxs.  eoff = float offset of the unit's E window (tap rows / columns are compile-time
   // displacements), ooff = element offset of the unit's first output relative to the block's output base, which is
   // UNIFORM (scalar registers): the stores use a scalar base + a 32-bit lane offset, no 64-bit vector arithmetic.
-  constexpr int UPT = NUNIT / NG;
+  constexpr int UPT = (NUNIT + NG - 1) / NG;
+  constexpr bool UNIT_GUARD = (NUNIT % NG) != 0;      // the last round of units does not fill the thread groups
   int eoff[UPT];
   unsigned ooff[UPT];
 #pragma unroll
   for (int ui = 0; ui < UPT; ++ui) {
-    const int u = g + NG * ui;
+    const int u = (UNIT_GUARD && g + NG * ui >= NUNIT) ? 0 : g + NG * ui;
     const int orow = u / UPR, oxs = (u % UPR) * XW;
     eoff[ui] = ET ? c * CP + (orow * S) * IW + oxs * S : ((orow * S) * IW + oxs * S) * ES + c;
     ooff[ui] = (unsigned)((orow * a.Wo + oxs) * a.Cmid + c) * 4u;      // bytes
@@ -751,6 +756,9 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
       constexpr bool GUARD = decltype(guard)::value;
 #pragma unroll
       for (int ui = 0; ui < UPT; ++ui) {
+        if constexpr (UNIT_GUARD) {
+          if (g + NG * ui >= NUNIT) continue;
+        }
         if constexpr (GUARD) {
           if (oy0 + (g + NG * ui) / UPR >= a.Ho) continue;
         }

@@ -61,7 +61,8 @@ def mbx_tile(k, stride, cin=16):
     import os
     if int(os.environ.get("UDA_PW_TERMS", "3")) == 0 or not int(os.environ.get("UDA_MBX_BF16", "1")):
         return (8, 16) if stride == 1 else ((4, 16) if k == 3 else (4, 8))      # f32-MFMA fallback kernel (mbx_cfg)
-    return ((12, 16) if k == 3 else (8, 16)) if stride == 1 else ((4, 12) if k == 3 else (4, 10))
+    s2_k3 = (7, 8) if os.environ.get("UDA_MBXB_S2_TILE", "78") == "78" else (4, 12)     # (A/B builds: -DUDA_MBXB_S2_TILE=412)
+    return ((12, 16) if k == 3 else (8, 16)) if stride == 1 else (s2_k3 if k == 3 else (4, 10))
 
 
 def mbx_tiles(Ho, Wo, k, stride, cin=16):
