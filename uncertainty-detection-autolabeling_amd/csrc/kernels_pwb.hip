@@ -448,8 +448,13 @@ __host__ __device__ constexpr MbxCfgB mbxb_cfg(int k, int s) {
 // Wider inputs (3 or 4 k-steps: 48-64 registers of operand fragments per wave) do not reach that occupancy either way
 // and keep the weight fragments of the current and the next slab in registers (measured: the LDS image costs them 6-9 %,
 // its reads sit on the critical path right behind the slab barrier).
+// 5x5 with 3 k-steps (block 4: 40 -> 240): the 25 depthwise taps are read from LDS at their use and the tap-row loop is not
+// unrolled (as in mbxd_kernel), which brings the kernel under 168 registers = three blocks per CU instead of two.
+#ifndef UDA_MBXB_WK_LDS
+#define UDA_MBXB_WK_LDS 1
+#endif
 #ifndef UDA_MBXB_MINW
-#define UDA_MBXB_MINW(K, S, KSF) ((KSF) <= 2 ? ((K) == 3 ? 4 : 3) : (((K) == 3 && (S) == 2 && (KSF) <= 3) ? 3 : 2))
+#define UDA_MBXB_MINW(K, S, KSF) ((KSF) <= 2 ? ((K) == 3 ? 4 : 3) : (((KSF) <= 3 && ((K) == 3 ? (S) == 2 : UDA_MBXB_WK_LDS)) ? 3 : 2))
 #endif
 template <int K, int S, int KSF, bool FUSE0>   // KSF = 16-deep MFMA k-steps covering Cin + 1
 __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(MbxArgs a) {
@@ -745,15 +750,19 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
       asm volatile("" : "+v"(mk0n), "+v"(mk1n));
     }
     // ---- depthwise on E for channel 32 ch + c
-    float wk[K * K];
+    constexpr bool WK_LDS = UDA_MBXB_WK_LDS && K == 5 && KSF == 3;
+    float wk[WK_LDS ? 1 : K * K];
+    if constexpr (!WK_LDS) {
 #pragma unroll
-    for (int t = 0; t < K * K; ++t) wk[t] = pcur[t * 32 + c];
+      for (int t = 0; t < K * K; ++t) wk[t] = pcur[t * 32 + c];
+    }
     // BN scale x (-ln 2) x expand-side dropout scale of this channel (see swish_core)
     const float sc1 = pcur[K * K * 32 + c] * mk0, sh1 = pcur[(K * K + 1) * 32 + c];
     float ssum = 0.f;
     float* const ob = obase + ch * 32;            // uniform
     auto dw_units = [&](auto guard) {
       constexpr bool GUARD = decltype(guard)::value;
+      constexpr int KYU = (UDA_MBXB_WK_LDS && K == 5 && KSF == 3) ? 1 : K;      // (an unrolled tap-row loop hoists the tap reads back into registers)
 #pragma unroll
       for (int ui = 0; ui < UPT; ++ui) {
         if constexpr (UNIT_GUARD) {
@@ -766,7 +775,7 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
 #pragma unroll
         for (int o = 0; o < XW; ++o) acc[o] = 0.f;
         const float* eu = E + eoff[ui];
-#pragma unroll
+#pragma unroll KYU
         for (int ky = 0; ky < K; ++ky) {
           float rowv[NCOL];
           if constexpr (ET) {
@@ -782,8 +791,9 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
           }
 #pragma unroll
           for (int kx = 0; kx < K; ++kx) {
+            const float w = WK_LDS ? pcur[(ky * K + kx) * 32 + c] : wk[WK_LDS ? 0 : ky * K + kx];
 #pragma unroll
-            for (int o = 0; o < XW; ++o) acc[o] = fmaf(rowv[o * S + kx], wk[ky * K + kx], acc[o]);
+            for (int o = 0; o < XW; ++o) acc[o] = fmaf(rowv[o * S + kx], w, acc[o]);
           }
         }
 #pragma unroll
