@@ -2108,18 +2108,19 @@ bool launch_nms_coop(const NmsArgs& a, const float* scores, unsigned long long* 
   // Candidates per thread (IPT).  An epoch is latency-bound - three scans of the block's candidates, two grid-wide steps -
   // so a small batch is spread over more, shorter blocks: the smallest IPT with which every block of the launch still has
   // a CU to itself; a batch that fills the device anyway takes 32 (fewest blocks per problem, most problems per launch).
-  // UDA_NMS_COOP_IPT = 4 | 8 | 16 | 32 forces one.
+  // UDA_NMS_COOP_IPT = 4 | 8 | 16 | 24 | 32 forces one.
   static int force = -1;
   if (force < 0) { const char* e = getenv("UDA_NMS_COOP_IPT"); force = e ? atoi(e) : 0; }
-  const int ipts[4] = {4, 8, 16, 32};
+  const int ipts[5] = {4, 8, 16, 24, 32};
   int ipt = 0, bpi = 0, capacity = 0;
-  for (int i = 0; i < 4 && !ipt; ++i) {
+  for (int i = 0; i < 5 && !ipt; ++i) {
     const int t = ipts[i];
     if (force && t != force) continue;
     const int b = (a.K + t * SOLO_T - 1) / (t * SOLO_T);
     if (b > COOP_MAX_BPI) continue;
     int n_cu = 0;
-    const int cap = t == 4 ? coop_capacity<4>(dev, &n_cu) : t == 8 ? coop_capacity<8>(dev, &n_cu) : t == 16 ? coop_capacity<16>(dev, &n_cu) : coop_capacity<32>(dev, &n_cu);
+    const int cap = t == 4 ? coop_capacity<4>(dev, &n_cu) : t == 8 ? coop_capacity<8>(dev, &n_cu) : t == 16 ? coop_capacity<16>(dev, &n_cu)
+                  : t == 24 ? coop_capacity<24>(dev, &n_cu) : coop_capacity<32>(dev, &n_cu);
     if (force || t == 32 || ((long long)a.n_img * b <= n_cu && b <= cap)) { ipt = t; bpi = b; capacity = cap; }
   }
   // polls of an exchange slot before a block gives up (UDA_NMS_COOP_SPIN: debug knob, a tiny bound forces the time-out -> redo path)
@@ -2142,6 +2143,7 @@ bool launch_nms_coop(const NmsArgs& a, const float* scores, unsigned long long* 
   if (ipt == 4) coop_launch<4>(a, scores, slots, err, bpi, per, spin_max, s);
   else if (ipt == 8) coop_launch<8>(a, scores, slots, err, bpi, per, spin_max, s);
   else if (ipt == 16) coop_launch<16>(a, scores, slots, err, bpi, per, spin_max, s);
+  else if (ipt == 24) coop_launch<24>(a, scores, slots, err, bpi, per, spin_max, s);
   else coop_launch<32>(a, scores, slots, err, bpi, per, spin_max, s);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
