@@ -896,7 +896,7 @@ void launch_mbxb(const MbxArgs& a, int rows, int k, int stride, hipStream_t s) {
 template <int K, int KSF>
 __global__ __launch_bounds__(512, (KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a) {
   constexpr bool WK_LDS = (K == 5 && KSF <= 8);
-  constexpr int KY_UNROLL = WK_LDS ? 1 : K;     // (a fully unrolled tap loop hoists all 25 LDS tap reads back into registers)
+
   constexpr int NW = 8;
   constexpr int TH = (K == 3) ? 12 : 8, TW = 16;
   constexpr int IH = TH + K - 1, IW = TW + K - 1;
@@ -1079,7 +1079,7 @@ __global__ __launch_bounds__(512, (KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a
 #pragma unroll
         for (int o = 0; o < XW; ++o) acc[o] = 0.f;
         const float* eu = E + eoff[ui];
-        constexpr int KYU = (K == 5 && KSF <= 8) ? 1 : K;     // = KY_UNROLL (a pragma inside the lambda cannot name the enclosing local)
+        constexpr int KYU = (K == 5 && KSF <= 8) ? 1 : K;     // (a fully unrolled tap-row loop hoists all 25 LDS tap reads back into registers)
 #pragma unroll KYU
         for (int ky = 0; ky < K; ++ky) {
           float rowv[NCOL];
