@@ -408,17 +408,48 @@ void launch_pwb(const PwArgs& a, int rows, hipStream_t s) {
 //        sliding window along x, writes the output tile (128-byte channel segments) and the SE tile sums.
 // Two barriers per 32-channel slab (E complete / E free); the SE reduction rides on the second one.
 // E transposed (5x5 stride 1, every fused MBConv variant): the 32-channel slab is kept [channel][pixel] with a channel pitch
-// of MBX_ET_PITCH floats instead of [pixel][channel].  The accumulator of the expand MFMA holds 4 x 4 CONSECUTIVE pixels of
+// of 260 floats instead of [pixel][channel].  The accumulator of the expand MFMA holds 4 x 4 CONSECUTIVE pixels of
 // one channel per lane and the input tile is 20 pixels wide, so a group of 4 never straddles a tile row: the activation is
 // stored with 4 ds_write_b128 instead of 16 ds_write_b32, and the depthwise stage reads the 12-pixel window of a tap row with
 // 3 ds_read_b128 instead of 12 ds_read_b32 - half the LDS-array cycles (256 instead of 128 B/clk) and a quarter of the LDS
 // instructions of the phase that bounds the deep 5x5 blocks.  Pitch 260 = 4 x 65 (odd): the 16 lanes of a ds_read_b128 group
 // (16 different channels) land on 16 different 16-byte slots of the bank row, and the 8 lanes of a ds_write_b128 group on 8.
-constexpr int MBX_ET_PITCH = 260;
+// 3x3 stride 1 (18-pixel-wide tile: a tap row starts at an even, not always a fourth, pixel) does the same with 8-byte accesses
+// and pitch 258 = 2 x 129: 8 ds_write_b64 per slice, 3-5 ds_read_b64 per tap row, conflict-free (lane stride 2 banks).
 #ifndef UDA_MBX_ET
-#define UDA_MBX_ET 1
+#define UDA_MBX_ET 3      // bit 0: 5x5 stride 1 (16-byte accesses), bit 1: 3x3 stride 1 (8-byte accesses)
 #endif
-__host__ __device__ constexpr bool mbx_et(int k, int s) { return UDA_MBX_ET && k == 5 && s == 1; }
+// floats per LDS access of the transposed slab: 4, 2, or 0 = slab not transposed
+__host__ __device__ constexpr int mbx_et_w(int k, int s) {
+  return s != 1 ? 0 : (k == 5 ? ((UDA_MBX_ET & 1) ? 4 : 0) : ((UDA_MBX_ET & 2) ? 2 : 0));
+}
+__host__ __device__ constexpr int mbx_et_pitch(int w) { return w == 2 ? 258 : 260; }
+// activated accumulator of one 32-pixel slice -> transposed slab; ep = E + channel * pitch + slice * 32 + 4 * lane half
+// (registers 4q .. 4q+3 of a lane = pixels 8q .. 8q+3 of its half of the slice)
+template <int W>
+__device__ __forceinline__ void et_store_slice(float* ep, const f32x16& acc) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float v0 = swish_core(acc[4 * q]), v1 = swish_core(acc[4 * q + 1]), v2 = swish_core(acc[4 * q + 2]), v3 = swish_core(acc[4 * q + 3]);
+    if constexpr (W == 4) {
+      *(float4*)(ep + 8 * q) = make_float4(v0, v1, v2, v3);
+    } else {
+      *(float2*)(ep + 8 * q) = make_float2(v0, v1);
+      *(float2*)(ep + 8 * q + 2) = make_float2(v2, v3);
+    }
+  }
+}
+// access jj (W floats) of a tap row of the transposed slab
+template <int W>
+__device__ __forceinline__ void et_read(float* dst, const float* er, int jj) {
+  if constexpr (W == 4) {
+    const float4 v = *(const float4*)(er + 4 * jj);
+    dst[4 * jj] = v.x; dst[4 * jj + 1] = v.y; dst[4 * jj + 2] = v.z; dst[4 * jj + 3] = v.w;
+  } else {
+    const float2 v = *(const float2*)(er + 2 * jj);
+    dst[2 * jj] = v.x; dst[2 * jj + 1] = v.y;
+  }
+}
 
 namespace {
 struct MbxCfgB { int th, tw; };
@@ -467,9 +498,10 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
   constexpr int NG = NW * 2;                  // depthwise thread groups (32 channels each)
   constexpr int MTW = (NMT + NW - 1) / NW;    // pixel slices per wave
   constexpr int ES = 32;
-  // 5x5 stride 1: E is kept TRANSPOSED, [channel][pixel] with a channel pitch of CP floats (see mbx_et above)
-  constexpr bool ET = mbx_et(K, S);
-  constexpr int CP = MBX_ET_PITCH;
+  // stride 1: E is kept TRANSPOSED, [channel][pixel] with a channel pitch of CP floats (see mbx_et_w above)
+  constexpr int ETW = mbx_et_w(K, S);
+  constexpr bool ET = ETW != 0;
+  constexpr int CP = mbx_et_pitch(ETW);
   // depthwise units: XW consecutive outputs of one row; NUNIT units over the NG thread groups
   constexpr int XW = (S == 1) ? 8 : (K == 3 ? (TW == 8 ? 8 : 6) : 5);
   constexpr int UPR = TW / XW;                // units per output row
@@ -712,11 +744,7 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t][ks], bh[ks], acc, 0, 0, 0);
         }
         if constexpr (ET) {
-          float* ep = E + li * CP + mt * 32 + 4 * lh;      // registers 4q .. 4q+3 = pixels 8q .. 8q+3 of this lane half
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            *(float4*)(ep + 8 * q) = make_float4(swish_core(acc[4 * q]), swish_core(acc[4 * q + 1]), swish_core(acc[4 * q + 2]),
-                                                 swish_core(acc[4 * q + 3]));
+          et_store_slice<ETW>(E + li * CP + mt * 32 + 4 * lh, acc);
         } else {
           float* ep = E + (size_t)(mt * 32 + 4 * lh) * ES + li;
 #pragma unroll
@@ -779,12 +807,9 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
         for (int ky = 0; ky < K; ++ky) {
           float rowv[NCOL];
           if constexpr (ET) {
-            static_assert(!ET || NCOL % 4 == 0, "whole 16-byte reads");
+            static_assert(!ET || NCOL % ETW == 0, "whole 16- / 8-byte reads");
 #pragma unroll
-            for (int jj = 0; jj < NCOL / 4; ++jj) {
-              const float4 v = *(const float4*)(eu + ky * IW + 4 * jj);
-              rowv[4 * jj] = v.x; rowv[4 * jj + 1] = v.y; rowv[4 * jj + 2] = v.z; rowv[4 * jj + 3] = v.w;
-            }
+            for (int jj = 0; jj < NCOL / (ET ? ETW : 1); ++jj) et_read<ETW>(rowv, eu + ky * IW, jj);
           } else {
 #pragma unroll
             for (int j = 0; j < NCOL; ++j) rowv[j] = eu[(ky * IW + j) * ES];
@@ -846,7 +871,7 @@ static void launch_mbxb_t(const MbxArgs& a, int rows, hipStream_t s) {
   constexpr int TH = mbxb_cfg(K, S).th, TW = mbxb_cfg(K, S).tw;
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
   constexpr int NPP = (IH * IW + 31) / 32 * 32;
-  const size_t lds = ((mbx_et(K, S) ? (size_t)32 * MBX_ET_PITCH : (size_t)NPP * 32) + 8 * 32 + 2 * (K * K + 2) * 32) * sizeof(float) +
+  const size_t lds = ((mbx_et_w(K, S) ? (size_t)32 * mbx_et_pitch(mbx_et_w(K, S)) : (size_t)NPP * 32) + 8 * 32 + 2 * (K * K + 2) * 32) * sizeof(float) +
                      (size_t)KSF * 2 * 64 * sizeof(uint4);
   dim3 grid((a.Wo + TW - 1) / TW, (a.Ho + TH - 1) / TH, rows);
   MbxArgs b = a;
@@ -905,8 +930,9 @@ __global__ __launch_bounds__(512, (KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a
   constexpr int NPP = 256;
   constexpr int NG = NW * 2;                  // depthwise thread groups (32 channels each)
   constexpr int ES = 33;
-  constexpr bool ET = mbx_et(K, 1);           // 5x5: E transposed, [channel][pixel] (see mbx_et); 32 * CP <= NPP * ES floats
-  constexpr int CP = MBX_ET_PITCH;
+  constexpr int ETW = mbx_et_w(K, 1);         // E transposed, [channel][pixel] (see mbx_et_w); 32 * CP <= NPP * ES floats
+  constexpr bool ET = ETW != 0;
+  constexpr int CP = mbx_et_pitch(ETW);
   constexpr int XW = (K == 3) ? 4 : 8;        // outputs per unit along x
   constexpr int UPR = TW / XW;                // units per output row
   constexpr int NUNIT = TH * UPR;             // 48 (3x3) / 16 (5x5) units over 16 groups
@@ -1031,11 +1057,7 @@ __global__ __launch_bounds__(512, (KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh, acc, 0, 0, 0);
       }
       if constexpr (ET) {
-        float* ep = E + li * CP + wave * 32 + 4 * lh;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *(float4*)(ep + 8 * q) = make_float4(swish_core(acc[4 * q]), swish_core(acc[4 * q + 1]), swish_core(acc[4 * q + 2]),
-                                               swish_core(acc[4 * q + 3]));
+        et_store_slice<ETW>(E + li * CP + wave * 32 + 4 * lh, acc);
       } else {
         float* ep = E + (size_t)(wave * 32 + 4 * lh) * ES + li;
 #pragma unroll
@@ -1084,12 +1106,9 @@ __global__ __launch_bounds__(512, (KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a
         for (int ky = 0; ky < K; ++ky) {
           float rowv[NCOL];
           if constexpr (ET) {
-            const float* er = eu + ky * IW;
+            static_assert(!ET || NCOL % ETW == 0, "whole 16- / 8-byte reads");
 #pragma unroll
-            for (int jj = 0; jj < NCOL / 4; ++jj) {
-              const float4 v = *(const float4*)(er + 4 * jj);
-              rowv[4 * jj] = v.x; rowv[4 * jj + 1] = v.y; rowv[4 * jj + 2] = v.z; rowv[4 * jj + 3] = v.w;
-            }
+            for (int jj = 0; jj < NCOL / (ET ? ETW : 1); ++jj) et_read<ETW>(rowv, eu + ky * IW, jj);
           } else {
             const float* er = eu + ky * IW * ES;
 #pragma unroll
@@ -1150,8 +1169,9 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
   constexpr int NPP = 256;
   constexpr int NG = NW * 2;
   constexpr int ES = 33;
-  constexpr bool ET = mbx_et(K, 1);           // 5x5: E transposed, [channel][pixel] (see mbx_et); 32 * CP <= NPP * ES floats per buffer
-  constexpr int CP = MBX_ET_PITCH;
+  constexpr int ETW = mbx_et_w(K, 1);         // E transposed, [channel][pixel] (see mbx_et_w); 32 * CP <= NPP * ES floats per buffer
+  constexpr bool ET = ETW != 0;
+  constexpr int CP = mbx_et_pitch(ETW);
   constexpr int XW = (K == 3) ? 4 : 8;
   constexpr int UPR = TW / XW;
   constexpr int NUNIT = TH * UPR;
@@ -1238,11 +1258,7 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
   // activated accumulator -> E buffer (registers 4q .. 4q+3 of a lane = pixels 8q .. 8q+3 of its half of the slice)
   auto e_store = [&](float* Eb, const f32x16& acc) {
     if constexpr (ET) {
-      float* ep = Eb + li * CP + wave * 32 + 4 * lh;
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *(float4*)(ep + 8 * q) = make_float4(swish_core(acc[4 * q]), swish_core(acc[4 * q + 1]), swish_core(acc[4 * q + 2]),
-                                             swish_core(acc[4 * q + 3]));
+      et_store_slice<ETW>(Eb + li * CP + wave * 32 + 4 * lh, acc);
     } else {
       float* ep = Eb + (size_t)(wave * 32 + 4 * lh) * ES + li;
 #pragma unroll
@@ -1327,15 +1343,13 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
       return Ec + eoff[ui] + (ET ? ky * IW : ky * IW * ES);
     };
     float rowv[2][NCOL];
-    auto row_read4 = [&](float* dst, const float* er, int jj) {      // ET: pixels 4 jj .. 4 jj + 3 of a tap row, one ds_read_b128
-      const float4 v = *(const float4*)(er + 4 * jj);
-      dst[4 * jj] = v.x; dst[4 * jj + 1] = v.y; dst[4 * jj + 2] = v.z; dst[4 * jj + 3] = v.w;
-    };
+    constexpr int NRD = ET ? NCOL / (ET ? ETW : 1) : 1;      // wide reads per tap row of the transposed slab
+    static_assert(!ET || NCOL % (ET ? ETW : 1) == 0, "whole 16- / 8-byte reads");
     {
       const float* er = e_row(0);
       if constexpr (ET) {
 #pragma unroll
-        for (int jj = 0; jj < NCOL / 4; ++jj) row_read4(rowv[0], er, jj);
+        for (int jj = 0; jj < NRD; ++jj) et_read<ETW>(rowv[0], er, jj);
       } else {
 #pragma unroll
         for (int j = 0; j < NCOL; ++j) rowv[0][j] = er[j * ES];
@@ -1370,10 +1384,10 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
             dacc[ui][o] = fmaf(rowv[st & 1][o + kx], wk[ky * K + kx], dacc[ui][o]);
           }
         if (st + 1 < ROWS) {
-          if constexpr (ET) {      // the next tap row: NCOL / 4 wide reads, spread over the MFMA gaps of this step
-            constexpr int GAP = MPS / (NCOL / 4) > 0 ? MPS / (NCOL / 4) : 1;
-            if (m % GAP == 0 && m / GAP < NCOL / 4) row_read4(rowv[(st + 1) & 1], ern, m / GAP);
-            static_assert(!ET || (MPS >= NCOL / 4), "a gap per wide read");
+          if constexpr (ET) {      // the next tap row: NRD wide reads, spread over the MFMA gaps of this step
+            constexpr int GAP = MPS / NRD > 0 ? MPS / NRD : 1;
+            if (m % GAP == 0 && m / GAP < NRD) et_read<ETW>(rowv[(st + 1) & 1], ern, m / GAP);
+            static_assert(!ET || (MPS >= NRD), "a gap per wide read");
           } else {
 #pragma unroll
             for (int r = m * RPM; r < (m + 1) * RPM; ++r)
