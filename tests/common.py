@@ -37,3 +37,32 @@ def make_weights(params, seed=1, cls_spread=1.0):
 
 def make_images(n, h, w, seed=0):
     return np.random.default_rng(seed).integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+
+
+def oracle_heads(p, w, x, seed, t_real=4):
+    """Head outputs of the CPU oracle network for the post-process tests: (class outputs, box outputs) per level.
+    With more than `t_real` MC samples only `t_real` go through the (slow) oracle network; the other sample rows are
+    derived from them (row t = row t % t_real plus a seeded float32 perturbation).  Those tests compare the post-process
+    on GIVEN head outputs bit for bit, so the extra rows only have to look like head outputs."""
+    from oracle import effdet_ref as E, philox_ref as R
+    sites = E.dropout_sites(p)
+    T = int(p["mc_dropoutsamp"]) if p["mc_dropout"] else 1
+    if not sites or T <= t_real:
+        masks = R.make_masks(sites, seed, x.shape[0], T) if sites else None
+        return E.forward(w, p, x, masks)
+    q = dict(p, mc_dropoutsamp=t_real)
+    cls, box = E.forward(w, q, x, R.make_masks(sites, seed, x.shape[0], t_real))
+    rng = np.random.default_rng([seed, T])
+
+    def widen(levels, stacked):
+        if not stacked:
+            return levels
+        out = []
+        for a in levels:
+            rows = [a[t % t_real] if t < t_real else
+                    (a[t % t_real] * np.float32(1.0 + 0.03 * rng.standard_normal()) +
+                     rng.normal(0.0, 0.05, a.shape[1:]).astype(np.float32)).astype(np.float32) for t in range(T)]
+            out.append(np.stack(rows, 0))
+        return out
+    return (widen(cls, bool(p["mc_classheadrate"] or p["mc_dropoutrate"])),
+            widen(box, bool(p["mc_boxheadrate"] or p["mc_dropoutrate"])))

@@ -29,12 +29,10 @@ def _driver(params, w, batch, **kw):
 
 
 def _oracle_heads(p, w, imgs, hw, seed):
-    from oracle import effdet_ref as E, philox_ref as R, preprocess_ref as PP
+    from oracle import preprocess_ref as PP
+    from common import oracle_heads
     x, scales = PP.preprocess(imgs, hw, p["mean_rgb"], p["stddev_rgb"])
-    sites = E.dropout_sites(p)
-    T = p["mc_dropoutsamp"] if p["mc_dropout"] else 1
-    masks = R.make_masks(sites, seed, x.shape[0], T) if sites else None
-    rcls, rbox = E.forward(w, p, x, masks)
+    rcls, rbox = oracle_heads(p, w, x, seed)       # (more than 4 MC samples: 4 real network passes, the rest derived)
     return rcls, rbox, scales
 
 
@@ -69,9 +67,9 @@ AGG_WORKER = r"""
 import sys
 sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
 import numpy as np
-from common import FULL_MC, MC_NO_ATT, make_images, make_params, make_weights
+from common import FULL_MC, MC_NO_ATT, make_images, make_params, make_weights, oracle_heads
 from uda_amd.infer_lib import KerasDriver, ServingDriver
-from oracle import effdet_ref as E, philox_ref as R, post_ref as P, preprocess_ref as PP
+from oracle import post_ref as P, preprocess_ref as PP
 for over, spread in ((dict(FULL_MC, mc_dropoutsamp=10), 1.0), (dict(FULL_MC, mc_dropoutsamp=20, num_classes=10), 1.0),
                      (dict(FULL_MC, mc_dropoutsamp=10), 20.0), (dict(MC_NO_ATT, mc_dropoutsamp=10), 20.0),
                      (dict(FULL_MC, mc_dropoutsamp=30), 1.0), (dict(FULL_MC, mc_dropoutsamp=10, num_classes=10), 20.0),
@@ -79,8 +77,7 @@ for over, spread in ((dict(FULL_MC, mc_dropoutsamp=10), 1.0), (dict(FULL_MC, mc_
     p = make_params(**over)
     w = make_weights(p, seed=11, cls_spread=spread)
     x, scales = PP.preprocess(make_images(2, 100, 180, seed=12), (128, 192), p["mean_rgb"], p["stddev_rgb"])
-    masks = R.make_masks(E.dropout_sites(p), 21, 2, p["mc_dropoutsamp"])
-    rcls, rbox = E.forward(w, p, x, masks)
+    rcls, rbox = oracle_heads(p, w, x, 21)
     want = P.postprocess_global(p, rcls, rbox, scales)
     d = KerasDriver("_", False, p["name"], batch_size=2, model_params=p, weights=w)
     got = d.postprocess(rcls, rbox, scales)

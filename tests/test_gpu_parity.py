@@ -274,7 +274,8 @@ def test_postprocess_bit_exact_on_oracle_heads(name, over):
     p = make_params(**over)
     w = make_weights(p, seed=11, cls_spread=20.0 if name in ("plain", "full_mc") else 1.0)
     x, scales = PP.preprocess(make_images(2, 100, 180, seed=12), (128, 192), p["mean_rgb"], p["stddev_rgb"])
-    (rcls, rbox), _ = _oracle_net(p, w, x, 21)
+    from common import oracle_heads
+    rcls, rbox = oracle_heads(p, w, x, 21)         # (T = 10 / 20: 4 real network passes, the other sample rows derived)
     want = P.postprocess_global(p, rcls, rbox, scales)
     d = _driver(p, w, 2)
     got = d.postprocess(rcls, rbox, scales)
