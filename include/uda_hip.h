@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define UDA_ABI_VERSION 2
+#define UDA_ABI_VERSION 3
 #define UDA_MAX_LEVELS 8
 #define UDA_MAX_FUSE_INPUTS 3
 
@@ -89,6 +89,11 @@ typedef struct uda_op {
   int32_t drop_site2;              /* MBX: dropout site after the depthwise stage (drop_site = after the expand stage) */
   int64_t w2_off;                  /* MBX: depthwise kernel [k*k][Cmid]; SEP: depthwise kernel [9][C] */
   int64_t bn2_scale_off, bn2_shift_off; /* MBX: BN after the depthwise stage */
+  int32_t launch_group;            /* SEP: n > 1 on the first of n consecutive, mutually independent ops of one shape class
+                                      (same channels, activation, sample axes) that may share ONE launch - the pyramid levels
+                                      of a head layer; the planner keeps every buffer they touch alive to the end of the run.
+                                      0 / 1 elsewhere. */
+  int32_t reserved0;
 } uda_op_t;
 
 /* ---- MC dropout sites -------------------------------------------------------------------- */

@@ -35,7 +35,7 @@ def pmc_per_op(path, counter, scale):
     ix = [i for i, r in enumerate(rr) if "preprocess" in r["Kernel_Name"]]
     rr = rr[ix[-1]:]
     cv = [r for r in rr if any(n in r["Kernel_Name"] for n in names)]
-    return [float(r["Counter_Value"]) * 1024 * scale for r in cv[:len(pl.ops)]]
+    return [float(r["Counter_Value"]) * 1024 * scale for r in cv[:len(units)]]
 
 
 rows = list(csv.DictReader(open(a.trace)))
@@ -43,15 +43,30 @@ names = ("stem_kernel", "stem16_kernel", "pw_kernel", "pwb_kernel", "pwb_shared_
 idx = [i for i, r in enumerate(rows) if "preprocess" in r["Kernel_Name"]]
 rows = rows[idx[-1]:]
 conv = [r for r in rows if any(n in r["Kernel_Name"] for n in names)]
-nops = len(pl.ops)
+# launch units: one op, or the ops of a head layer that share a launch (launch_group, plan.py)
+units, i = [], 0
+while i < len(pl.ops):
+    n = max(1, pl.ops[i].get("launch_group", 0))
+    units.append(pl.ops[i:i + n])
+    i += n
+nops = len(units)
 assert len(conv) % nops == 0, (len(conv), nops)
 first = conv[:nops]                       # first chunk of the last step
 T = pl.T
 res = []
-for o, r in zip(pl.ops, first):
+size = lambda bi: a.chunk * (T if pl.bufs[bi].per_sample else 1) * pl.bufs[bi].H * pl.bufs[bi].W * pl.bufs[bi].C
+for unit, r in zip(units, first):
     dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    if len(unit) > 1:                     # separable convs of one layer on all pyramid levels
+        by = sum(size(o["out"]) + size(o["ins"][0]) for o in unit)
+        fl = sum(2 * a.chunk * (T if pl.bufs[o["out"]].per_sample else 1) * pl.bufs[o["out"]].H * pl.bufs[o["out"]].W *
+                 (9 * pl.bufs[o["ins"][0]].C + pl.bufs[o["ins"][0]].C * pl.bufs[o["out"]].C) for o in unit)
+        ob = pl.bufs[unit[0]["out"]]
+        desc = "sep %d->%d x%d levels" % (pl.bufs[unit[0]["ins"][0]].C, ob.C, len(unit))
+        res.append((dur, desc, ob.name.rsplit("-", 1)[0], by * 4, fl, r["Kernel_Name"].split("(")[0][-16:], r["VGPR_Count"]))
+        continue
+    o = unit[0]
     ob = pl.bufs[o["out"]]
-    size = lambda bi: a.chunk * (T if pl.bufs[bi].per_sample else 1) * pl.bufs[bi].H * pl.bufs[bi].W * pl.bufs[bi].C
     by = size(o["out"]) + sum(size(i) for i in (o["ins"][:1] if o["kind"] == capi.OP_SE else o["ins"]))
     for k in ("se_scale", "residual", "se_partial"):
         if o[k] >= 0 and o["kind"] != capi.OP_SE:
@@ -81,7 +96,7 @@ write = pmc_per_op(a.write, "WRITE_SIZE", 1.0) if a.write else None
 if fetch or write:
     res = [r + ((fetch[i] if fetch else 0.0) + (write[i] if write else 0.0),) for i, r in enumerate(res)]
 tot = sum(r[0] for r in res)
-print("chunk of %d images: %d ops, %.2f ms kernel time" % (a.chunk, nops, tot / 1e3))
+print("chunk of %d images: %d ops in %d launches, %.2f ms kernel time" % (a.chunk, len(pl.ops), nops, tot / 1e3))
 for kind in ("pw", "dw", "mbx", "sep", "se", "fuse", "stem", "pool"):
     sel = [r for r in res if r[1].split()[0] == kind]
     if sel:

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("UDA_LIB") or os.path.join(CSRC, "libuda_hip.so")   # UDA_LIB: an alternative build for A/B runs
 HEADER = os.path.join(os.path.dirname(HERE), "include", "uda_hip.h")
 
-UDA_ABI_VERSION = 2
+UDA_ABI_VERSION = 3
 MAX_LEVELS = 8
 MAX_FUSE = 3
 
@@ -42,7 +42,8 @@ class Op(C.Structure):
                 ("se_w2_off", C.c_int64), ("se_b2_off", C.c_int64), ("se_mid", C.c_int32),
                 ("drop_site", C.c_int32), ("resample", C.c_int32 * MAX_FUSE),
                 ("fuse_w", C.c_float * MAX_FUSE), ("n_in", C.c_int32), ("drop_site2", C.c_int32),
-                ("w2_off", C.c_int64), ("bn2_scale_off", C.c_int64), ("bn2_shift_off", C.c_int64)]
+                ("w2_off", C.c_int64), ("bn2_scale_off", C.c_int64), ("bn2_shift_off", C.c_int64),
+                ("launch_group", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class DropSite(C.Structure):

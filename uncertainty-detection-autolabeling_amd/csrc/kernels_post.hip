@@ -2074,19 +2074,40 @@ static int coop_capacity(int dev, int* n_cu) {
   static int capacity_of[64], cus_of[64];
   static bool known[64];
   if (!known[dev]) {
-    int per_cu = 0, cap = 0;
-    hipDeviceProp_t prop;
-    cus_of[dev] = 0;
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.cooperativeLaunch) {
-      cus_of[dev] = prop.multiProcessorCount;
-      if (hipFuncSetAttribute((const void*)nms_coop_kernel<IPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_lds_bytes<IPT>()) == hipSuccess &&
-          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nms_coop_kernel<IPT>, SOLO_T, coop_lds_bytes<IPT>()) == hipSuccess)
-        cap = per_cu * prop.multiProcessorCount;
+    (void)hipGetLastError();          // an error left behind by an unrelated earlier call must not be read as ours
+    // Blocks of this kernel a CU holds, from the kernel's own resources: 16 waves of <= 128 registers (launch bounds) are one
+    // block per CU by registers, two below 65; LDS and the 2048-thread limit likewise.  (Not
+    // hipOccupancyMaxActiveBlocksPerMultiprocessor: on ROCm 7.2 it answered 0 for this kernel - same registers, same LDS -
+    // depending on which other kernels the process had run before, and 1 otherwise.)
+    int per_cu = 0, cap = 0, n_cus = 0, coop = 0, lds_cu = 0;
+    const hipError_t e0 = hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const hipError_t e1 = hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev);
+    if (hipDeviceGetAttribute(&lds_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess) lds_cu = 0;
+    hipError_t e2 = hipSuccess, e3 = hipSuccess;
+    hipFuncAttributes fa{};
+    cus_of[dev] = e0 == hipSuccess ? n_cus : 0;
+    if (e0 == hipSuccess && e1 == hipSuccess && coop) {
+      e2 = hipFuncSetAttribute((const void*)nms_coop_kernel<IPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_lds_bytes<IPT>());
+      if (e2 == hipSuccess) e3 = hipFuncGetAttributes(&fa, (const void*)nms_coop_kernel<IPT>);
+      if (e2 == hipSuccess && e3 == hipSuccess && fa.numRegs > 0 && fa.numRegs <= 128 && fa.maxThreadsPerBlock >= SOLO_T) {
+        const size_t lds = fa.sharedSizeBytes + coop_lds_bytes<IPT>();       // the launch was accepted above: one block fits
+        const int by_regs = (512 / ((fa.numRegs + 7) / 8 * 8)) * 4 / (SOLO_T / 64);
+        const int by_lds = (size_t)lds_cu >= lds ? (int)((size_t)lds_cu / lds) : 1;
+        per_cu = by_regs < by_lds ? by_regs : by_lds;
+        if (per_cu > 2048 / SOLO_T) per_cu = 2048 / SOLO_T;
+        if (per_cu < 1) per_cu = 1;
+        cap = per_cu * n_cus;
+      }
     }
     (void)hipGetLastError();
-    if (const char* e = getenv("UDA_NMS_COOP_CAP")) cap = atoi(e);     // test hook: a wrong capacity must end in the time-out path, not in a hang
+    if (getenv("UDA_NMS_DEBUG"))
+      fprintf(stderr, "[uda] cooperative NMS capacity<%d> on device %d: %d CUs (%d B LDS each), cooperative %d, %d registers, %zu + %zu B LDS -> %d blocks per CU "
+              "(%s / %s / %s / %s)\n", IPT, dev, n_cus, lds_cu, coop, fa.numRegs, fa.sharedSizeBytes, coop_lds_bytes<IPT>(), per_cu,
+              hipGetErrorName(e0), hipGetErrorName(e1), hipGetErrorName(e2), hipGetErrorName(e3));
+    const char* hook = getenv("UDA_NMS_COOP_CAP");     // test hook: a wrong capacity must end in the time-out path, not in a hang
+    if (hook) cap = atoi(hook);
     capacity_of[dev] = cap;
-    known[dev] = true;
+    known[dev] = cap > 0 || hook != nullptr;          // a failed query is asked again next time
   }
   *n_cu = cus_of[dev];
   return capacity_of[dev];

@@ -18,8 +18,20 @@ namespace uda {
 constexpr int SEP_TH = 8, SEP_TW = 16;
 
 template <int NT, int PARTS, int OCC>     // NT = 32-column tiles of the 1x1 output handled per block (each wave: all of them)
-__global__ __launch_bounds__(256, OCC) void sep_kernel(SepArgs a) {
+__global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
   constexpr int BM = SEP_TH * SEP_TW;      // 128 pixels = 4 MFMA row tiles, one per wave
+  // the problem of this block (uniform): one conv, or one of the pyramid levels of a head layer launched together
+  SepArgs a = m.one;
+  int bx = blockIdx.x;
+  if (m.n_lv > 0) {
+    int l = 0;
+    while (l + 1 < m.n_lv && bx >= m.tile0[l + 1]) ++l;
+    bx -= m.tile0[l];
+    const SepLevel& L = m.lv[l];
+    a.in = L.in; a.out = L.out; a.wd = L.wd; a.wsplit = L.wsplit;
+    a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift; a.mask = L.mask;
+    a.H = L.H; a.W = L.W;
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned char slds[];
   const int C = a.C, C4 = C >> 2;
   const int KS = (C + 15) >> 4;            // MFMA k-steps
@@ -30,7 +42,7 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepArgs a) {
   const int li = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, b_in = b / a.in_div;
   const int tiles_x = (a.W + SEP_TW - 1) / SEP_TW;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
   const int oy0 = ty * SEP_TH, ox0 = tx * SEP_TW;
   const int nt0 = blockIdx.y * NT, n0 = nt0 * 32;
   const int NTL = (a.Cout + 31) >> 5;
@@ -220,20 +232,23 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepArgs a) {
 
 bool sep_supported(int C, int Cout) { return C % 8 == 0 && C >= 16 && C <= 128 && Cout >= 1; }
 
+static int sep_tiles(int H, int W) { return ((W + SEP_TW - 1) / SEP_TW) * ((H + SEP_TH - 1) / SEP_TH); }
+
 template <int NT>
-static void launch_sep_nt(const SepArgs& a, int rows, int gy, hipStream_t s) {
+static void launch_sep_nt(const SepMulti& m, int rows, int gy, hipStream_t s) {
+  const SepArgs& a = m.one;
   const int KS = (a.C + 15) / 16, arow = KS * 32 + 16;
   size_t lds = (size_t)a.wparts * 128 * arow + (size_t)KS * NT * a.wparts * 1024;
   const size_t stg = 4 * 32 * PWB_STG * 4;
   if (lds < stg) lds = stg;
-  const dim3 grid(((a.W + SEP_TW - 1) / SEP_TW) * ((a.H + SEP_TH - 1) / SEP_TH), gy, rows);
+  const dim3 grid(m.n_lv > 0 ? m.tile0[m.n_lv] : sep_tiles(a.H, a.W), gy, rows);
   auto go = [&](auto kern) {
     static size_t attr_lds = 64 * 1024;
     if (lds > attr_lds) {
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_lds = lds;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, m);
   };
   static int occ = -1;
   if (occ < 0) { const char* e = getenv("UDA_SEP_OCC"); occ = e ? atoi(e) : 3; }   // 3 blocks per CU: measured 14 % faster than 2
@@ -242,14 +257,35 @@ static void launch_sep_nt(const SepArgs& a, int rows, int gy, hipStream_t s) {
   else go(sep_kernel<NT, 2, 2>);
 }
 
-void launch_sep(const SepArgs& a, int rows, hipStream_t s) {
-  const int ntl = (a.Cout + 31) / 32;
+static void launch_sep_any(const SepMulti& m, int rows, hipStream_t s) {
+  const int ntl = (m.one.Cout + 31) / 32;
   // all columns in one block when they fit four 32-column tiles, else blocks of three
-  if (ntl == 1) launch_sep_nt<1>(a, rows, 1, s);
-  else if (ntl == 2) launch_sep_nt<2>(a, rows, 1, s);
-  else if (ntl == 3) launch_sep_nt<3>(a, rows, 1, s);
-  else if (ntl == 4) launch_sep_nt<4>(a, rows, 1, s);
-  else launch_sep_nt<3>(a, rows, (ntl + 2) / 3, s);
+  if (ntl == 1) launch_sep_nt<1>(m, rows, 1, s);
+  else if (ntl == 2) launch_sep_nt<2>(m, rows, 1, s);
+  else if (ntl == 3) launch_sep_nt<3>(m, rows, 1, s);
+  else if (ntl == 4) launch_sep_nt<4>(m, rows, 1, s);
+  else launch_sep_nt<3>(m, rows, (ntl + 2) / 3, s);
+}
+
+void launch_sep(const SepArgs& a, int rows, hipStream_t s) {
+  SepMulti m{};
+  m.one = a;
+  m.n_lv = 0;
+  launch_sep_any(m, rows, s);
+}
+
+void launch_sep_multi(const SepArgs& common, const SepLevel* lv, int n_lv, int rows, hipStream_t s) {
+  SepMulti m{};
+  m.one = common;
+  m.n_lv = n_lv;
+  int t = 0;
+  for (int i = 0; i < n_lv; ++i) {
+    m.lv[i] = lv[i];
+    m.tile0[i] = t;
+    t += sep_tiles(lv[i].H, lv[i].W);
+  }
+  m.tile0[n_lv] = t;
+  launch_sep_any(m, rows, s);
 }
 
 }  // namespace uda

@@ -913,6 +913,46 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
   return 0;
 }
 
+// ops[oi .. oi + n): the separable convs of one head layer on all pyramid levels (uda_op_t.launch_group) as ONE launch.
+// Returns -1 when the run does not qualify (the caller then executes the ops one by one), 0 on success, > 0 on failure.
+static int run_sep_group(uda_ctx* c, const ChunkView& v, int oi, int n) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("UDA_SEP_MULTI"); on = e ? atoi(e) : 1; }
+  if (!on || n < 2 || n > UDA_SEP_MAX_LV || oi + n > (int)c->ops.size()) return -1;
+  const uda_op_t& o0 = c->ops[oi];
+  const uda_buf_desc_t& ib0 = c->bufs[o0.in[0]];
+  const uda_buf_desc_t& ob0 = c->bufs[o0.out];
+  SepLevel lv[UDA_SEP_MAX_LV];
+  for (int j = 0; j < n; ++j) {
+    const uda_op_t& o = c->ops[oi + j];
+    if (o.kind != UDA_OP_SEP || c->wsplit_off[oi + j] < 0) return -1;
+    const uda_buf_desc_t& ib = c->bufs[o.in[0]];
+    const uda_buf_desc_t& ob = c->bufs[o.out];
+    if (ib.C != ib0.C || ob.C != ob0.C || o.act != o0.act || ib.per_sample != ib0.per_sample || ob.per_sample != ob0.per_sample ||
+        ib.H != ob.H || ib.W != ob.W)
+      return -1;
+    for (int k = 0; k < n; ++k)
+      if (k != j && (c->ops[oi + k].out == o.in[0] || c->ops[oi + k].out == o.out)) return -1;    // not independent
+    lv[j].in = v.ptr(o.in[0]);
+    lv[j].out = v.ptr(o.out);
+    lv[j].wd = v.wt(o.w2_off);
+    lv[j].wsplit = c->d_wsplit + c->wsplit_off[oi + j];
+    lv[j].bias = v.wt(o.bias_off);
+    lv[j].bn_scale = v.wt(o.bn_scale_off);
+    lv[j].bn_shift = v.wt(o.bn_shift_off);
+    lv[j].mask = v.mask(o.drop_site);
+    lv[j].H = ob.H; lv[j].W = ob.W;
+  }
+  ProfScope ps(c, UDA_OP_SEP, v.stream());
+  SepArgs a{};
+  a.C = ib0.C; a.Cout = ob0.C;
+  a.in_div = v.div(ib0, ob0);
+  a.act = o0.act;
+  a.wparts = c->pw_parts;
+  launch_sep_multi(a, lv, n, v.rows(ob0), v.stream());
+  return 0;
+}
+
 static int run_post_range(uda_ctx* c, int i0, int n, int post_mode, hipStream_t st);
 
 static int run_network(uda_ctx* c, int post_mode = 0, bool chunk_post = false) {
@@ -955,6 +995,12 @@ static int run_network(uda_ctx* c, int post_mode = 0, bool chunk_post = false) {
     ChunkView v{c, i0, (n - i0 < m.chunk_images) ? n - i0 : m.chunk_images};
     v.lane = ci % lanes;
     for (int oi = 0; oi < (int)c->ops.size(); ++oi) {
+      const int grp = c->ops[oi].launch_group;
+      if (grp > 1) {
+        const int rg = run_sep_group(c, v, oi, grp);
+        if (rg > 0) return rg;
+        if (rg == 0) { oi += grp - 1; continue; }
+      }
       const int rc = run_op(c, v, oi);
       if (rc) return rc;
     }

@@ -98,6 +98,22 @@ struct SepArgs {          // fused depthwise 3x3 (stride 1, SAME) + 1x1 (kernels
   int wparts;
 };
 void launch_sep(const SepArgs& a, int rows, hipStream_t s);
+// Several independent separable convs of ONE shape class (same C, Cout, activation, sample-axis relation, row count) in one
+// launch: the five pyramid levels of a head layer.  The grid covers the tiles of all problems; a block finds its problem
+// from the tile prefix sums.  Everything that differs between the problems lives in SepLevel.
+constexpr int UDA_SEP_MAX_LV = 8;
+struct SepLevel {
+  const float* in; float* out; const float* wd; const void* wsplit;
+  const float* bias; const float* bn_scale; const float* bn_shift; const float* mask;
+  int H, W;
+};
+struct SepMulti {
+  SepArgs one;                         // the single problem (n_lv == 0) / the fields shared by all problems
+  int n_lv;
+  int tile0[UDA_SEP_MAX_LV + 1];       // first tile of every problem, total in [n_lv]
+  SepLevel lv[UDA_SEP_MAX_LV];
+};
+void launch_sep_multi(const SepArgs& common, const SepLevel* lv, int n_lv, int rows, hipStream_t s);
 bool sep_supported(int C, int Cout);
 
 struct DwArgs {

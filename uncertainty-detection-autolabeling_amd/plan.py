@@ -193,7 +193,7 @@ class Plan:
                  stride=1, act=capi.ACT_NONE, w_off=-1, bias_off=-1, bn_scale_off=-1, bn_shift_off=-1,
                  se_w1_off=-1, se_b1_off=-1, se_w2_off=-1, se_b2_off=-1, se_mid=0, drop_site=-1,
                  resample=[0, 0, 0], fuse_w=[0.0, 0.0, 0.0], drop_site2=-1, w2_off=-1, bn2_scale_off=-1,
-                 bn2_shift_off=-1)
+                 bn2_shift_off=-1, launch_group=0)
         o.update(kw)
         self.ops.append(o)
         return out
@@ -246,6 +246,28 @@ class Plan:
         if bn is not None:
             kw["bn_scale_off"], kw["bn_shift_off"] = self._bn(bn)
         return self._op(capi.OP_SEP, [x], out, **kw)
+
+    def _mark_launch_group(self, first):
+        """ops[first:] were just emitted for the pyramid levels of one head layer.  If they are fused separable convs of one
+        shape class (same channels, activation, sample axes) and mutually independent, the first one is marked with their
+        count: the executor may run them as one launch.  _plan_memory keeps every buffer the run touches alive to its end
+        (concurrent problems must not reuse each other's freed inputs)."""
+        import os
+        run = self.ops[first:]
+        if len(run) < 2 or len(run) > 8 or not int(os.environ.get("UDA_SEP_MULTI", "1")):
+            return
+        if any(o["kind"] != capi.OP_SEP for o in run):
+            return
+
+        def shape_class(o):
+            ib, ob = self.bufs[o["ins"][0]], self.bufs[o["out"]]
+            return (ib.C, ob.C, o["act"], ib.per_sample, ob.per_sample)
+        if len({shape_class(o) for o in run}) != 1:
+            return
+        outs = {o["out"] for o in run}
+        if any(o["ins"][0] in outs for o in run) or len(outs) != len(run):
+            return
+        run[0]["launch_group"] = len(run)
 
     def _resample(self, x, th, tw, prefix, name):
         """ResampleFeatureMap.call: optional 1x1+BN to F channels, then (mode for the consumer)."""
@@ -410,19 +432,28 @@ class Plan:
         cls_ch = A * cfg["num_classes"]
         box_ch = A * (8 if cfg["loss_attenuation"] else 4)
         self.head_out = {"class": [], "box": []}
+        # Layer-major: a head layer is emitted for all pyramid levels before the next layer (the reference loops level-major,
+        # efficientdet_keras.py:470-486; the levels are independent, so the order is free).  The ops of one layer are
+        # consecutive and of one shape class: the executor runs them as ONE launch (launch_group), which spares the
+        # small levels their launch latency and lets them run in the shadow of the large ones.
         for net, tag, outc, kind in (("class_net", "class", cls_ch, 2), ("box_net", "box", box_ch, 3)):
-            for li, f in enumerate(feats):
-                x = f
-                for i in range(cfg["box_class_repeats"]):
-                    pre = "%s/%s-%d" % (net, tag, i)
-                    x = self._sepconv(x, F, pre + "/depthwise_kernel", pre + "/pointwise_kernel",
-                                      "%s-%d-%d" % (tag, i, lo + li), bias=pre + "/bias",
-                                      bn="%s/%s-%d-bn-%d" % (net, tag, i, lo + li), act=capi.ACT_SWISH,
-                                      site=self._site("%s-%d-%d" % (tag, i, lo + li)))
-                pre = "%s/%s-predict" % (net, tag)
-                out = self._sepconv(x, outc, pre + "/depthwise_kernel", pre + "/pointwise_kernel",
+            xs = list(feats)
+            for i in range(cfg["box_class_repeats"]):
+                pre = "%s/%s-%d" % (net, tag, i)
+                first = len(self.ops)
+                for li in range(len(feats)):
+                    xs[li] = self._sepconv(xs[li], F, pre + "/depthwise_kernel", pre + "/pointwise_kernel",
+                                           "%s-%d-%d" % (tag, i, lo + li), bias=pre + "/bias",
+                                           bn="%s/%s-%d-bn-%d" % (net, tag, i, lo + li), act=capi.ACT_SWISH,
+                                           site=self._site("%s-%d-%d" % (tag, i, lo + li)))
+                self._mark_launch_group(first)
+            pre = "%s/%s-predict" % (net, tag)
+            first = len(self.ops)
+            for li in range(len(feats)):
+                out = self._sepconv(xs[li], outc, pre + "/depthwise_kernel", pre + "/pointwise_kernel",
                                     "%s-predict-%d" % (tag, lo + li), bias=pre + "/bias", out_kind=kind, level=li)
                 self.head_out[tag].append(out)
+            self._mark_launch_group(first)
         # the head buffers must carry the sample axis exactly when the reference stacks them
         for tag, stacked in (("class", self.cls_stacked), ("box", self.box_stacked)):
             for o in self.head_out[tag]:
@@ -448,6 +479,16 @@ class Plan:
                 buf.last = oi
         for f in self.fpn_out:
             self.bufs[f].last = len(self.ops)
+        # ops that share a launch run concurrently: nothing they touch may be recycled before the last of them
+        for oi, o in enumerate(self.ops):
+            n = o.get("launch_group", 0)
+            if n > 1:
+                end = oi + n - 1
+                for g in self.ops[oi:oi + n]:
+                    for b in list(g["ins"]) + [g["out"]]:
+                        buf = self.bufs[b]
+                        buf.last = max(buf.last, end)
+                        buf.first = min(buf.first, oi)
         free, top = [], 0  # free: list of (offset, size)
 
         def alloc(size):
@@ -581,7 +622,7 @@ class Plan:
             c.n_in = len(o["ins"])
             for k in ("out", "se_scale", "se_partial", "residual", "k", "stride", "act", "w_off", "bias_off",
                       "bn_scale_off", "bn_shift_off", "se_w1_off", "se_b1_off", "se_w2_off", "se_b2_off",
-                      "se_mid", "drop_site", "drop_site2", "w2_off", "bn2_scale_off", "bn2_shift_off"):
+                      "se_mid", "drop_site", "drop_site2", "w2_off", "bn2_scale_off", "bn2_shift_off", "launch_group"):
                 setattr(c, k, int(o[k]))
         sites = (capi.DropSite * max(1, len(self.sites)))()
         for i, (_, ch, r) in enumerate(self.sites):
