@@ -582,18 +582,22 @@ __global__ __launch_bounds__(SE_THREADS) void se_kernel(SeArgs a) {
     const int c4 = cbase + tid % cw, g = tid / cw;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g < G) {
-      // two independent accumulation chains (tiles g, g + 2G, ... and g + G, g + 3G, ...), summed in a fixed order
+      // tiles g, g + G, g + 2G, ...: eight loads in flight per step (the reduction is a chain of load latencies: 1120 tiles
+      // over 42 groups = 27 per thread were 14 round trips with two loads per step, now 4), two accumulation chains
+      // (even / odd position), summed in a fixed order; positions past the end add zeros
       float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f);
-      int t = g;
-      for (; t + G < a.n_tiles; t += 2 * G) {
-        const float4 v0 = *(const float4*)(part + (size_t)t * a.C + c4 * 4);
-        const float4 v1 = *(const float4*)(part + (size_t)(t + G) * a.C + c4 * 4);
-        s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
-        s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
-      }
-      if (t < a.n_tiles) {
-        const float4 v0 = *(const float4*)(part + (size_t)t * a.C + c4 * 4);
-        s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+      for (int t = g; t < a.n_tiles; t += 8 * G) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int tt = t + k * G;
+          v[k] = tt < a.n_tiles ? *(const float4*)(part + (size_t)tt * a.C + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+          s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w;
+          s1.x += v[k + 1].x; s1.y += v[k + 1].y; s1.z += v[k + 1].z; s1.w += v[k + 1].w;
+        }
       }
       s.x += s1.x; s.y += s1.y; s.z += s1.z; s.w += s1.w;
     }
