@@ -948,11 +948,16 @@ __global__ __launch_bounds__(512, (KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, b_in = b / a.in_div;
+  const int b = blockIdx.z / a.ch_groups, b_in = b / a.in_div;
   const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
   const int iy0 = oy0 - a.pad_t, ix0 = ox0 - a.pad_l;
   const float* xin = a.in + (size_t)b_in * a.H * a.W * a.Cin;
   const int NCH = (a.Cmid + 31) >> 5;
+  // this block's slabs [chb, che): all of them, or one of ch_groups contiguous ranges (small grids, see MbxArgs)
+  const int ch_per = (NCH + a.ch_groups - 1) / a.ch_groups;
+  const int chb = (int)(blockIdx.z % a.ch_groups) * ch_per;
+  const int che = chb + ch_per < NCH ? chb + ch_per : NCH;
+  if (chb >= che) return;                     // (whole block, before any barrier)
   const uint4* Wp = (const uint4*)a.wsplit;
   // Every per-slab operand (packed expand weights, host-packed depthwise taps + BN scale / shift, dropout scales) is
   // requested while the PREVIOUS slab's expand phase ends, i.e. before that slab's output stores are issued: vmcnt
@@ -961,9 +966,9 @@ __global__ __launch_bounds__(512, (KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a
   // ---- slab 0 operands -> LDS buffers 0
   for (int f = tid; f < BSLAB; f += 512) {
     const int ks = f >> 7, rest = f & 127;     // [ks][part][lane]
-    Bs[f] = Wp[(((size_t)ks * NCH + 0) * 2 + (rest >> 6)) * 64 + (rest & 63)];
+    Bs[f] = Wp[(((size_t)ks * NCH + chb) * 2 + (rest >> 6)) * 64 + (rest & 63)];
   }
-  for (int f = tid; f < NPAR; f += 512) par[f] = a.wpar[f];
+  for (int f = tid; f < NPAR; f += 512) par[f] = a.wpar[(size_t)chb * NPAR + f];
   for (int f = tid; f < 2 * 32 * NCH; f += 512) {
     const int which = f / (32 * NCH), col = f - which * 32 * NCH;
     const float* m = which ? a.mask1 : a.mask0;
@@ -1018,14 +1023,14 @@ __global__ __launch_bounds__(512, (KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a
   const unsigned cm = (unsigned)a.Cmid;
   const bool full = (oy0 + TH <= a.Ho) && (ox0 + TW <= a.Wo);
 
-  for (int ch = 0; ch < NCH; ++ch) {
+  for (int ch = chb; ch < che; ++ch) {
     const int col = ch * 32 + c;
     const bool dcol = col < a.Cmid;
     const uint4* bcur = Bs;
     const float mk0c = mks[ch * 32 + c], mk1 = mks[32 * NCH + ch * 32 + c];   // expand-side scale of channel c: applied after the depthwise
-    const float* pcur = par + (ch & 1) * NPAR;
+    const float* pcur = par + ((ch - chb) & 1) * NPAR;
     // ---- the NEXT slab's operands are requested first: they have the whole expand phase to arrive
-    const bool more = ch + 1 < NCH;
+    const bool more = ch + 1 < che;
     uint4 nb[B_PER];
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {      // (guarded loads measured 6 % faster than clamped unconditional ones here)
@@ -1074,7 +1079,7 @@ __global__ __launch_bounds__(512, (KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a
         const int f = tid + 512 * i;
         if (more && f < BSLAB) Bs[f] = nb[i];
       }
-      float* pnext = par + ((ch + 1) & 1) * NPAR;
+      float* pnext = par + ((ch + 1 - chb) & 1) * NPAR;
 #pragma unroll
       for (int i = 0; i < P_PER; ++i) {
         const int f = tid + 512 * i;
@@ -1188,23 +1193,28 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, b_in = b / a.in_div;
+  const int b = blockIdx.z / a.ch_groups, b_in = b / a.in_div;
   const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
   const int iy0 = oy0 - a.pad_t, ix0 = ox0 - a.pad_l;
   const float* xin = a.in + (size_t)b_in * a.H * a.W * a.Cin;
   const int NCH = (a.Cmid + 31) >> 5;
+  // this block's slabs [chb, che) (see mbxd_kernel); buffers rotate with the slab's position in the range, r = ch - chb
+  const int ch_per = (NCH + a.ch_groups - 1) / a.ch_groups;
+  const int chb = (int)(blockIdx.z % a.ch_groups) * ch_per;
+  const int che = chb + ch_per < NCH ? chb + ch_per : NCH;
+  if (chb >= che) return;
   const uint4* Wp = (const uint4*)a.wsplit;
 
-  // ---- operands of slabs 0 and 1 -> LDS
+  // ---- operands of the first two slabs -> LDS
   for (int f = tid; f < 2 * BSLAB; f += 512) {
     const int sl = f / BSLAB, r = f - sl * BSLAB;
     const int ks = r >> 7, rest = r & 127;
-    const int ch = sl < NCH ? sl : NCH - 1;
+    const int ch = chb + sl < che ? chb + sl : che - 1;
     Bs[f] = Wp[(((size_t)ks * NCH + ch) * 2 + (rest >> 6)) * 64 + (rest & 63)];
   }
   for (int f = tid; f < 2 * NPAR; f += 512) {
     const int sl = f / NPAR;
-    par[f] = a.wpar[(size_t)(sl < NCH ? sl : NCH - 1) * NPAR + (f - sl * NPAR)];
+    par[f] = a.wpar[(size_t)(chb + sl < che ? chb + sl : che - 1) * NPAR + (f - sl * NPAR)];
   }
   for (int f = tid; f < 2 * 32 * NCH; f += 512) {
     const int which = f / (32 * NCH), col = f - which * 32 * NCH;
@@ -1282,17 +1292,18 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
     e_store(E, acc);
   }
 
-  for (int ch = 0; ch < NCH; ++ch) {
-    __syncthreads();      // E[ch & 1], Bs[(ch + 1) & 1], par[(ch + 1) % 3], red[(ch - 1) & 1] are complete
+  for (int ch = chb; ch < che; ++ch) {
+    __syncthreads();      // E[r & 1], Bs[(r + 1) & 1], par[(r + 1) % 3], red[(r - 1) & 1] are complete
+    const int r = ch - chb;
     const int col = ch * 32 + c;
     const bool dcol = col < a.Cmid;
-    const float* Ec = E + (size_t)(ch & 1) * NPP * ES;
-    float* En = E + (size_t)((ch + 1) & 1) * NPP * ES;
-    const float* pcur = par + (ch % 3) * NPAR;
-    const uint4* bnext = Bs + (size_t)((ch + 1) & 1) * BSLAB;
-    const bool more = ch + 1 < NCH, more2 = ch + 2 < NCH;
-    if (ch > 0 && a.se_partial && g == 0 && (ch - 1) * 32 + c < a.Cmid) {      // SE tile sums of the previous slab
-      const float* rp = red + ((ch - 1) & 1) * NG * 32;
+    const float* Ec = E + (size_t)(r & 1) * NPP * ES;
+    float* En = E + (size_t)((r + 1) & 1) * NPP * ES;
+    const float* pcur = par + (r % 3) * NPAR;
+    const uint4* bnext = Bs + (size_t)((r + 1) & 1) * BSLAB;
+    const bool more = ch + 1 < che, more2 = ch + 2 < che;
+    if (r > 0 && a.se_partial && g == 0 && (ch - 1) * 32 + c < a.Cmid) {      // SE tile sums of the previous slab
+      const float* rp = red + ((r - 1) & 1) * NG * 32;
       float t = rp[c];
 #pragma unroll
       for (int gg = 1; gg < NG; ++gg) t += rp[gg * 32 + c];
@@ -1426,18 +1437,18 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
     };
     if (full) store_units(std::false_type());
     else if (dcol) store_units(std::true_type());
-    if (a.se_partial) red[((ch & 1) * NG + g) * 32 + c] = ssum;
+    if (a.se_partial) red[((r & 1) * NG + g) * 32 + c] = ssum;
     // ---- slab ch + 1: activate -> the other E buffer (its readers, depthwise ch - 1, finished before the barrier above)
     if (more) e_store(En, acc);
-    // ---- slab ch + 2 operands -> LDS: Bs[ch & 1] (its MFMAs were issued one iteration ago), par[(ch + 2) % 3]
+    // ---- slab ch + 2 operands -> LDS: Bs[r & 1] (its MFMAs were issued one iteration ago), par[(r + 2) % 3]
     {
-      uint4* bw = Bs + (size_t)(ch & 1) * BSLAB;
+      uint4* bw = Bs + (size_t)(r & 1) * BSLAB;
 #pragma unroll
       for (int i = 0; i < B_PER; ++i) {
         const int f = tid + 512 * i;
         if (more2 && f < BSLAB) bw[f] = nb[i];
       }
-      float* pw = par + ((ch + 2) % 3) * NPAR;
+      float* pw = par + ((r + 2) % 3) * NPAR;
 #pragma unroll
       for (int i = 0; i < P_PER; ++i) {
         const int f = tid + 512 * i;
@@ -1447,15 +1458,34 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
   }
   if (a.se_partial) {
     __syncthreads();
-    const int lc = (NCH - 1) * 32 + c;
+    const int lc = (che - 1) * 32 + c;
     if (g == 0 && lc < a.Cmid) {
-      const float* rp = red + ((NCH - 1) & 1) * NG * 32;
+      const float* rp = red + ((che - 1 - chb) & 1) * NG * 32;
       float t = rp[c];
 #pragma unroll
       for (int gg = 1; gg < NG; ++gg) t += rp[gg * 32 + c];
       a.se_partial[((size_t)b * a.n_tiles + tile) * a.Cmid + lc] = t;
     }
   }
+}
+
+// Slab groups of a deep fused MBConv launch: a launch of `blocks` blocks on a device that holds per_cu of them per CU is
+// split along the channels until it fills the device (at most 4 ways, at least 4 slabs per block).  A batch of 32 images never
+// splits; one image with T = 10 has 60-90 blocks of 36 slabs each in the last blocks.  UDA_MBX_SPLIT=0: never.
+static int mbx_ch_groups(long long blocks, int per_cu, int n_slabs) {
+  static int on = -1, n_cu = 0;
+  if (on < 0) {
+    const char* e = getenv("UDA_MBX_SPLIT");
+    on = e ? atoi(e) : 1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 0;
+    (void)hipGetLastError();
+  }
+  if (!on || n_cu <= 0 || blocks <= 0) return 1;
+  long long g = (long long)n_cu * per_cu / blocks;
+  if (g > 4) g = 4;
+  if (g > n_slabs / 4) g = n_slabs / 4;
+  return g < 1 ? 1 : (int)g;
 }
 
 template <int K, int KSF>
@@ -1468,8 +1498,11 @@ static void launch_mbxp_t(const MbxArgs& a, int rows, hipStream_t s) {
     hipFuncSetAttribute((const void*)mbxp_kernel<K, KSF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_lds = lds;
   }
-  const dim3 grid((a.Wo + 15) / 16, (a.Ho + TH - 1) / TH, rows);
-  hipLaunchKernelGGL((mbxp_kernel<K, KSF>), grid, dim3(512), lds, s, a);
+  dim3 grid((a.Wo + 15) / 16, (a.Ho + TH - 1) / TH, rows);
+  MbxArgs b = a;
+  b.ch_groups = mbx_ch_groups((long long)grid.x * grid.y * rows, 1, (a.Cmid + 31) / 32);
+  grid.z = (unsigned)(rows * b.ch_groups);
+  hipLaunchKernelGGL((mbxp_kernel<K, KSF>), grid, dim3(512), lds, s, b);
 }
 
 bool mbxd_supported(int Cin, int Cmid, int k, int stride) {
@@ -1497,8 +1530,11 @@ static void launch_mbxd_t(const MbxArgs& a, int rows, hipStream_t s) {
     hipFuncSetAttribute((const void*)mbxd_kernel<K, KSF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_lds = lds;
   }
-  const dim3 grid((a.Wo + 15) / 16, (a.Ho + TH - 1) / TH, rows);
-  hipLaunchKernelGGL((mbxd_kernel<K, KSF>), grid, dim3(512), lds, s, a);
+  dim3 grid((a.Wo + 15) / 16, (a.Ho + TH - 1) / TH, rows);
+  MbxArgs b = a;
+  b.ch_groups = mbx_ch_groups((long long)grid.x * grid.y * rows, KSF <= 8 ? 2 : 1, (a.Cmid + 31) / 32);
+  grid.z = (unsigned)(rows * b.ch_groups);
+  hipLaunchKernelGGL((mbxd_kernel<K, KSF>), grid, dim3(512), lds, s, b);
 }
 
 void launch_mbxd(const MbxArgs& a, int rows, int k, hipStream_t s) {

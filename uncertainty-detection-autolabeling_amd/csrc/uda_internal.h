@@ -162,6 +162,9 @@ struct MbxArgs {
   // in_div blocks of one tile adjacent and on ONE XCD (ids = tile slot + 8 t), so that the shared tile is fetched into
   // that XCD's L2 once instead of once per sample; 0 = plain (tiles_x, tiles_y, rows) grid
   int remap_T, tiles_x, tiles_y;
+  // deep variants (mbxd / mbxp) on small grids (a few sample rows): the 32-channel slabs of a tile are divided among
+  // ch_groups blocks (grid z = rows x ch_groups), so that a launch of fewer blocks than the device holds still fills it
+  int ch_groups;
 };
 void mbxb_pack_proj(const float* w0, const float* sc, const float* sh, int c0, int cout, float* out);
 size_t mbx_par_floats(int Cmid, int k);
