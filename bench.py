@@ -147,8 +147,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     tdev = None
-    if world > 1 or a.gpus > 1 or a.force_dist:
+    if a.gpus > 1 and world != a.gpus:
+        sys.exit("bench.py --gpus %d needs one process per GPU: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                 "--master-addr 127.0.0.1 --master-port <port> bench.py --gpus %d ... (WORLD_SIZE is %d)" % (a.gpus, a.gpus, a.gpus, world))
+    if world > 1 or a.force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "RANK" not in os.environ:           # --force-dist in a plain process: a world of one over RCCL
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
         import torch                    # torch first: the HIP library then binds to the same runtime
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
