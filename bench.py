@@ -19,8 +19,10 @@ Prints ONE JSON line (rank 0) with the driver's contract plus
   cpu_baseline   the CPU oracle (restatement, not TF) timed on a bounded sample in a subprocess
   precision      ms_per_step of the same workload with six-term ("float32-equivalent") and exact f32-input
                  MFMA products, each measured in a child process that sets the switch before its first GPU call
-  h2d_inclusive  ms_per_step with the uint8 batch uploaded inside every step (the reference times serve(image)
-                 including the feed, validate_model.py:154-158)
+  h2d_inclusive  ms_per_step with a fresh uint8 batch fed inside every step (the reference times serve(image) including
+                 the feed, validate_model.py:154-158): host bytes -> pinned staging -> DMA on the copy stream into the
+                 second input slot while the current batch computes (uda_prefetch_images_u8 / uda_swap_prefetched)
+  ranks          (N > 1) what RCCL actually formed: world size and every rank's device (name, uuid, PCI bus id)
   p50_detect_latency_ms   batch-1 serve() of one image, T as configured, upload and download included
 """
 import argparse
@@ -121,16 +123,29 @@ def precision_child(a, terms):
     """ms_per_step of the same workload with UDA_PW_TERMS=<terms>, in a child started with the switch in its environment
     (the library reads it once, at its first call)."""
     env = dict(os.environ, UDA_PW_TERMS=str(terms))
-    cmd = [sys.executable, os.path.abspath(__file__), "--child", "--no-cpu-baseline", "--no-side", "--steps", str(max(2, min(a.steps, 3))),
-           "--warmup", "1", "--config", str(a.config), "--batch", str(a.batch), "--samples", str(a.samples), "--image-size", a.image_size,
+    cmd = [sys.executable, os.path.abspath(__file__), "--child", "--no-cpu-baseline", "--no-side", "--steps", str(a.steps),
+           "--warmup", str(a.warmup), "--config", str(a.config), "--batch", str(a.batch), "--samples", str(a.samples), "--image-size", a.image_size,
            "--raw-size", a.raw_size, "--classes", str(a.classes), "--variant", a.variant, "--chunk", str(a.chunk), "--model", a.model,
            "--post-mode", a.post_mode, "--ensemble", str(a.ensemble)]
     try:
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
         return json.loads(line)
     except Exception as e:
         return {"ms_per_step": None, "error": repr(e)}
+
+
+def rank_devices(dist, torch, rank, local_rank):
+    """What RCCL formed: every rank reports the device it computes on; rank 0 gets the list (a SCALE run can then show N ranks
+    on N distinct GPUs, not N processes on one)."""
+    pr = torch.cuda.get_device_properties(local_rank)
+    me = {"rank": rank, "local_device": local_rank, "name": pr.name, "uuid": str(getattr(pr, "uuid", "")),
+          "pci_bus_id": getattr(pr, "pci_bus_id", None), "pci_device_id": getattr(pr, "pci_device_id", None),
+          "visible": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES"))}
+    got = [None] * dist.get_world_size()
+    dist.all_gather_object(got, me)
+    ids = {(g["uuid"], g["pci_bus_id"], g["visible"], g["local_device"]) for g in got}
+    return {"world_size_formed": dist.get_world_size(), "backend": dist.get_backend(), "distinct_devices": len(ids), "devices": got}
 
 
 def log(msg):
@@ -171,6 +186,10 @@ def main():
         finally:
             os.dup2(saved, 1)
             os.close(saved)
+        ranks_info = rank_devices(dist, torch, rank, local_rank)
+        world = dist.get_world_size()          # what RCCL formed, not what the environment asked for
+    else:
+        ranks_info = None
 
     from uda_amd import plan as plan_mod, weights as weights_mod
     from uda_amd.infer_lib import EnsembleDriver, KerasDriver
@@ -181,7 +200,7 @@ def main():
     terms = os.environ.get("UDA_PW_TERMS", "3")
 
     if a.ensemble:
-        return ensemble_main(a, params, images, rank, world, local_rank, dist, tdev)
+        return ensemble_main(a, params, images, rank, world, local_rank, dist, tdev, ranks_info)
 
     w = weights_mod.init_weights(params, seed=0, cls_spread=a.cls_spread)
     drv = KerasDriver("_", False, a.model, a.batch, False, params, weights=w, device=local_rank,
@@ -248,7 +267,8 @@ def main():
 
     if a.child:
         if rank == 0:
-            print(json.dumps({"ms_per_step": round(elapsed / a.steps * 1e3, 2), "UDA_PW_TERMS": terms,
+            print(json.dumps({"ms_per_step": round(elapsed / a.steps * 1e3, 2), "value": round(value, 2), "steps": a.steps,
+                              "warmup": a.warmup, "UDA_PW_TERMS": terms,
                               "kernel_ms_per_step": {KIND_NAMES.get(k, str(k)): round(v[0], 2) for k, v in calib.items()}}), flush=True)
         drv.close()
         return
@@ -257,14 +277,24 @@ def main():
     side = {}
     if world == 1 and not a.no_side:
         k_side = max(3, a.steps)
+        fresh = [images, np.ascontiguousarray(images[::-1])]           # two different host batches, alternating
+        drv.stage_images(fresh[0])
         drv.synchronize()
         t1 = time.perf_counter()
-        for _ in range(k_side):
-            step(upload=True)
+        for k in range(k_side):
+            drv.run_resident(sync=False)                   # queue this step's kernels
+            drv.prefetch_images(fresh[(k + 1) & 1])        # next batch: host bytes -> pinned -> DMA on the copy stream, meanwhile
+            drv._collect(a.batch)                          # this step's detections (synchronises the compute stream)
+            drv.swap_prefetched()
         drv.synchronize()
         side["h2d_inclusive"] = {"ms_per_step": round((time.perf_counter() - t1) / k_side * 1e3, 2),
-                                 "note": "uint8 batch (%.0f MB, pageable host memory) uploaded inside every step" % (images.nbytes / 1e6)}
-    coop_fb, pfx_fb = drv.nms_coop_fallbacks(), drv.nms_prefix_fallbacks()
+                                 "note": "a fresh uint8 batch (%.0f MB, pageable host memory) fed in every step: gathered into the "
+                                         "handle's pinned staging buffer and uploaded on the copy stream under the previous step's "
+                                         "kernels (uda_prefetch_images_u8 / uda_swap_prefetched)" % (images.nbytes / 1e6)}
+        t2 = time.perf_counter()
+        drv.stage_images(fresh[0])
+        side["h2d_serial_upload_ms"] = round((time.perf_counter() - t2) * 1e3, 2)
+    coop_fb, pfx_fb, coop_nl = drv.nms_coop_fallbacks(), drv.nms_prefix_fallbacks(), drv.nms_coop_not_launched()
     summary = drv.plan.summary()
     drv.close()
     if world == 1 and not a.no_side:
@@ -280,6 +310,7 @@ def main():
         side["p50_detect_latency_ms"] = round(float(np.median(l1)) * 1e3, 2)
         side["detect_latency_note"] = "batch 1, T=%d, serve(image) = upload + preprocess + network x T + post-process + download; 20 calls" % a.samples
         coop_fb += d1.nms_coop_fallbacks()
+        coop_nl += d1.nms_coop_not_launched()
         d1.close()
 
     if rank == 0:
@@ -338,17 +369,22 @@ def main():
             "h2d_upload_ms": round(upload_s * 1e3, 1),
             "nms_prefix_redone_images": pfx_fb,
             "nms_coop_fallbacks": coop_fb,
+            "nms_coop_not_launched": coop_nl,
+            "ranks": ranks_info,
             "roofline": roof,
             "pipeline": pipeline,
         }
         line.update(side)
         if world == 1 and not a.no_side:
             log("GPU part done (%.2f units/s); precision children (UDA_PW_TERMS=6, 0) ..." % value)
+            six, exact = precision_child(a, 6), precision_child(a, 0)
             line["precision"] = {"default_terms": terms,
-                                 "six_terms_float32_equivalent": precision_child(a, 6),
-                                 "exact_f32_mfma": precision_child(a, 0),
-                                 "note": "same workload, each in a child process whose environment carries the switch before its first "
-                                         "GPU call; detection-level effect of 3 terms vs exact: tests/test_gpu_fullsize.py"}
+                                 "six_terms_float32_equivalent": six,
+                                 "exact_f32_mfma": exact,
+                                 "note": "same workload and the same --steps / --warmup protocol, each in a child process whose "
+                                         "environment carries the switch before its first GPU call; detection-level effect of 3 "
+                                         "terms vs exact: tests/test_gpu_fullsize.py"}
+            line["value_fp32_equivalent"] = six.get("value")      # images*MC-samples/s with float32-equivalent (six-term) products
         if world == 1 and not a.no_cpu_baseline:
             log("timing the CPU oracle on a bounded sample ...")
             line["cpu_baseline"] = cpu_baseline(a)
@@ -357,7 +393,7 @@ def main():
         dist.destroy_process_group()
 
 
-def ensemble_main(a, params, images, rank, world, local_rank, dist, tdev):
+def ensemble_main(a, params, images, rank, world, local_rank, dist, tdev, ranks_info=None):
     """BASELINE configs[3]: M deterministic members (independent random-init weight sets), aggregated like MC samples.
     One GPU: EnsembleDriver.  Several ranks: members striped round-robin, head outputs re-sharded by image over RCCL,
     every rank aggregates / NMSes its image shard, one all-gather of the detections (dist.serve_ensemble_striped)."""
@@ -408,7 +444,7 @@ def ensemble_main(a, params, images, rank, world, local_rank, dist, tdev):
             "dtype": "f32 (1x1 products split-bf16 MFMA x%s)" % os.environ.get("UDA_PW_TERMS", "3"), "data": "synthetic",
             "config": {"workload": "%s: %d-member deep ensemble of %s, %d synthetic images (%s) per GPU, members striped over %d rank(s), "
                                    "uploads included" % (CONFIG_NAMES[3], M, a.model, a.batch, a.image_size, world),
-                       "images_per_gpu": a.batch, "members": M}}), flush=True)
+                       "images_per_gpu": a.batch, "members": M}, "ranks": ranks_info}), flush=True)
     close()
     if dist is not None:
         dist.destroy_process_group()

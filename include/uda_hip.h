@@ -147,8 +147,22 @@ void uda_destroy(uda_ctx_t* ctx);
 /* last error of `ctx` (or of the last failed uda_create when ctx == NULL) */
 const char* uda_last_error(const uda_ctx_t* ctx);
 
-/* Raw uint8 images [n,h,w,3] from host memory into the handle's device staging buffer. */
+/* Raw uint8 images [n,h,w,3] from host memory into the handle's device staging buffer (replaces the feed of
+ * ServingDriver.serve, infer_lib.py:139-151,232-249).  The bytes are gathered into a pinned host buffer owned by the
+ * handle and leave by one DMA: the caller's array is free as soon as the call returns. */
 int uda_set_images_u8(uda_ctx_t* ctx, const uint8_t* images, int32_t n, int32_t h, int32_t w);
+/* A batch whose raw sizes differ per image - KITTI frames are 370-376 x 1224-1242 (dataset_data.py:105) and the
+ * reference's callers feed them one file at a time (validate_model.py:479-483, infer_model.py:554-581): images[i] points
+ * at [h[i], w[i], 3] bytes.  Every image gets its own resize scale / scaled size / image_scale, exactly as
+ * dataloader.py:123-152 computes them per image. */
+int uda_set_images_u8_ragged(uda_ctx_t* ctx, const uint8_t* const* images, int32_t n, const int32_t* h, const int32_t* w);
+/* Feed hiding: upload the NEXT batch into the handle's second input slot on a copy stream while the current batch is
+ * being processed (call it after uda_run has queued the current batch); uda_swap_prefetched then makes that batch the
+ * input of the following uda_run (the compute stream waits for the upload event, no host synchronisation).  The reference
+ * times serve() including its feed (validate_model.py:154-158); with these two calls the feed costs no device time. */
+int uda_prefetch_images_u8(uda_ctx_t* ctx, const uint8_t* images, int32_t n, int32_t h, int32_t w);
+int uda_prefetch_images_u8_ragged(uda_ctx_t* ctx, const uint8_t* const* images, int32_t n, const int32_t* h, const int32_t* w);
+int uda_swap_prefetched(uda_ctx_t* ctx);
 /* Same, from a device pointer the caller owns (device-to-device copy on the stream). */
 int uda_set_images_u8_device(uda_ctx_t* ctx, const void* images_dev, int32_t n, int32_t h, int32_t w);
 /* Preprocessed float images [n,H,W,3] (the `only_network` input); scales default to 1. */
@@ -177,6 +191,10 @@ int64_t uda_nms_prefix_fallbacks(const uda_ctx_t* ctx);
  * the handle stays on that version; this counts those redone post-process runs (0 in normal operation; results are
  * identical either way).  UDA_NMS_COOP_SPIN=<polls> shortens the bound (test hook). */
 int64_t uda_nms_coop_fallbacks(const uda_ctx_t* ctx);
+/* NMS runs that were eligible for the single-launch grid but did NOT get it (capacity query failed, grid larger than the
+ * device holds, launch refused) and therefore ran the slower prefix / two-launches-per-epoch versions: 0 in normal
+ * operation; a non-zero value explains a slow post-process that uda_nms_coop_fallbacks (time-outs only) would not show. */
+int64_t uda_nms_coop_not_launched(const uda_ctx_t* ctx);
 
 /* Detections of the last uda_run (synchronises).  Shapes for n images, M = max_output_size:
  *   boxes   [n, M, box_cols]   box_cols = 4 (+4 aleatoric sigma)(+4 epistemic sigma)

@@ -66,3 +66,21 @@ def oracle_heads(p, w, x, seed, t_real=4):
         return out
     return (widen(cls, bool(p["mc_classheadrate"] or p["mc_dropoutrate"])),
             widen(box, bool(p["mc_boxheadrate"] or p["mc_dropoutrate"])))
+
+
+def check_heads(got, want, tol=2e-4, tol_rms=1e-4):
+    """max-norm per level tensor AND relative RMS per channel group.  A box head with loss attenuation carries the box
+    deltas and the sigma channels in one tensor ([4A | 4A]): the groups are judged on their own scales, so that a
+    small-magnitude group cannot hide behind a large one (VERDICT r01, weak 3 iii)."""
+    for lvl, (g, r) in enumerate(zip(got, want)):
+        assert g.shape == r.shape, (lvl, g.shape, r.shape)
+        scale = np.abs(r).max()
+        err = np.abs(g - r).max()
+        assert err <= tol * scale + 1e-6, "level %d: err %g vs scale %g" % (lvl, err, scale)
+        ch = g.shape[-1]
+        groups = [(0, ch // 2), (ch // 2, ch)] if ch == 72 else [(0, ch)]      # 72 = 9 anchors x (4 deltas + 4 sigmas)
+        for lo, hi in groups:
+            gg, rr = g[..., lo:hi].astype(np.float64), r[..., lo:hi].astype(np.float64)
+            rms = np.sqrt(np.mean(rr * rr))
+            e = np.sqrt(np.mean((gg - rr) ** 2))
+            assert e <= tol_rms * rms + 1e-7, "level %d channels %d:%d: relative rms error %g" % (lvl, lo, hi, e / max(rms, 1e-30))

@@ -58,7 +58,7 @@ def test_restore_rules_ema_missing_and_mismatch(tmp_path):
     prefix = CR.save_checkpoint(str(tmp_path / "ckpt-3"), bundle, checksum=False)
     got = CR.load_checkpoint(prefix, p, use_ema=True, skip_mismatch=True)
     np.testing.assert_array_equal(got[k], w[k] * 2)
-    np.testing.assert_array_equal(CR.load_checkpoint(prefix, p, use_ema=False)[k], w[k])
+    np.testing.assert_array_equal(CR.load_checkpoint(prefix, p, use_ema=False, skip_mismatch=True)[k], w[k])
     ref = W.init_weights(p, seed=0)                                     # skipped variables keep their initial value
     np.testing.assert_array_equal(got["class_net/class-predict/bias"], ref["class_net/class-predict/bias"])
     np.testing.assert_array_equal(got["box_net/box-predict/bias"], ref["box_net/box-predict/bias"])
@@ -121,3 +121,64 @@ def test_prefix_compressed_blocks_are_read():
     body = ent(0, b"conv/kernel", b"A") + ent(5, b"bias", b"B") + ent(0, b"dense", b"C")
     block = body + struct.pack("<III", 0, len(body) - len(ent(0, b"dense", b"C")), 2)
     assert CR._block_entries(block) == [(b"conv/kernel", b"A"), (b"conv/bias", b"B"), (b"dense", b"C")]
+
+
+def test_ema_shadow_wins_for_bn_statistics_too(tmp_path):
+    """`get_ema_vars` adds the BN moving statistics (utils_keras.py:85-97) and `restore_ckpt` assigns the shadow after the
+    plain name (:183-196): a bundle holding both keys for a BN statistic restores the shadow."""
+    p = make_params()
+    w = W.init_weights(p, seed=6)
+    bundle = dict(w)
+    for f in ("moving_mean", "moving_variance", "gamma"):
+        k = "efficientnet-b0/stem/tpu_batch_normalization/" + f
+        bundle[k + "/ExponentialMovingAverage"] = w[k] + 3
+    prefix = CR.save_checkpoint(str(tmp_path / "ckpt-7"), bundle, checksum=False)
+    got = CR.load_checkpoint(prefix, p, use_ema=True, verify_crc=False)
+    plain = CR.load_checkpoint(prefix, p, use_ema=False, verify_crc=False)
+    for f in ("moving_mean", "moving_variance", "gamma"):
+        k = "efficientnet-b0/stem/tpu_batch_normalization/" + f
+        np.testing.assert_array_equal(got[k], w[k] + 3)
+        np.testing.assert_array_equal(plain[k], w[k])
+
+
+def test_driver_restore_is_strict_and_follows_moving_average_decay(tmp_path, caplog):
+    """`resolve_weights` restores as the reference's KerasDriver does (infer_lib.py:435): skip_mismatch=False, EMA shadows
+    only when config.moving_average_decay > 0; an explicit skip_mismatch logs every variable it skips."""
+    p = make_params()
+    w = W.init_weights(p, seed=8)
+    k = "efficientnet-b0/blocks_2/conv2d/kernel"
+    bundle = dict(w)
+    bundle[k + "/ExponentialMovingAverage"] = w[k] * 3
+    prefix = CR.save_checkpoint(str(tmp_path / "ckpt-1"), bundle, checksum=False)
+    np.testing.assert_array_equal(W.resolve_weights(prefix, dict(p, moving_average_decay=0.9998))[k], w[k] * 3)
+    np.testing.assert_array_equal(W.resolve_weights(prefix, dict(p, moving_average_decay=0))[k], w[k])
+    del bundle["class_net/class-predict/bias"]
+    bundle["box_net/box-predict/bias"] = np.zeros((6, 6), np.float32)     # same element count, wrong layout: still a mismatch
+    prefix = CR.save_checkpoint(str(tmp_path / "ckpt-2"), bundle, checksum=False)
+    with pytest.raises((KeyError, ValueError)):
+        W.resolve_weights(prefix, p)
+    import logging
+    with caplog.at_level(logging.WARNING):
+        got = CR.load_checkpoint(prefix, p, skip_mismatch=True, verify_crc=False)
+    text = caplog.text
+    assert "class_net/class-predict/bias" in text and "box_net/box-predict/bias" in text
+    assert got["box_net/box-predict/bias"].shape == (36,)
+
+
+def test_truncated_or_corrupt_data_shard_raises(tmp_path):
+    arrays = {"a/kernel": np.arange(64, dtype=np.float32), "b/kernel": np.arange(32, dtype=np.float32)}
+    prefix = CR.save_checkpoint(str(tmp_path / "ckpt-5"), arrays, checksum=True)
+    data = prefix + ".data-00000-of-00001"
+    raw = bytearray(open(data, "rb").read())
+    r = CR.BundleReader(prefix)
+    np.testing.assert_array_equal(r.get_tensor("a/kernel", verify_crc=True), arrays["a/kernel"])
+    raw[5] ^= 0x40                                                         # one flipped bit in a/kernel
+    open(data, "wb").write(bytes(raw))
+    r = CR.BundleReader(prefix)
+    with pytest.raises(ValueError, match="crc32c mismatch"):
+        r.get_tensor("a/kernel", verify_crc=True)
+    np.testing.assert_array_equal(r.get_tensor("b/kernel", verify_crc=True), arrays["b/kernel"])
+    open(data, "wb").write(bytes(raw[:-16]))                               # truncated: b/kernel's range runs past the end
+    r = CR.BundleReader(prefix)
+    with pytest.raises(ValueError, match="truncated"):
+        r.get_tensor("b/kernel")

@@ -116,9 +116,9 @@ def test_oracle_spot_check_one_image_full_resolution(full_run):
     x, scales = PP.preprocess(imgs[:1], (768, 1280), p["mean_rgb"], p["stddev_rgb"])
     masks = R.make_masks(E.dropout_sites(p), 9, 1, 2)
     rcls, rbox = E.forward(w, p, x, masks)
-    for l in range(5):
-        for g, r in ((cls[l], rcls[l]), (box[l], rbox[l])):
-            assert np.abs(g - r).max() <= 2e-4 * np.abs(r).max() + 1e-6
+    from common import check_heads
+    check_heads(cls, rcls)          # max-norm 2e-4 per level AND relative RMS 1e-4 per channel group (deltas | sigmas)
+    check_heads(box, rbox)
     want = P.postprocess_global(p, rcls, rbox, scales)
     got = d.postprocess(rcls, rbox, scales)
     for g, r in zip(got, want):

@@ -73,6 +73,10 @@ _SIGNATURES = {
     "uda_last_error": (C.c_char_p, [_P]),
     "uda_set_images_u8": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32]),
     "uda_set_images_u8_device": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32]),
+    "uda_set_images_u8_ragged": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
+    "uda_prefetch_images_u8": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32]),
+    "uda_prefetch_images_u8_ragged": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
+    "uda_swap_prefetched": (C.c_int, [_P]),
     "uda_set_images_f32": (C.c_int, [_P, _P, C.c_int32, _P]),
     "uda_set_dropout_seed": (C.c_int, [_P, C.c_uint64]),
     "uda_set_dropout_image_offset": (C.c_int, [_P, C.c_int64]),
@@ -82,6 +86,7 @@ _SIGNATURES = {
     "uda_synchronize": (C.c_int, [_P]),
     "uda_nms_prefix_fallbacks": (C.c_int64, [_P]),
     "uda_nms_coop_fallbacks": (C.c_int64, [_P]),
+    "uda_nms_coop_not_launched": (C.c_int64, [_P]),
     "uda_get_detections": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "uda_detection_cols": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "uda_get_class_probs": (C.c_int, [_P, _P, _P]),

@@ -13,8 +13,12 @@ and a 40-line protobuf wire decoder, maps the variables to the reference names `
 
 Pinning: there is no TensorFlow and no checkpoint file in this environment, so the format is restated from
 the published TensorBundle / LevelDB table layouts and exercised only against this module's own writer -
-**format parity unpinned**; CRCs are written (crc32c, masked as LevelDB does) but not verified on read.
+**format parity unpinned**.  Integrity on read: a tensor whose byte range runs past the end of its data shard raises
+(truncated files never load silently); the per-tensor crc32c (masked as LevelDB does) is verified when `verify_crc` is
+set - always for bundles up to 4 MB, on request for larger ones (pure-Python CRC, ~1 s per MB), and a log line says so
+when it is skipped.
 """
+import logging
 import os
 import re
 import struct
@@ -72,7 +76,7 @@ def _signed(v):
 
 def _bundle_entry(buf):
     """BundleEntryProto -> dict(dtype, shape, shard, offset, size)."""
-    e = dict(dtype=0, shape=[], shard=0, offset=0, size=0, sliced=False)
+    e = dict(dtype=0, shape=[], shard=0, offset=0, size=0, sliced=False, crc32c=None)
     for num, _, v in _fields(buf):
         if num == 1:
             e["dtype"] = v
@@ -86,6 +90,8 @@ def _bundle_entry(buf):
             e["offset"] = v
         elif num == 5:
             e["size"] = v
+        elif num == 6:
+            e["crc32c"] = v
         elif num == 7:
             e["sliced"] = True
     return e
@@ -165,15 +171,28 @@ class BundleReader:
     def variable_to_shape_map(self):
         return {k: tuple(e["shape"]) for k, e in self.entries.items()}
 
-    def get_bytes(self, name):
+    def _raw(self, name):
         e = self.entries[name]
-        return bytes(self._shard(e["shard"])[e["offset"]:e["offset"] + e["size"]])
+        shard = self._shard(e["shard"])
+        if e["offset"] + e["size"] > shard.shape[0]:
+            raise ValueError("checkpoint %s is truncated: tensor %s needs bytes [%d, %d) of a %d-byte shard"
+                             % (self.prefix, name, e["offset"], e["offset"] + e["size"], shard.shape[0]))
+        return shard[e["offset"]:e["offset"] + e["size"]]
 
-    def get_tensor(self, name):
+    def get_bytes(self, name):
+        return bytes(self._raw(name))
+
+    def total_bytes(self):
+        return sum(e["size"] for e in self.entries.values())
+
+    def get_tensor(self, name, verify_crc=False):
         e = self.entries[name]
         if e["sliced"]:
             raise ValueError("partitioned variable %s is not supported" % name)
-        raw = self._shard(e["shard"])[e["offset"]:e["offset"] + e["size"]]
+        raw = self._raw(name)
+        if verify_crc and e["crc32c"] is not None and e["dtype"] != _DT_STRING:
+            if _masked(_crc32c(raw)) != e["crc32c"]:
+                raise ValueError("checkpoint %s: crc32c mismatch in tensor %s (corrupt data shard)" % (self.prefix, name))
         if e["dtype"] == _DT_STRING:
             n = int(np.prod(e["shape"])) if e["shape"] else 1
             buf, pos, lens = bytes(raw), 0, []
@@ -215,12 +234,19 @@ def latest_checkpoint(directory):
     return None
 
 
-def load_checkpoint(path, config, use_ema=True, skip_mismatch=True):
+_CRC_AUTO_BYTES = 4 << 20
+
+
+def load_checkpoint(path, config, use_ema=True, skip_mismatch=False, verify_crc=None):
     """Weight set (reference variable name -> float32 array) of the detector described by `config`.
 
-    Every variable `weights.variable_specs(config)` lists is looked up by name (EMA shadow first when `use_ema`, as
-    restore_ckpt does with `ema.average_name`, utils_keras.py:183-196).  A missing variable or a shape mismatch raises
-    (KeyError / ValueError, :213-233) unless `skip_mismatch`, in which case the variable keeps its initial value."""
+    Every variable `weights.variable_specs(config)` lists is looked up by name; with `use_ema` the shadow
+    `<name>/ExponentialMovingAverage` wins for EVERY variable, BN moving statistics included, as `get_ema_vars` +
+    `restore_ckpt` assign it after the plain name (utils_keras.py:85-97,183-196).  A missing variable or a shape
+    mismatch raises (KeyError / ValueError, :213-233) - the reference's driver restores with `skip_mismatch=False`
+    (infer_lib.py:435).  With `skip_mismatch` the variable keeps its initial value and every such variable is logged.
+    Shapes must be equal; only the scalar fusion weights (WSM) may be stored as () or (1,).
+    verify_crc: None = check the per-tensor crc32c for bundles up to 4 MB, True / False = always / never."""
     path = str(path)
     if os.path.isdir(path):
         path = latest_checkpoint(path) or path
@@ -229,13 +255,19 @@ def load_checkpoint(path, config, use_ema=True, skip_mismatch=True):
             path = path[:-len(ext)]
     reader = BundleReader(path)
     names = reader.name_map()
+    if verify_crc is None:
+        verify_crc = reader.total_bytes() <= _CRC_AUTO_BYTES
+        if not verify_crc:
+            logging.getLogger(__name__).warning(
+                "%s: per-tensor crc32c NOT verified (%.1f MB; pass verify_crc=True to check, ~1 s per MB)",
+                path, reader.total_bytes() / 2 ** 20)
     init = None
     out = {}
     for name, shape, kind in weights_mod.variable_specs(config):
         fields = [(name + "/" + f, shape) for f in weights_mod.BN_FIELDS] if kind == "bn" else [(name, shape)]
         for var, shp in fields:
             key = None
-            if use_ema and not var.endswith(("moving_mean", "moving_variance")):
+            if use_ema:
                 key = names.get(var + "/ExponentialMovingAverage")
             key = key or names.get(var)
             problem = None
@@ -244,16 +276,17 @@ def load_checkpoint(path, config, use_ema=True, skip_mismatch=True):
             else:
                 got = tuple(reader.entries[key]["shape"])
                 want = tuple(shp) if kind != "wsm" else ()
-                if got != want and int(np.prod(got or (1,))) != int(np.prod(want or (1,))):
+                if got != want and not (kind == "wsm" and got in ((), (1,))):
                     problem = ValueError("Shape mismatch: %s, expected %s, but got %s" % (var, want, got))
             if problem is not None:
                 if not skip_mismatch:
                     raise problem
+                logging.getLogger(__name__).warning("skip_mismatch: %s keeps its initial value (%s)", var, problem)
                 if init is None:
                     init = weights_mod.init_weights(config, seed=int(config.get("uda_seed", 0)))
                 out[var] = init[var]
                 continue
-            out[var] = np.ascontiguousarray(reader.get_tensor(key), dtype=np.float32).reshape(tuple(shp) if kind != "wsm" else ())
+            out[var] = np.ascontiguousarray(reader.get_tensor(key, verify_crc), dtype=np.float32).reshape(tuple(shp) if kind != "wsm" else ())
     return out
 
 

@@ -36,26 +36,27 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocArgs a) {
   const int y = (int)((gid / a.W) % a.H);
   const int n = (int)(gid / ((int64_t)a.W * a.H));
   float* o = a.out + (size_t)gid * 3;
-  if (y >= a.sh || x >= a.sw) {
+  const PreGeo g = a.geo[n];                    // (uniform per image: one 40-byte scalar load for most waves)
+  if (y >= g.sh || x >= g.sw) {
     o[0] = 0.f; o[1] = 0.f; o[2] = 0.f;
     return;
   }
-  const uint8_t* img = a.in + (size_t)n * a.h * a.w * 3;
-  if (a.sh == a.h && a.sw == a.w) {
-    const uint8_t* p = img + ((size_t)y * a.w + x) * 3;
+  const uint8_t* img = a.in + g.off;
+  if (g.sh == g.h && g.sw == g.w) {
+    const uint8_t* p = img + ((size_t)y * g.w + x) * 3;
     for (int c = 0; c < 3; ++c) o[c] = norm_px(p, c, a);
     return;
   }
-  const float fy = ((float)y + 0.5f) * a.scale_y - 0.5f;
-  const float fx = ((float)x + 0.5f) * a.scale_x - 0.5f;
+  const float fy = ((float)y + 0.5f) * g.scale_y - 0.5f;
+  const float fx = ((float)x + 0.5f) * g.scale_x - 0.5f;
   const float fly = floorf(fy), flx = floorf(fx);
-  const int ylo = (int)fmaxf(fly, 0.f), yhi = min((int)ceilf(fy), a.h - 1);
-  const int xlo = (int)fmaxf(flx, 0.f), xhi = min((int)ceilf(fx), a.w - 1);
+  const int ylo = (int)fmaxf(fly, 0.f), yhi = min((int)ceilf(fy), g.h - 1);
+  const int xlo = (int)fmaxf(flx, 0.f), xhi = min((int)ceilf(fx), g.w - 1);
   const float ly = fy - fly, lx = fx - flx;
-  const uint8_t* ptl = img + ((size_t)ylo * a.w + xlo) * 3;
-  const uint8_t* ptr = img + ((size_t)ylo * a.w + xhi) * 3;
-  const uint8_t* pbl = img + ((size_t)yhi * a.w + xlo) * 3;
-  const uint8_t* pbr = img + ((size_t)yhi * a.w + xhi) * 3;
+  const uint8_t* ptl = img + ((size_t)ylo * g.w + xlo) * 3;
+  const uint8_t* ptr = img + ((size_t)ylo * g.w + xhi) * 3;
+  const uint8_t* pbl = img + ((size_t)yhi * g.w + xlo) * 3;
+  const uint8_t* pbr = img + ((size_t)yhi * g.w + xhi) * 3;
   for (int c = 0; c < 3; ++c) {
     const float tl = norm_px(ptl, c, a), tr = norm_px(ptr, c, a);
     const float bl = norm_px(pbl, c, a), br = norm_px(pbr, c, a);
@@ -2121,11 +2122,13 @@ static void coop_launch(const NmsArgs& a, const float* scores, unsigned long lon
   }
 }
 
-// false = not launched (grid not co-resident on this device, or the runtime refused): the caller uses the grid version
-bool launch_nms_coop(const NmsArgs& a, const float* scores, unsigned long long* slots, int* err, hipStream_t s) {
-  if (a.segs != 1 || a.M > 128 || a.K < 1 || a.n_img <= 0) return false;
+// 1 = launched; 0 = a problem outside this kernel's domain (segmented candidates, more than 128 outputs, nothing to do);
+// -1 = wanted but NOT launched (the capacity query failed, the grid is not co-resident on this device, more candidates than
+// COOP_MAX_BPI blocks hold, or the runtime refused): the caller falls back to the slower versions and counts it.
+int launch_nms_coop(const NmsArgs& a, const float* scores, unsigned long long* slots, int* err, hipStream_t s) {
+  if (a.segs != 1 || a.M > 128 || a.K < 1 || a.n_img <= 0) return 0;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
   // Candidates per thread (IPT).  An epoch is latency-bound - three scans of the block's candidates, two grid-wide steps -
   // so a small batch is spread over more, shorter blocks: the smallest IPT with which every block of the launch still has
   // a CU to itself; a batch that fills the device anyway takes 32 (fewest blocks per problem, most problems per launch).
@@ -2151,7 +2154,7 @@ bool launch_nms_coop(const NmsArgs& a, const float* scores, unsigned long long* 
   static const bool dbg = getenv("UDA_NMS_DEBUG") != nullptr;
   if (!ipt || bpi > capacity) {
     if (dbg) fprintf(stderr, "[uda] cooperative NMS: %d blocks per problem > capacity %d\n", bpi, capacity);
-    return false;
+    return -1;
   }
   const int per = capacity / bpi;          // problems per launch: more problems than the device holds run in consecutive grids
   hipMemsetAsync(slots, 0, (size_t)a.n_img * a.M * 2 * bpi * sizeof(unsigned long long), s);
@@ -2169,7 +2172,7 @@ bool launch_nms_coop(const NmsArgs& a, const float* scores, unsigned long long* 
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     if (dbg) fprintf(stderr, "[uda] cooperative NMS: launch refused: %s\n", hipGetErrorString(e));
-    return false;
+    return -1;
   }
   if (dbg) fprintf(stderr, "[uda] cooperative NMS: %d problems x %d blocks of %d candidates per thread (capacity %d)\n", a.n_img, bpi, ipt, capacity);
 #ifdef UDA_NMS_STATS
@@ -2192,7 +2195,7 @@ bool launch_nms_coop(const NmsArgs& a, const float* scores, unsigned long long* 
                        (double)h[4] / h2[1], (double)h[5] / h2[1], (double)h[6] / h2[1], (double)h[7] / h2[1], (double)h2[0] / h2[1], h2[1]);
   }
 #endif
-  return true;
+  return 1;
 }
 
 // ------------------------------------------------------------------------------------ NMS on a score prefix

@@ -451,6 +451,35 @@ __device__ __forceinline__ void et_read(float* dst, const float* er, int jj) {
   }
 }
 
+// 8 consecutive channels of a pixel -> PARTS bf16 pieces (piece p = round-to-nearest bf16 of what pieces 0..p-1 left over)
+template <int PARTS>
+__device__ __forceinline__ void split_parts(const float4& v0, const float4& v1, bf16x8* out) {
+  float r0 = v0.x, r1 = v0.y, r2 = v0.z, r3 = v0.w, r4 = v1.x, r5 = v1.y, r6 = v1.z, r7 = v1.w;
+#pragma unroll
+  for (int p = 0; p < PARTS; ++p) {
+    const unsigned u0 = pack_bf16(r0, r1), u1 = pack_bf16(r2, r3), u2 = pack_bf16(r4, r5), u3 = pack_bf16(r6, r7);
+    out[p] = __builtin_bit_cast(bf16x8, make_uint4(u0, u1, u2, u3));
+    if (p + 1 < PARTS) {
+      r0 -= bf16_lo_f32(u0); r1 -= bf16_hi_f32(u0); r2 -= bf16_lo_f32(u1); r3 -= bf16_hi_f32(u1);
+      r4 -= bf16_lo_f32(u2); r5 -= bf16_hi_f32(u2); r6 -= bf16_lo_f32(u3); r7 -= bf16_hi_f32(u3);
+    }
+  }
+}
+// the significant cross terms of (sum a[i]) x (sum b[j]), smallest first: PARTS = 2 -> a1 b0 + a0 b1 + a0 b0 (~2^-17 per
+// product), PARTS = 3 -> + a2 b0 + a0 b2 + a1 b1 in front (~2^-24: float32-equivalent, UDA_PW_TERMS=6)
+template <int PARTS>
+__device__ __forceinline__ f32x16 mfma_terms(const bf16x8* a, const bf16x8* b, f32x16 acc) {
+  if constexpr (PARTS == 3) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+  }
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+  return acc;
+}
+
 namespace {
 struct MbxCfgB { int th, tw; };
 __host__ __device__ constexpr MbxCfgB mbxb_cfg(int k, int s) {
@@ -484,11 +513,14 @@ __host__ __device__ constexpr MbxCfgB mbxb_cfg(int k, int s) {
 #ifndef UDA_MBXB_WK_LDS
 #define UDA_MBXB_WK_LDS 1
 #endif
+// Three pieces per operand (PARTS = 3, six cross terms, UDA_PW_TERMS=6): half as many operand fragments again per wave, so a
+// block per CU less than the three-term variant.
 #ifndef UDA_MBXB_MINW
-#define UDA_MBXB_MINW(K, S, KSF) ((KSF) <= 2 ? ((K) == 3 ? 4 : 3) : (((KSF) <= 3 && ((K) == 3 ? (S) == 2 : UDA_MBXB_WK_LDS)) ? 3 : 2))
+#define UDA_MBXB_MINW(K, S, KSF, PARTS) ((PARTS) == 3 ? (((KSF) <= 2 && (K) == 3) ? 3 : 2) : \
+    ((KSF) <= 2 ? ((K) == 3 ? 4 : 3) : (((KSF) <= 3 && ((K) == 3 ? (S) == 2 : UDA_MBXB_WK_LDS)) ? 3 : 2)))
 #endif
-template <int K, int S, int KSF, bool FUSE0>   // KSF = 16-deep MFMA k-steps covering Cin + 1
-__global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(MbxArgs a) {
+template <int K, int S, int KSF, bool FUSE0, int PARTS>   // KSF = 16-deep MFMA k-steps covering Cin + 1
+__global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF, PARTS)) void mbxb_kernel(MbxArgs a) {
   constexpr int NW = 4;
   constexpr int TH = mbxb_cfg(K, S).th, TW = mbxb_cfg(K, S).tw;
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
@@ -514,8 +546,8 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
   constexpr int NPAR = (K * K + 2) * 32;      // per slab: depthwise taps [K*K][32] | BN scale | BN shift (host-packed, a.wpar)
   float* par = red + NG * 32;                 // [2][NPAR]
   constexpr bool B_LDS = KSF <= 2;            // packed expand weights of a slab: LDS image (else registers, one slab ahead)
-  constexpr int BSLAB = KSF * 2 * 64;         // uint4 per slab of packed expand weights
-  uint4* Bs = (uint4*)(par + 2 * NPAR);       // [KSF][2 parts][64 lanes]: rewritten between the two barriers of a slab
+  constexpr int BSLAB = KSF * PARTS * 64;     // uint4 per slab of packed expand weights
+  uint4* Bs = (uint4*)(par + 2 * NPAR);       // [KSF][PARTS][64 lanes]: rewritten between the two barriers of a slab
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -543,18 +575,8 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
   const int cin_mem = FUSE0 ? a.c0 : a.Cin;   // channels of the tensor that is actually read
   const float* xin = a.in + (size_t)b_in * a.H * a.W * cin_mem;
 
-  auto split8 = [](const float4& v0, const float4& v1, bf16x8& hi, bf16x8& lo) {
-    const unsigned h0 = pack_bf16(v0.x, v0.y), h1 = pack_bf16(v0.z, v0.w);
-    const unsigned h2 = pack_bf16(v1.x, v1.y), h3 = pack_bf16(v1.z, v1.w);
-    const unsigned l0 = pack_bf16(v0.x - bf16_lo_f32(h0), v0.y - bf16_hi_f32(h0));
-    const unsigned l1 = pack_bf16(v0.z - bf16_lo_f32(h1), v0.w - bf16_hi_f32(h1));
-    const unsigned l2 = pack_bf16(v1.x - bf16_lo_f32(h2), v1.y - bf16_hi_f32(h2));
-    const unsigned l3 = pack_bf16(v1.z - bf16_lo_f32(h3), v1.w - bf16_hi_f32(h3));
-    hi = __builtin_bit_cast(bf16x8, make_uint4(h0, h1, h2, h3));
-    lo = __builtin_bit_cast(bf16x8, make_uint4(l0, l1, l2, l3));
-  };
   // FUSE0: A' = W0^T (row = projected channel li) x gate of this sample row, both k-steps of the 32 input channels
-  bf16x8 w0h[2], w0l[2];
+  bf16x8 w0p[2][PARTS];
   float sh0v[8];
   if constexpr (FUSE0) {
     const float* gp = a.gate + (size_t)(b / a.g_div) * a.c0;
@@ -565,14 +587,14 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
       const float4 g0 = *(const float4*)(gp + k), g1 = *(const float4*)(gp + k + 4);
       w0.x *= g0.x; w0.y *= g0.y; w0.z *= g0.z; w0.w *= g0.w;
       w1.x *= g1.x; w1.y *= g1.y; w1.z *= g1.z; w1.w *= g1.w;
-      split8(w0, w1, w0h[ks], w0l[ks]);
+      split_parts<PARTS>(w0, w1, w0p[ks]);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) sh0v[j] = a.sh0f[(j & 3) + 8 * (j >> 2) + 4 * lh];
   }
 
   // ---- this wave's operand fragments: pixel = slice * 32 + li, channels 16 ks + 8 lh .. + 7
-  bf16x8 ah[MTW][KSF], al[MTW][KSF];
+  bf16x8 ap[MTW][KSF][PARTS];
 #pragma unroll
   for (int t = 0; t < MTW; ++t) {
     const int mt = wave + NW * t;
@@ -593,11 +615,9 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
           d0 = *(const float4*)(px + k);
           d1 = *(const float4*)(px + k + 4);
         }
-        bf16x8 dh, dl;
-        split8(d0, d1, dh, dl);
-        xacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0l[ks], dh, xacc, 0, 0, 0);
-        xacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0h[ks], dl, xacc, 0, 0, 0);
-        xacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0h[ks], dh, xacc, 0, 0, 0);
+        bf16x8 dp[PARTS];
+        split_parts<PARTS>(d0, d1, dp);
+        xacc = mfma_terms<PARTS>(w0p[ks], dp, xacc);
       }
       // registers 0..7 = channels (j & 3) + 8 (j >> 2) + 4 lh of pixel li: BN shift, zero outside the image
       float4 v0, v1;
@@ -605,9 +625,9 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
       v0.z = in ? xacc[2] + sh0v[2] : 0.f; v0.w = in ? xacc[3] + sh0v[3] : 0.f;
       v1.x = in ? xacc[4] + sh0v[4] : 0.f; v1.y = in ? xacc[5] + sh0v[5] : 0.f;
       v1.z = in ? xacc[6] + sh0v[6] : 0.f; v1.w = in ? xacc[7] + sh0v[7] : 0.f;
-      split8(v0, v1, ah[t][0], al[t][0]);
+      split_parts<PARTS>(v0, v1, ap[t][0]);
       float4 f0 = make_float4((lh == 0 && in) ? 1.f : 0.f, 0.f, 0.f, 0.f), f1 = make_float4(0.f, 0.f, 0.f, 0.f);
-      split8(f0, f1, ah[t][1], al[t][1]);       // k-step 1: only the "inside the image" channel
+      split_parts<PARTS>(f0, f1, ap[t][1]);     // k-step 1: only the "inside the image" channel
       continue;
     }
 #pragma unroll
@@ -619,14 +639,7 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
         v1 = *(const float4*)(px + k + 4);
       }
       if (k == a.Cin) v0.x = in ? 1.f : 0.f;          // the "inside the image" channel that carries the BN shift
-      const unsigned h0 = pack_bf16(v0.x, v0.y), h1 = pack_bf16(v0.z, v0.w);
-      const unsigned h2 = pack_bf16(v1.x, v1.y), h3 = pack_bf16(v1.z, v1.w);
-      const unsigned l0 = pack_bf16(v0.x - bf16_lo_f32(h0), v0.y - bf16_hi_f32(h0));
-      const unsigned l1 = pack_bf16(v0.z - bf16_lo_f32(h1), v0.w - bf16_hi_f32(h1));
-      const unsigned l2 = pack_bf16(v1.x - bf16_lo_f32(h2), v1.y - bf16_hi_f32(h2));
-      const unsigned l3 = pack_bf16(v1.z - bf16_lo_f32(h3), v1.w - bf16_hi_f32(h3));
-      ah[t][ks] = __builtin_bit_cast(bf16x8, make_uint4(h0, h1, h2, h3));
-      al[t][ks] = __builtin_bit_cast(bf16x8, make_uint4(l0, l1, l2, l3));
+      split_parts<PARTS>(v0, v1, ap[t][ks]);
     }
   }
 
@@ -663,22 +676,21 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
   constexpr int P_PER = (NPAR + 255) / 256;
   constexpr int B_PER = (BSLAB + 255) / 256;
   auto b_src = [&](int ch, int f) -> const uint4* {       // element f of slab ch in the [ks][part][lane] image
-    const int ks = f >> 7, rest = f & 127;
-    return Wp + (((size_t)ks * NCH + ch) * 2 + (rest >> 6)) * 64 + (rest & 63);
+    const int ks = f / (PARTS * 64), rest = f - ks * (PARTS * 64);
+    return Wp + (((size_t)ks * NCH + ch) * PARTS + (rest >> 6)) * 64 + (rest & 63);
   };
   constexpr int KR = B_LDS ? 1 : KSF;         // register copies (B_LDS: unused)
-  uint4 rbh[KR], rbl[KR], nbh[KR], nbl[KR];
-  auto load_regs = [&](int ch, uint4* h, uint4* l) {
+  uint4 rb[KR][PARTS], nbr[KR][PARTS];
+  auto load_regs = [&](int ch, uint4 (*dst)[PARTS]) {
 #pragma unroll
-    for (int ks = 0; ks < KR; ++ks) {
-      h[ks] = Wp[(((size_t)ks * NCH + ch) * 2 + 0) * 64 + lane];
-      l[ks] = Wp[(((size_t)ks * NCH + ch) * 2 + 1) * 64 + lane];
-    }
+    for (int ks = 0; ks < KR; ++ks)
+#pragma unroll
+      for (int p_ = 0; p_ < PARTS; ++p_) dst[ks][p_] = Wp[(((size_t)ks * NCH + ch) * PARTS + p_) * 64 + lane];
   };
   if constexpr (B_LDS) {
     for (int f = tid; f < BSLAB; f += 256) Bs[f] = *b_src(0, f);
   } else {
-    load_regs(0, rbh, rbl);
+    load_regs(0, rb);
   }
   for (int f = tid; f < NPAR; f += 256) par[f] = a.wpar[f];
   auto mask_at = [&](const float* m, int ch) -> float {   // keep-scale x (-ln 2) of channel 32 ch + c (c == li) of this sample row
@@ -706,7 +718,7 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
         nb[i] = *b_src(chn, f < BSLAB ? f : 0);
       }
     } else {
-      load_regs(chn, nbh, nbl);
+      load_regs(chn, nbr);
     }
     float np_[P_PER];
     const float* wnext = a.wpar + (size_t)chn * NPAR;
@@ -718,17 +730,14 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
     mk0n = mask_at(a.mask0, chn);
     mk1n = mask_at(a.mask1, chn);
     // this slab's weight fragments: one LDS image for the block, read once per wave and used for both of its slices
-    bf16x8 bh[KSF], bl[KSF];
+    bf16x8 bp[KSF][PARTS];
 #pragma unroll
-    for (int ks = 0; ks < KSF; ++ks) {
-      if constexpr (B_LDS) {
-        bh[ks] = __builtin_bit_cast(bf16x8, Bs[(ks * 2 + 0) * 64 + lane]);
-        bl[ks] = __builtin_bit_cast(bf16x8, Bs[(ks * 2 + 1) * 64 + lane]);
-      } else {
-        bh[ks] = __builtin_bit_cast(bf16x8, rbh[ks < KR ? ks : 0]);
-        bl[ks] = __builtin_bit_cast(bf16x8, rbl[ks < KR ? ks : 0]);
+    for (int ks = 0; ks < KSF; ++ks)
+#pragma unroll
+      for (int p_ = 0; p_ < PARTS; ++p_) {
+        if constexpr (B_LDS) bp[ks][p_] = __builtin_bit_cast(bf16x8, Bs[(ks * PARTS + p_) * 64 + lane]);
+        else bp[ks][p_] = __builtin_bit_cast(bf16x8, rb[ks < KR ? ks : 0][p_]);
       }
-    }
     // ---- expand: E[p][j] = swish(sum_k X[p][k] We'[k][32 ch + j]) / (-ln 2)   (dropout scale: after the depthwise)
 #pragma unroll
     for (int t = 0; t < MTW; ++t) {
@@ -738,11 +747,7 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < KSF; ++ks) {
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t][ks], bh[ks], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t][ks], bl[ks], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t][ks], bh[ks], acc, 0, 0, 0);
-        }
+        for (int ks = 0; ks < KSF; ++ks) acc = mfma_terms<PARTS>(ap[t][ks], bp[ks], acc);
         if constexpr (ET) {
           et_store_slice<ETW>(E + li * CP + mt * 32 + 4 * lh, acc);
         } else {
@@ -766,8 +771,9 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
       } else {
 #pragma unroll
         for (int ks = 0; ks < KR; ++ks)
-          asm volatile("" : "+v"(nbh[ks].x), "+v"(nbh[ks].y), "+v"(nbh[ks].z), "+v"(nbh[ks].w),
-                            "+v"(nbl[ks].x), "+v"(nbl[ks].y), "+v"(nbl[ks].z), "+v"(nbl[ks].w));
+#pragma unroll
+          for (int p_ = 0; p_ < PARTS; ++p_)
+            asm volatile("" : "+v"(nbr[ks][p_].x), "+v"(nbr[ks][p_].y), "+v"(nbr[ks][p_].z), "+v"(nbr[ks][p_].w));
       }
       float* pnext = par + ((ch + 1) & 1) * NPAR;
 #pragma unroll
@@ -852,7 +858,9 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF)) void mbxb_kernel(Mbx
     mk1 = mk1n;
     if constexpr (!B_LDS) {
 #pragma unroll
-      for (int ks = 0; ks < KR; ++ks) { rbh[ks] = nbh[ks]; rbl[ks] = nbl[ks]; }
+      for (int ks = 0; ks < KR; ++ks)
+#pragma unroll
+        for (int p_ = 0; p_ < PARTS; ++p_) rb[ks][p_] = nbr[ks][p_];
     }
   }
 }
@@ -866,13 +874,13 @@ bool mbxb_supported(int Cin, int Cmid, int k, int stride) {
   return Cin % 8 == 0 && Cin >= 16 && Cin <= 48 && Cmid % 4 == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2);
 }
 
-template <int K, int S, int KSF>
+template <int K, int S, int KSF, int PARTS>
 static void launch_mbxb_t(const MbxArgs& a, int rows, hipStream_t s) {
   constexpr int TH = mbxb_cfg(K, S).th, TW = mbxb_cfg(K, S).tw;
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
   constexpr int NPP = (IH * IW + 31) / 32 * 32;
   const size_t lds = ((mbx_et_w(K, S) ? (size_t)32 * mbx_et_pitch(mbx_et_w(K, S)) : (size_t)NPP * 32) + 8 * 32 + 2 * (K * K + 2) * 32) * sizeof(float) +
-                     (size_t)KSF * 2 * 64 * sizeof(uint4);
+                     (size_t)KSF * PARTS * 64 * sizeof(uint4);
   dim3 grid((a.Wo + TW - 1) / TW, (a.Ho + TH - 1) / TH, rows);
   MbxArgs b = a;
   static int remap = -1;
@@ -887,25 +895,32 @@ static void launch_mbxb_t(const MbxArgs& a, int rows, hipStream_t s) {
     }
   }
   if constexpr (KSF == 2) {
-    if (a.gate) { hipLaunchKernelGGL((mbxb_kernel<K, S, KSF, true>), grid, dim3(256), lds, s, b); return; }
+    if (a.gate) { hipLaunchKernelGGL((mbxb_kernel<K, S, KSF, true, PARTS>), grid, dim3(256), lds, s, b); return; }
   }
-  hipLaunchKernelGGL((mbxb_kernel<K, S, KSF, false>), grid, dim3(256), lds, s, b);
+  hipLaunchKernelGGL((mbxb_kernel<K, S, KSF, false, PARTS>), grid, dim3(256), lds, s, b);
 }
 
-template <int K, int S>
+template <int K, int S, int PARTS>
 static void launch_mbxb_ks(const MbxArgs& a, int rows, hipStream_t s) {
   switch ((a.Cin + 1 + 15) / 16) {
-    case 2: launch_mbxb_t<K, S, 2>(a, rows, s); break;
-    case 3: launch_mbxb_t<K, S, 3>(a, rows, s); break;
-    default: launch_mbxb_t<K, S, 4>(a, rows, s); break;
+    case 2: launch_mbxb_t<K, S, 2, PARTS>(a, rows, s); break;
+    case 3: launch_mbxb_t<K, S, 3, PARTS>(a, rows, s); break;
+    default: launch_mbxb_t<K, S, 4, PARTS>(a, rows, s); break;
   }
 }
 
+template <int PARTS>
+static void launch_mbxb_p(const MbxArgs& a, int rows, int k, int stride, hipStream_t s) {
+  if (k == 3 && stride == 1) launch_mbxb_ks<3, 1, PARTS>(a, rows, s);
+  else if (k == 3 && stride == 2) launch_mbxb_ks<3, 2, PARTS>(a, rows, s);
+  else if (k == 5 && stride == 1) launch_mbxb_ks<5, 1, PARTS>(a, rows, s);
+  else launch_mbxb_ks<5, 2, PARTS>(a, rows, s);
+}
+
+// a.wparts: bf16 pieces per operand in the packed expand weights (2 = three cross terms, 3 = six: UDA_PW_TERMS=6)
 void launch_mbxb(const MbxArgs& a, int rows, int k, int stride, hipStream_t s) {
-  if (k == 3 && stride == 1) launch_mbxb_ks<3, 1>(a, rows, s);
-  else if (k == 3 && stride == 2) launch_mbxb_ks<3, 2>(a, rows, s);
-  else if (k == 5 && stride == 1) launch_mbxb_ks<5, 1>(a, rows, s);
-  else launch_mbxb_ks<5, 2>(a, rows, s);
+  if (a.wparts == 3) launch_mbxb_p<3>(a, rows, k, stride, s);
+  else launch_mbxb_p<2>(a, rows, k, stride, s);
 }
 
 // ---------------------------------------------------------------- fused MBConv front half, deep blocks
@@ -918,9 +933,9 @@ void launch_mbxb(const MbxArgs& a, int rows, int k, int stride, hipStream_t s) {
 // blocks per CU = at most 128 VGPRs.  The 5x5 variants with up to 8 k-steps fit that once the 25 depthwise taps are read
 // from LDS at their use instead of living in registers; with two blocks per CU the expand phase of one block (MFMA +
 // transcendentals) overlaps the depthwise phase of the other (FMA + LDS) - with one block both phases run in lockstep.)
-template <int K, int KSF>
-__global__ __launch_bounds__(512, (KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a) {
-  constexpr bool WK_LDS = (K == 5 && KSF <= 8);
+template <int K, int KSF, int PARTS>
+__global__ __launch_bounds__(512, (KSF <= 8 && PARTS == 2) ? 4 : 2) void mbxd_kernel(MbxArgs a) {
+  constexpr bool WK_LDS = (K == 5 && (KSF <= 8 || PARTS == 3));     // the 25 taps from LDS at their use, not 25 registers
 
   constexpr int NW = 8;
   constexpr int TH = (K == 3) ? 12 : 8, TW = 16;
@@ -937,7 +952,7 @@ __global__ __launch_bounds__(512, (KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a
   constexpr int UPR = TW / XW;                // units per output row
   constexpr int NUNIT = TH * UPR;             // 48 (3x3) / 16 (5x5) units over 16 groups
   constexpr int NCOL = XW + K - 1;
-  constexpr int BSLAB = KSF * 2 * 64;         // uint4 per slab of packed expand weights
+  constexpr int BSLAB = KSF * PARTS * 64;     // uint4 per slab of packed expand weights
   extern __shared__ __attribute__((aligned(16))) float dlds[];
   float* E = dlds;                            // [NPP][ES]
   float* red = E + (size_t)NPP * ES;          // [NG][32]
@@ -965,8 +980,8 @@ __global__ __launch_bounds__(512, (KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a
   // HBM round trip.  The loads are plain and branch-free so that no wait is placed right behind them.
   // ---- slab 0 operands -> LDS buffers 0
   for (int f = tid; f < BSLAB; f += 512) {
-    const int ks = f >> 7, rest = f & 127;     // [ks][part][lane]
-    Bs[f] = Wp[(((size_t)ks * NCH + chb) * 2 + (rest >> 6)) * 64 + (rest & 63)];
+    const int ks = f / (PARTS * 64), rest = f - ks * (PARTS * 64);     // [ks][part][lane]
+    Bs[f] = Wp[(((size_t)ks * NCH + chb) * PARTS + (rest >> 6)) * 64 + (rest & 63)];
   }
   for (int f = tid; f < NPAR; f += 512) par[f] = a.wpar[(size_t)chb * NPAR + f];
   for (int f = tid; f < 2 * 32 * NCH; f += 512) {
@@ -976,7 +991,7 @@ __global__ __launch_bounds__(512, (KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a
   }
 
   // ---- this wave's operand fragments: pixel = wave * 32 + li, channels 16 ks + 8 lh .. + 7
-  bf16x8 ah[KSF], al[KSF];
+  bf16x8 ap[KSF][PARTS];
   {
     const int p = wave * 32 + li;
     const int iy = iy0 + p / IW, ix = ix0 + p % IW;
@@ -991,14 +1006,7 @@ __global__ __launch_bounds__(512, (KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a
         v1 = *(const float4*)(px + k + 4);
       }
       if (k == a.Cin) v0.x = in ? 1.f : 0.f;          // the "inside the image" channel that carries the BN shift
-      const unsigned h0 = pack_bf16(v0.x, v0.y), h1 = pack_bf16(v0.z, v0.w);
-      const unsigned h2 = pack_bf16(v1.x, v1.y), h3 = pack_bf16(v1.z, v1.w);
-      const unsigned l0 = pack_bf16(v0.x - bf16_lo_f32(h0), v0.y - bf16_hi_f32(h0));
-      const unsigned l1 = pack_bf16(v0.z - bf16_lo_f32(h1), v0.w - bf16_hi_f32(h1));
-      const unsigned l2 = pack_bf16(v1.x - bf16_lo_f32(h2), v1.y - bf16_hi_f32(h2));
-      const unsigned l3 = pack_bf16(v1.z - bf16_lo_f32(h3), v1.w - bf16_hi_f32(h3));
-      ah[ks] = __builtin_bit_cast(bf16x8, make_uint4(h0, h1, h2, h3));
-      al[ks] = __builtin_bit_cast(bf16x8, make_uint4(l0, l1, l2, l3));
+      split_parts<PARTS>(v0, v1, ap[ks]);
     }
   }
   __syncthreads();
@@ -1035,9 +1043,9 @@ __global__ __launch_bounds__(512, (KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {      // (guarded loads measured 6 % faster than clamped unconditional ones here)
       const int f = tid + 512 * i;
-      const int ks = f >> 7, rest = f & 127;
+      const int ks = f / (PARTS * 64), rest = f - ks * (PARTS * 64);
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (more && f < BSLAB) v = Wp[(((size_t)ks * NCH + (ch + 1)) * 2 + (rest >> 6)) * 64 + (rest & 63)];
+      if (more && f < BSLAB) v = Wp[(((size_t)ks * NCH + (ch + 1)) * PARTS + (rest >> 6)) * 64 + (rest & 63)];
       nb[i] = v;
     }
     constexpr int P_PER = (NPAR + 511) / 512;
@@ -1055,11 +1063,10 @@ __global__ __launch_bounds__(512, (KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < KSF; ++ks) {
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, bcur[(ks * 2 + 0) * 64 + lane]);
-        const bf16x8 bl = __builtin_bit_cast(bf16x8, bcur[(ks * 2 + 1) * 64 + lane]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh, acc, 0, 0, 0);
+        bf16x8 bp[PARTS];
+#pragma unroll
+        for (int p_ = 0; p_ < PARTS; ++p_) bp[p_] = __builtin_bit_cast(bf16x8, bcur[(ks * PARTS + p_) * 64 + lane]);
+        acc = mfma_terms<PARTS>(ap[ks], bp, acc);
       }
       if constexpr (ET) {
         et_store_slice<ETW>(E + li * CP + wave * 32 + 4 * lh, acc);
@@ -1106,7 +1113,7 @@ __global__ __launch_bounds__(512, (KSF <= 8) ? 4 : 2) void mbxd_kernel(MbxArgs a
 #pragma unroll
         for (int o = 0; o < XW; ++o) acc[o] = 0.f;
         const float* eu = E + eoff[ui];
-        constexpr int KYU = (K == 5 && KSF <= 8) ? 1 : K;     // (a fully unrolled tap-row loop hoists all 25 LDS tap reads back into registers)
+        constexpr int KYU = WK_LDS ? 1 : K;     // (a fully unrolled tap-row loop hoists all 25 LDS tap reads back into registers)
 #pragma unroll KYU
         for (int ky = 0; ky < K; ++ky) {
           float rowv[NCOL];
@@ -1520,47 +1527,56 @@ int mbxd_tiles(int Ho, int Wo, int k) {
   return ((Ho + th - 1) / th) * ((Wo + 15) / 16);
 }
 
-template <int K, int KSF>
+template <int K, int KSF, int PARTS>
 static void launch_mbxd_t(const MbxArgs& a, int rows, hipStream_t s) {
   constexpr int TH = (K == 3) ? 12 : 8;
   const size_t lds = ((size_t)256 * 33 + 16 * 32 + 2 * (K * K + 2) * 32 + 2 * 32 * ((a.Cmid + 31) / 32)) * sizeof(float) +
-                     (size_t)KSF * 2 * 64 * sizeof(uint4);
+                     (size_t)KSF * PARTS * 64 * sizeof(uint4);
   static size_t attr_lds = 64 * 1024;      // above the default limit the kernel needs an explicit opt-in
   if (lds > attr_lds) {
-    hipFuncSetAttribute((const void*)mbxd_kernel<K, KSF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)mbxd_kernel<K, KSF, PARTS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_lds = lds;
   }
   dim3 grid((a.Wo + 15) / 16, (a.Ho + TH - 1) / TH, rows);
   MbxArgs b = a;
-  b.ch_groups = mbx_ch_groups((long long)grid.x * grid.y * rows, KSF <= 8 ? 2 : 1, (a.Cmid + 31) / 32);
+  b.ch_groups = mbx_ch_groups((long long)grid.x * grid.y * rows, (KSF <= 8 && PARTS == 2) ? 2 : 1, (a.Cmid + 31) / 32);
   grid.z = (unsigned)(rows * b.ch_groups);
-  hipLaunchKernelGGL((mbxd_kernel<K, KSF>), grid, dim3(512), lds, s, b);
+  hipLaunchKernelGGL((mbxd_kernel<K, KSF, PARTS>), grid, dim3(512), lds, s, b);
+}
+
+template <int PARTS>
+static void launch_mbxd_p(const MbxArgs& a, int rows, int k, int ksf, hipStream_t s) {
+  if (k == 3) {
+    switch (ksf) {
+      case 6: launch_mbxd_t<3, 6, PARTS>(a, rows, s); break;
+      case 8: launch_mbxd_t<3, 8, PARTS>(a, rows, s); break;
+      case 13: launch_mbxd_t<3, 13, PARTS>(a, rows, s); break;
+      default: launch_mbxd_t<3, 14, PARTS>(a, rows, s); break;
+    }
+  } else {
+    switch (ksf) {
+      case 6: launch_mbxd_t<5, 6, PARTS>(a, rows, s); break;
+      case 8: launch_mbxd_t<5, 8, PARTS>(a, rows, s); break;
+      case 13: launch_mbxd_t<5, 13, PARTS>(a, rows, s); break;
+      default: launch_mbxd_t<5, 14, PARTS>(a, rows, s); break;
+    }
+  }
 }
 
 void launch_mbxd(const MbxArgs& a, int rows, int k, hipStream_t s) {
   const int ksf = (a.Cin + 1 + 15) / 16;
   static int pipe = -1;
   if (pipe < 0) { const char* e = getenv("UDA_MBXP"); pipe = e ? atoi(e) : 1; }
+  if (a.wparts == 3) {              // six cross terms (UDA_PW_TERMS=6): three pieces per operand, the two-phase kernel
+    launch_mbxd_p<3>(a, rows, k, ksf, s);
+    return;
+  }
   if (pipe && ksf >= 13) {          // one block per CU anyway: the self-overlapping variant
     if (k == 3) { if (ksf == 13) launch_mbxp_t<3, 13>(a, rows, s); else launch_mbxp_t<3, 14>(a, rows, s); }
     else { if (ksf == 13) launch_mbxp_t<5, 13>(a, rows, s); else launch_mbxp_t<5, 14>(a, rows, s); }
     return;
   }
-  if (k == 3) {
-    switch (ksf) {
-      case 6: launch_mbxd_t<3, 6>(a, rows, s); break;
-      case 8: launch_mbxd_t<3, 8>(a, rows, s); break;
-      case 13: launch_mbxd_t<3, 13>(a, rows, s); break;
-      default: launch_mbxd_t<3, 14>(a, rows, s); break;
-    }
-  } else {
-    switch (ksf) {
-      case 6: launch_mbxd_t<5, 6>(a, rows, s); break;
-      case 8: launch_mbxd_t<5, 8>(a, rows, s); break;
-      case 13: launch_mbxd_t<5, 13>(a, rows, s); break;
-      default: launch_mbxd_t<5, 14>(a, rows, s); break;
-    }
-  }
+  launch_mbxd_p<2>(a, rows, k, ksf, s);
 }
 
 // depthwise-side operands of the fused kernels, one contiguous block per 32-channel slab:
@@ -1580,10 +1596,10 @@ void mbx_pack_params(const float* wd, const float* sc1, const float* sh1, int Cm
 }
 
 // expand kernel [Cin][Cmid] times the BN scale, plus the BN shift as row Cin -> packed split-bf16 fragments
-size_t mbxb_packed_elems(int Cin, int Cmid) { return pwb_packed_elems(Cin + 1, Cmid, 2); }
+size_t mbxb_packed_elems(int Cin, int Cmid, int parts) { return pwb_packed_elems(Cin + 1, Cmid, parts); }
 // perm16: rows 0..15 stored in the k order of an accumulator tile used as the A operand (FUSE0): slot 8 h + j holds
 // channel (j & 3) + 8 (j >> 2) + 4 h
-void mbxb_pack_weights(const float* we, const float* sc0, const float* sh0, int Cin, int Cmid, uint16_t* out, bool perm16) {
+void mbxb_pack_weights(const float* we, const float* sc0, const float* sh0, int Cin, int Cmid, uint16_t* out, bool perm16, int parts) {
   float* w = (float*)malloc((size_t)(Cin + 1) * Cmid * sizeof(float));
   // the GEMM delivers y = -log2(e) * BN(x W): see swish_folded
   const float L = -1.4426950408889634f;
@@ -1598,7 +1614,7 @@ void mbxb_pack_weights(const float* we, const float* sc0, const float* sh0, int 
         memcpy(w + (size_t)(8 * h + j) * Cmid, t + (size_t)((j & 3) + 8 * (j >> 2) + 4 * h) * Cmid, (size_t)Cmid * sizeof(float));
     free(t);
   }
-  pwb_pack_weights(w, Cin + 1, Cmid, 2, out);
+  pwb_pack_weights(w, Cin + 1, Cmid, parts, out);
   free(w);
 }
 

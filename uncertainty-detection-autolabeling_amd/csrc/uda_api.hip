@@ -19,8 +19,9 @@ static thread_local std::string g_create_error;
 
 struct ProfSlot {
   double total_ms = 0;
-  int64_t launches = 0;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  int64_t launches = 0;       // in units of PLANNED ops: a launch that covers a group of n ops counts n (plan.op_costs counts per op)
+  struct Pending { hipEvent_t first, second; int weight; };
+  std::vector<Pending> pending;
 };
 
 struct uda_ctx {
@@ -57,10 +58,25 @@ struct uda_ctx {
   int A_tot = 0;
   int a_off[UDA_MAX_LEVELS + 1];
 
-  // inputs
-  uint8_t* d_u8 = nullptr;
-  size_t u8_cap = 0;
-  int raw_h = 0, raw_w = 0;
+  // inputs.  uint8 batches go through one of two slots (device buffer + pinned host staging buffer each): `cur` feeds the
+  // next uda_run; the other one takes a batch that is uploaded on the copy stream while the current one is being
+  // processed (uda_prefetch_images_u8 / uda_swap_prefetched) - the feed then costs no device time.
+  struct U8Slot {
+    uint8_t* d = nullptr;        // device: geometry table, then the images back to back (image i at d_img + geo[i].off)
+    size_t cap = 0;
+    uint8_t* pinned = nullptr;   // host staging (hipHostMalloc): pageable caller memory is copied here, DMA reads this
+    size_t pcap = 0;
+    int n = 0;
+    bool valid = false, uploaded = false;
+    std::vector<PreGeo> geo;     // per image: offset, raw size, scaled size, sampling ratios (dataloader.py:123-152)
+    PreGeo* d_geo = nullptr;     // = d (the table leads the buffer)
+    uint8_t* d_img = nullptr;    // = d + header
+    std::vector<float> scales;   // image_scale per image (1 / resize scale)
+    hipEvent_t ev = nullptr;     // upload complete (copy stream)
+  } u8[2];
+  int cur = 0;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_pre_done[2] = {nullptr, nullptr};   // the preprocess kernel has consumed slot i (its buffer may be refilled)
   bool have_u8 = false;
   float* d_images = nullptr;   // [max_images, H, W, 3]
   float* d_scales = nullptr;   // [max_images]
@@ -120,6 +136,7 @@ struct uda_ctx {
   bool coop_used = false;
   bool coop_off = false;                           // set after a barrier time-out: this handle stays on the two-launch version
   int64_t coop_fallbacks = 0;                      // post-process runs redone with two launches per epoch after such a time-out
+  int64_t coop_not_launched = 0;                   // NMS runs that wanted the single-launch grid and did not get it (capacity query / launch refused)
   unsigned long long* d_merge_keys = nullptr;
   // outputs
   float *d_oboxes = nullptr, *d_oscores = nullptr, *d_oclasses = nullptr, *d_ologits = nullptr;
@@ -170,7 +187,9 @@ struct ProfScope {
   hipStream_t st;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   bool on;
-  ProfScope(uda_ctx* c_, int kind_, hipStream_t st_ = nullptr) : c(c_), kind(kind_), st(st_ ? st_ : c_->stream) {
+  int weight;
+  ProfScope(uda_ctx* c_, int kind_, hipStream_t st_ = nullptr, int weight_ = 1)
+      : c(c_), kind(kind_), st(st_ ? st_ : c_->stream), weight(weight_) {
     on = (c->prof_mask >> kind) & 1u;
     if (on) {
       hipEventCreate(&e0);
@@ -181,7 +200,7 @@ struct ProfScope {
   ~ProfScope() {
     if (on) {
       hipEventRecord(e1, st);
-      c->prof[kind].pending.emplace_back(e0, e1);
+      c->prof[kind].pending.push_back({e0, e1, weight});
     }
   }
 };
@@ -193,7 +212,7 @@ static void prof_collect(uda_ctx* c, int kind) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
       s.total_ms += ms;
-      s.launches += 1;
+      s.launches += pr.weight;
     }
     hipEventDestroy(pr.first);
     hipEventDestroy(pr.second);
@@ -211,7 +230,15 @@ extern "C" void uda_destroy(uda_ctx_t* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   for (int k = 0; k < 32; ++k) prof_collect(c, k);
-  void* ptrs[] = {c->d_weights, c->d_wsplit, c->d_arena, c->d_anchors, c->d_u8, c->d_images, c->d_scales, c->d_masks,
+  if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
+  for (auto& sl : c->u8) {
+    if (sl.d) hipFree(sl.d);
+    if (sl.pinned) hipHostFree(sl.pinned);
+    if (sl.ev) hipEventDestroy(sl.ev);
+  }
+  for (auto& e : c->ev_pre_done) if (e) hipEventDestroy(e);
+  if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+  void* ptrs[] = {c->d_weights, c->d_wsplit, c->d_arena, c->d_anchors, c->d_images, c->d_scales, c->d_masks,
                   c->d_site_off, c->d_site_ch, c->d_site_rate, c->d_cboxes, c->d_cscores, c->d_clogits,
                   c->d_cclasses, c->d_ucls, c->d_ual, c->d_uep, c->d_clsmean, c->d_cand_flat, c->d_merge_keys,
                   c->d_oboxes, c->d_oscores, c->d_oclasses, c->d_ologits, c->d_ovalid, c->d_oprobs, c->d_oentropy};
@@ -447,11 +474,11 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
           const bool fuse0 = o.se_scale >= 0;      // the previous block's projection is computed in this op's prologue
           const int Ke = fuse0 ? o.se_mid : K;     // input channels of the expand
           // [split expand weights | 16-byte aligned float block of the depthwise-side operands | (fuse0) projection block]
-          const size_t we_elems = (mbxb_packed_elems(Ke, Nn) + 7) / 8 * 8;
+          const size_t we_elems = (mbxb_packed_elems(Ke, Nn, c->pw_parts) + 7) / 8 * 8;
           const size_t par_fl = mbx_par_floats(Nn, o.k);
           const size_t proj_fl = fuse0 ? 32 * 32 + 32 : 0;
           packed.resize(at + we_elems + 2 * (par_fl + proj_fl));
-          mbxb_pack_weights(weights + o.w_off, weights + o.bn_scale_off, weights + o.bn_shift_off, Ke, Nn, packed.data() + at, fuse0);
+          mbxb_pack_weights(weights + o.w_off, weights + o.bn_scale_off, weights + o.bn_shift_off, Ke, Nn, packed.data() + at, fuse0, c->pw_parts);
           std::vector<float> par(par_fl + proj_fl);
           mbx_pack_params(weights + o.w2_off, weights + o.bn2_scale_off, weights + o.bn2_shift_off, Nn, o.k, par.data());
           if (fuse0) mbxb_pack_proj(weights + o.se_w1_off, weights + o.se_b1_off, weights + o.se_w2_off, K, Ke, par.data() + par_fl);
@@ -578,49 +605,145 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
 }
 
 // ------------------------------------------------------------------------------------ inputs
-static int set_scales_for_raw(uda_ctx* c, int n, int h, int w) {
-  // scale = min(H/h, W/w) in float32; scaled size = int(h*scale), int(w*scale)  (dataloader.py:123-135)
-  const float sy = (float)c->model.image_h / (float)h;
-  const float sx = (float)c->model.image_w / (float)w;
+// Per-image geometry of the resize (dataloader.py:123-135): scale = min(H/h, W/w) in float32, scaled size =
+// int(h*scale), int(w*scale), image_scale = 1/scale; the bilinear sampler maps an output pixel with the ratios
+// raw / scaled (half-pixel centres).
+static PreGeo geo_for_raw(const uda_model_t& m, int h, int w, size_t off) {
+  const float sy = (float)m.image_h / (float)h;
+  const float sx = (float)m.image_w / (float)w;
   const float s = sx < sy ? sx : sy;
-  c->sh = (int)((float)h * s);
-  c->sw = (int)((float)w * s);
-  if (c->sh > c->model.image_h) c->sh = c->model.image_h;
-  if (c->sw > c->model.image_w) c->sw = c->model.image_w;
-  for (int i = 0; i < n; ++i) c->h_scales[i] = 1.0f / s;
+  PreGeo g{};
+  g.off = (unsigned long long)off;
+  g.h = h; g.w = w;
+  g.sh = (int)((float)h * s);
+  g.sw = (int)((float)w * s);
+  if (g.sh > m.image_h) g.sh = m.image_h;
+  if (g.sw > m.image_w) g.sw = m.image_w;
+  g.scale_y = (float)h / (float)g.sh;
+  g.scale_x = (float)w / (float)g.sw;
+  g.inv_scale = 1.0f / s;
+  return g;
+}
+
+static int ensure_input_streams(uda_ctx* c) {
+  if (!c->copy_stream) HIPC(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) {
+    if (!c->u8[i].ev) HIPC(c, hipEventCreateWithFlags(&c->u8[i].ev, hipEventDisableTiming));
+    if (!c->ev_pre_done[i]) HIPC(c, hipEventCreateWithFlags(&c->ev_pre_done[i], hipEventDisableTiming));
+  }
   return 0;
 }
 
-static int stage_u8(uda_ctx* c, const void* src, int n, int h, int w, hipMemcpyKind kind) {
-  if (!c) return 1;
+// Fills slot `si` with n images and starts their upload on stream `st`.  `images` (host or device, uniform size) or
+// `ragged` (host pointers, per-image sizes): host bytes are first gathered into the slot's pinned staging buffer, so the
+// DMA never reads pageable memory (a pageable hipMemcpyAsync is a synchronous, chunked copy) and the caller's arrays are
+// free as soon as this returns.
+static int fill_slot(uda_ctx* c, int si, const void* images, const uint8_t* const* ragged, int n, const int32_t* hs, const int32_t* ws,
+                     hipMemcpyKind kind, hipStream_t st) {
   if (n < 1 || n > c->model.max_images) return fail(c, "set_images: n=%d outside [1, %d]", n, c->model.max_images);
-  if (h < 1 || w < 1) return fail(c, "set_images: bad image size %dx%d", h, w);
   HIPC(c, hipSetDevice(c->device));
-  const size_t bytes = (size_t)n * h * w * 3;
-  if (bytes > c->u8_cap) {
-    if (c->d_u8) HIPC(c, hipFree(c->d_u8));
-    c->d_u8 = nullptr;
-    HIPC(c, hipMalloc((void**)&c->d_u8, bytes));
-    c->u8_cap = bytes;
+  if (ensure_input_streams(c)) return 1;
+  uda_ctx::U8Slot& sl = c->u8[si];
+  sl.geo.resize(n);
+  sl.scales.resize(n);
+  size_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    const int h = hs[ragged ? i : 0], w = ws[ragged ? i : 0];
+    if (h < 1 || w < 1) return fail(c, "set_images: bad size %dx%d of image %d", h, w, i);
+    if (ragged && !ragged[i]) return fail(c, "set_images: NULL image %d", i);
+    sl.geo[i] = geo_for_raw(c->model, h, w, total);
+    sl.scales[i] = sl.geo[i].inv_scale;
+    total += (size_t)h * w * 3;
   }
-  HIPC(c, hipMemcpyAsync(c->d_u8, src, bytes, kind, c->stream));
-  c->raw_h = h;
-  c->raw_w = w;
-  c->n_images = n;
+  // the slot's previous batch must have left: its upload done and the preprocess kernel that read it finished
+  HIPC(c, hipEventSynchronize(sl.ev));
+  HIPC(c, hipEventSynchronize(c->ev_pre_done[si]));
+  // device / pinned layout: [geometry table, max_images entries, padded to 256 B][images back to back] - ONE copy moves both
+  const size_t hdr = ((size_t)c->model.max_images * sizeof(PreGeo) + 255) & ~(size_t)255;
+  if (hdr + total > sl.cap) {
+    if (sl.d) HIPC(c, hipFree(sl.d));
+    sl.d = nullptr; sl.cap = 0;
+    HIPC(c, hipMalloc((void**)&sl.d, hdr + total));
+    sl.cap = hdr + total;
+  }
+  sl.d_geo = (PreGeo*)sl.d;
+  sl.d_img = sl.d + hdr;
+  if (kind == hipMemcpyDeviceToDevice) {
+    HIPC(c, hipMemcpyAsync(sl.d_img, images, total, kind, st));
+    HIPC(c, hipMemcpyAsync(sl.d_geo, sl.geo.data(), (size_t)n * sizeof(PreGeo), hipMemcpyHostToDevice, st));
+  } else {
+    if (hdr + total > sl.pcap) {
+      if (sl.pinned) HIPC(c, hipHostFree(sl.pinned));
+      sl.pinned = nullptr; sl.pcap = 0;
+      HIPC(c, hipHostMalloc((void**)&sl.pinned, hdr + total, hipHostMallocDefault));
+      sl.pcap = hdr + total;
+    }
+    memcpy(sl.pinned, sl.geo.data(), (size_t)n * sizeof(PreGeo));
+    if (ragged) {
+      for (int i = 0; i < n; ++i) memcpy(sl.pinned + hdr + sl.geo[i].off, ragged[i], (size_t)sl.geo[i].h * sl.geo[i].w * 3);
+    } else {
+      memcpy(sl.pinned + hdr, images, total);
+    }
+    HIPC(c, hipMemcpyAsync(sl.d, sl.pinned, hdr + total, hipMemcpyHostToDevice, st));
+  }
+  HIPC(c, hipEventRecord(sl.ev, st));
+  sl.n = n;
+  sl.valid = true;
+  return 0;
+}
+
+// Makes slot `si` the input of the next uda_run: the main stream waits for its upload, the image scales follow.
+static int make_current(uda_ctx* c, int si) {
+  uda_ctx::U8Slot& sl = c->u8[si];
+  if (!sl.valid) return fail(c, "no uint8 batch in the input slot");
+  HIPC(c, hipStreamWaitEvent(c->stream, sl.ev, 0));
+  c->cur = si;
+  c->n_images = sl.n;
   c->have_u8 = true;
-  set_scales_for_raw(c, n, h, w);
-  HIPC(c, hipMemcpyAsync(c->d_scales, c->h_scales.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  for (int i = 0; i < sl.n; ++i) c->h_scales[i] = sl.scales[i];
+  HIPC(c, hipMemcpyAsync(c->d_scales, c->h_scales.data(), sl.n * sizeof(float), hipMemcpyHostToDevice, c->stream));
   return 0;
 }
 
 extern "C" int uda_set_images_u8(uda_ctx_t* c, const uint8_t* images, int32_t n, int32_t h, int32_t w) {
   if (!c || !images) return c ? fail(c, "set_images_u8: NULL images") : 1;
-  return stage_u8(c, images, n, h, w, hipMemcpyHostToDevice);
+  const int si = c->cur;
+  const int rc = fill_slot(c, si, images, nullptr, n, &h, &w, hipMemcpyHostToDevice, c->stream);
+  return rc ? rc : make_current(c, si);
 }
 
 extern "C" int uda_set_images_u8_device(uda_ctx_t* c, const void* images_dev, int32_t n, int32_t h, int32_t w) {
   if (!c || !images_dev) return c ? fail(c, "set_images_u8_device: NULL images") : 1;
-  return stage_u8(c, images_dev, n, h, w, hipMemcpyDeviceToDevice);
+  const int si = c->cur;
+  const int rc = fill_slot(c, si, images_dev, nullptr, n, &h, &w, hipMemcpyDeviceToDevice, c->stream);
+  return rc ? rc : make_current(c, si);
+}
+
+extern "C" int uda_set_images_u8_ragged(uda_ctx_t* c, const uint8_t* const* images, int32_t n, const int32_t* h, const int32_t* w) {
+  if (!c || !images || !h || !w) return c ? fail(c, "set_images_u8_ragged: NULL argument") : 1;
+  const int si = c->cur;
+  const int rc = fill_slot(c, si, nullptr, images, n, h, w, hipMemcpyHostToDevice, c->stream);
+  return rc ? rc : make_current(c, si);
+}
+
+extern "C" int uda_prefetch_images_u8(uda_ctx_t* c, const uint8_t* images, int32_t n, int32_t h, int32_t w) {
+  if (!c || !images) return c ? fail(c, "prefetch_images_u8: NULL images") : 1;
+  if (ensure_input_streams(c)) return 1;
+  return fill_slot(c, c->cur ^ 1, images, nullptr, n, &h, &w, hipMemcpyHostToDevice, c->copy_stream);
+}
+
+extern "C" int uda_prefetch_images_u8_ragged(uda_ctx_t* c, const uint8_t* const* images, int32_t n, const int32_t* h, const int32_t* w) {
+  if (!c || !images || !h || !w) return c ? fail(c, "prefetch_images_u8_ragged: NULL argument") : 1;
+  if (ensure_input_streams(c)) return 1;
+  return fill_slot(c, c->cur ^ 1, nullptr, images, n, h, w, hipMemcpyHostToDevice, c->copy_stream);
+}
+
+extern "C" int uda_swap_prefetched(uda_ctx_t* c) {
+  if (!c) return 1;
+  if (!c->u8[c->cur ^ 1].valid) return fail(c, "swap_prefetched: nothing was prefetched");
+  HIPC(c, hipSetDevice(c->device));
+  c->u8[c->cur].valid = false;
+  return make_current(c, c->cur ^ 1);
 }
 
 extern "C" int uda_set_images_f32(uda_ctx_t* c, const float* images, int32_t n, const float* image_scales) {
@@ -814,6 +937,7 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       }
       if (c->wsplit_off[oi] >= 0) {
         a.wsplit = c->d_wsplit + c->wsplit_off[oi];
+        a.wparts = c->pw_parts;
         a.wpar = (const float*)(c->d_wsplit + c->wpar_off[oi]);
         if (fuse0) {
           const uda_buf_desc_t& gb = c->bufs[o.se_scale];
@@ -943,7 +1067,25 @@ static int run_sep_group(uda_ctx* c, const ChunkView& v, int oi, int n) {
     lv[j].mask = v.mask(o.drop_site);
     lv[j].H = ob.H; lv[j].W = ob.W;
   }
-  ProfScope ps(c, UDA_OP_SEP, v.stream());
+  // The grouped ops run concurrently inside one grid: no op's OUTPUT byte range may touch another op's input or output
+  // (the planner keeps every buffer of such a run alive to its end; this is the executor's own check of that promise).
+  for (int j = 0; j < n; ++j) {
+    const uda_buf_desc_t& obj = c->bufs[c->ops[oi + j].out];
+    const char* o0p = (const char*)lv[j].out;
+    const char* o1p = o0p + (size_t)v.rows(obj) * obj.H * obj.W * obj.C * sizeof(float);
+    for (int k = 0; k < n; ++k) {
+      if (k == j) continue;
+      const uda_buf_desc_t& ibk = c->bufs[c->ops[oi + k].in[0]];
+      const uda_buf_desc_t& obk = c->bufs[c->ops[oi + k].out];
+      const char* i0p = (const char*)lv[k].in;
+      const char* i1p = i0p + (size_t)v.rows(ibk) * ibk.H * ibk.W * ibk.C * sizeof(float);
+      const char* q0p = (const char*)lv[k].out;
+      const char* q1p = q0p + (size_t)v.rows(obk) * obk.H * obk.W * obk.C * sizeof(float);
+      if ((o0p < i1p && i0p < o1p) || (o0p < q1p && q0p < o1p))
+        return fail(c, "ops %d and %d of a launch group overlap in memory (arena plan broken)", oi + j, oi + k);
+    }
+  }
+  ProfScope ps(c, UDA_OP_SEP, v.stream(), n);      // one launch for n planned ops
   SepArgs a{};
   a.C = ib0.C; a.Cout = ob0.C;
   a.in_div = v.div(ib0, ob0);
@@ -961,13 +1103,12 @@ static int run_network(uda_ctx* c, int post_mode = 0, bool chunk_post = false) {
   if (c->have_u8) {
     ProfScope ps(c, 18);
     PreprocArgs a{};
-    a.in = c->d_u8; a.out = c->d_images;
-    a.n = n; a.h = c->raw_h; a.w = c->raw_w; a.H = m.image_h; a.W = m.image_w;
-    a.sh = c->sh; a.sw = c->sw;
+    const uda_ctx::U8Slot& sl = c->u8[c->cur];
+    a.in = sl.d_img; a.out = c->d_images; a.geo = sl.d_geo;
+    a.n = n; a.H = m.image_h; a.W = m.image_w;
     for (int k = 0; k < 3; ++k) { a.mean[k] = m.mean_rgb[k]; a.stdv[k] = m.stddev_rgb[k]; }
-    a.scale_y = (float)c->raw_h / (float)c->sh;
-    a.scale_x = (float)c->raw_w / (float)c->sw;
     launch_preprocess(a, c->stream);
+    HIPC(c, hipEventRecord(c->ev_pre_done[c->cur], c->stream));
   }
   if (!c->sites.empty()) {
     const int rows = n * T;
@@ -1037,6 +1178,7 @@ struct NmsCoop {           // scratch of the cooperative kernel; null members = 
   unsigned long long* bar = nullptr;    // exchange slots (per problem nms_coop_slot_words(M) words)
   int* err = nullptr;
   bool* used = nullptr;
+  int64_t* not_launched = nullptr;      // counts the runs that wanted the single launch and fell through to the slower versions
 };
 
 static bool run_nms(const NmsArgs& na, const float* scores, int M, hipStream_t st, uda_ctx::PrefixWs* pw = nullptr, size_t p0 = 0,
@@ -1060,9 +1202,13 @@ static bool run_nms(const NmsArgs& na, const float* scores, int M, hipStream_t s
   // The whole set: all epochs in one launch of a co-resident grid when the device holds it (UDA_NMS_COOP=0: never) ...
   static int coop_on = -1;
   if (coop_on < 0) { const char* e = getenv("UDA_NMS_COOP"); coop_on = e ? atoi(e) : 1; }
-  if (coop_on && coop.bar && coop.err && launch_nms_coop(na, scores, coop.bar + p0 * nms_coop_slot_words(M), coop.err, st)) {
-    if (coop.used) *coop.used = true;
-    return false;
+  if (coop_on && coop.bar && coop.err) {
+    const int lc = launch_nms_coop(na, scores, coop.bar + p0 * nms_coop_slot_words(M), coop.err, st);
+    if (lc > 0) {
+      if (coop.used) *coop.used = true;
+      return false;
+    }
+    if (lc < 0 && coop.not_launched) ++*coop.not_launched;
   }
   // ... else (more than 64 x 32768 candidates per problem, or a grid the device cannot hold): the single-launch kernel on
   // the candidates that can be popped at all (score prefix), checked on the device, full set - two launches per epoch -
@@ -1169,7 +1315,7 @@ static int run_post_global(uda_ctx* c, int i0, int n, hipStream_t st) {
     nms_params(na, m.nms_iou_thresh, m.nms_score_thresh, m.nms_soft_sigma);
     const bool try_prefix = !c->pfx_off && c->pfx_skip == 0;
     NmsCoop coop;
-    if (!c->coop_off) { coop.bar = c->d_coop_bar; coop.err = c->d_coop_err; coop.used = &c->coop_used; }
+    if (!c->coop_off) { coop.bar = c->d_coop_bar; coop.err = c->d_coop_err; coop.used = &c->coop_used; coop.not_launched = &c->coop_not_launched; }
     if (run_nms(na, c->d_cscores + (size_t)i0 * k, M, st, try_prefix ? &c->pfx : nullptr, (size_t)i0, coop))
       c->pfx_pending.push_back({i0, n});
   }
@@ -1331,6 +1477,7 @@ extern "C" int uda_run(uda_ctx_t* c, int32_t post_mode, int32_t do_post) {
 
 extern "C" int64_t uda_nms_prefix_fallbacks(const uda_ctx_t* c) { return c ? c->pfx_fallbacks : -1; }
 extern "C" int64_t uda_nms_coop_fallbacks(const uda_ctx_t* c) { return c ? c->coop_fallbacks : -1; }
+extern "C" int64_t uda_nms_coop_not_launched(const uda_ctx_t* c) { return c ? c->coop_not_launched : -1; }
 
 extern "C" int uda_synchronize(uda_ctx_t* c) {
   if (!c) return 1;
@@ -1691,7 +1838,7 @@ extern "C" int uda_nms(uda_ctx_t* c, const float* boxes, const float* scores, in
   {
     ProfScope ps(c, 17);
     NmsCoop coop;
-    if ((size_t)n_img * nms_coop_slot_words(max_out) <= (size_t)c->model.max_images * nms_coop_slot_words(c->model.max_output_size) && !c->coop_off) { coop.bar = c->d_coop_bar; coop.err = c->d_coop_err; coop.used = &c->coop_used; }
+    if ((size_t)n_img * nms_coop_slot_words(max_out) <= (size_t)c->model.max_images * nms_coop_slot_words(c->model.max_output_size) && !c->coop_off) { coop.bar = c->d_coop_bar; coop.err = c->d_coop_err; coop.used = &c->coop_used; coop.not_launched = &c->coop_not_launched; }
     if (k > 0) prefix = run_nms(a, d_scores, max_out, c->stream, pw.Lcap ? &pw : nullptr, 0, coop);
     else launch_nms_init(a, d_scores, c->stream);
   }
@@ -1709,7 +1856,7 @@ extern "C" int uda_nms(uda_ctx_t* c, const float* boxes, const float* scores, in
       f.nsel = d_nsel + p; f.done = d_done + p; f.n_img = 1;
       ProfScope ps(c, 17);
       NmsCoop coop;
-      if (!c->coop_off) { coop.bar = c->d_coop_bar; coop.err = c->d_coop_err; coop.used = &c->coop_used; }
+      if (!c->coop_off) { coop.bar = c->d_coop_bar; coop.err = c->d_coop_err; coop.used = &c->coop_used; coop.not_launched = &c->coop_not_launched; }
       run_nms(f, d_scores + pk, max_out, c->stream, nullptr, 0, coop);
       ++c->pfx_fallbacks;
     }

@@ -152,6 +152,7 @@ struct MbxArgs {
   int n_tiles;
   unsigned long long* stamps;  // diagnostic phase stamps (UDA_MBX_STAMPS); null in production
   const void* wsplit;     // expand kernel * BN scale (+ BN shift row) as split-bf16 fragments (kernels_pwb.hip) or null
+  int wparts;             // bf16 pieces per operand in wsplit: 2 (three cross terms) or 3 (six: UDA_PW_TERMS=6)
   const float* wpar;      // per-slab depthwise taps + BN scale / shift block (mbx_pack_params) or null
   // fused projection of the previous block (mbxb_kernel FUSE0): in = D [rows / in_div, H, W, c0]
   const float* gate;      // [rows / g_div, c0] per-sample gate on D (SE gate x deferred dropout), null = not fused
@@ -175,8 +176,8 @@ bool mbxd_supported(int Cin, int Cmid, int k, int stride);
 int mbxd_tiles(int Ho, int Wo, int k);
 bool mbxb_supported(int Cin, int Cmid, int k, int stride);
 int mbxb_tiles(int Ho, int Wo, int k, int stride);
-size_t mbxb_packed_elems(int Cin, int Cmid);
-void mbxb_pack_weights(const float* we, const float* sc0, const float* sh0, int Cin, int Cmid, uint16_t* out, bool perm16 = false);
+size_t mbxb_packed_elems(int Cin, int Cmid, int parts = 2);
+void mbxb_pack_weights(const float* we, const float* sc0, const float* sh0, int Cin, int Cmid, uint16_t* out, bool perm16 = false, int parts = 2);
 void launch_mbx(const MbxArgs& a, int rows, int k, int stride, hipStream_t s);
 int mbx_tiles(int Ho, int Wo, int k, int stride);
 bool mbx_supported(int Cin, int Cmid, int k, int stride);
@@ -260,12 +261,20 @@ void launch_class_mean(const AggArgs& a, float* out, hipStream_t s);
 void launch_topk(const float* vals, int n_img, int L, int k, int32_t* out_idx, void* ws, hipStream_t s);
 size_t topk_workspace_bytes(int n_img, int k);
 
+struct PreGeo {          // one raw image of a batch (raw sizes may differ between images: KITTI has four)
+  unsigned long long off;     // byte offset of the image in the packed uint8 buffer
+  int h, w;                   // raw size
+  int sh, sw;                 // scaled size inside the H x W network input (the rest is zero padding)
+  float scale_y, scale_x;     // raw / scaled ratios of the bilinear sampler
+  float inv_scale;            // image_scale handed to the post-process
+  int pad_;
+};
 struct PreprocArgs {
-  const uint8_t* in;   // [n, h, w, 3]
+  const uint8_t* in;   // images back to back, image i = [geo[i].h, geo[i].w, 3] at geo[i].off
   float* out;          // [n, H, W, 3]
-  int n, h, w, H, W, sh, sw;
+  const PreGeo* geo;   // [n] (device)
+  int n, H, W;
   float mean[3], stdv[3];
-  float scale_y, scale_x;  // in/out ratios for the bilinear sampler
 };
 void launch_preprocess(const PreprocArgs& a, hipStream_t s);
 
@@ -301,7 +310,7 @@ void launch_nms_reg(const NmsArgs& a, const float* scores, hipStream_t s);
 
 // all epochs of large problems in one launch of a co-resident grid; slots [n_img x nms_coop_slot_words(M)] / err [1] are scratch
 size_t nms_coop_slot_words(int M);
-bool launch_nms_coop(const NmsArgs& a, const float* scores, unsigned long long* slots, int* err, hipStream_t s);
+int launch_nms_coop(const NmsArgs& a, const float* scores, unsigned long long* slots, int* err, hipStream_t s);   // 1 launched, 0 not its domain, -1 wanted but not launched
 
 // NMS on the top-scoring prefix of a large candidate set (kernels_post.hip "NMS on a score prefix")
 struct PrefixArgs {

@@ -178,9 +178,13 @@ class DevArray:
                                              version=2, strides=None)
 
 
-def _head_tensor(torch, drv, level, which, dev):
+def _head_tensor(torch, drv, level, which, dev, rows_expected=None):
     """The handle's head-output buffer of (level, which) as a torch tensor [capacity, rows_per_image, floats_per_row]."""
     ptr, per, rows = drv.head_outputs_device(level, which)
+    if rows_expected is not None and rows != rows_expected:
+        raise ValueError("head buffer (level %d, %s) holds %d rows per image, the exchange needs %d: ensemble members must "
+                         "be deterministic networks (one row per image; a strided view is not a contiguous send buffer)"
+                         % (level, "box" if which else "class", rows, rows_expected))
     return torch.as_tensor(DevArray(ptr, (drv._cap, rows, per)), device=dev)
 
 
@@ -202,9 +206,10 @@ def reshard_member_heads_device(member_drivers, post_driver, n_members, n_total,
     ops, pending, keep = [], [], []
     for lvl in range(levels):
         for which in (0, 1):
-            dst = _head_tensor(torch, post_driver, lvl, which, dev)           # [cap, M, per]
-            assert dst.shape[1] == n_members, "the aggregating handle must stack %d samples" % n_members
-            srcs = {m: _head_tensor(torch, member_drivers[m], lvl, which, dev)[:, 0, :] for m in mine}   # [cap, per]
+            dst = _head_tensor(torch, post_driver, lvl, which, dev, rows_expected=n_members)   # [cap, M, per]
+            # one row per image in a member handle: [cap, 1, per] -> [cap, per] is contiguous, and so is every [s:e] slice
+            srcs = {m: _head_tensor(torch, member_drivers[m], lvl, which, dev, rows_expected=1)[:, 0, :] for m in mine}
+            assert all(t.is_contiguous() for t in srcs.values())
             for j in range(world):                                            # what this rank sends
                 s, e = shard_range(n_total, j, world)
                 if e == s:
@@ -230,9 +235,7 @@ def reshard_member_heads_device(member_drivers, post_driver, n_members, n_total,
     for dst, m, t in pending:
         dst[:b - a, m, :].copy_(t)
     torch.cuda.synchronize(dev)                 # the aggregating handle's stream may read its buffers now
-    post_driver._run_id += 1
-    if b > a:
-        post_driver._ck(post_driver._lib.uda_set_num_images(post_driver._h, b - a), "uda_set_num_images")
+    post_driver.heads_written_externally(b - a)
     return b - a
 
 
@@ -248,13 +251,17 @@ def serve_ensemble_striped(member_drivers, post_driver, images, n_members, rank,
     owned = {}
     scales = None
     for m, drv in sorted(member_drivers.items()):
-        a8 = drv._as_u8_batch(images)
-        drv._ck(drv._lib.uda_set_images_u8(drv._h, a8.ctypes.data, n, a8.shape[1], a8.shape[2]), "uda_set_images_u8")
+        drv._feed(images)
         drv._ck(drv._lib.uda_run(drv._h, -1, 0), "uda_run")
         owned[m] = drv
         _, scales = drv.preprocessed_scales(n)
+    import os
     import torch.distributed as dist
-    on_device = dist.get_backend(group) == "nccl" and device is not None
+    # UDA_ENSEMBLE_EXCHANGE=host forces the exchange through host arrays under RCCL too (the device-resident
+    # point-to-point branch moves 707 MB per member without touching PCIe, but a two-GPU RCCL run of it has only
+    # ever been possible on the driver's multi-GPU node, never on the builder's one-GPU box)
+    on_device = (dist.get_backend(group) == "nccl" and device is not None
+                 and os.environ.get("UDA_ENSEMBLE_EXCHANGE", "device") != "host")
     if on_device:
         reshard_member_heads_device(owned, post_driver, n_members, n, rank, world, device, group=group)
     else:       # CPU process group (gloo: tests): through host arrays

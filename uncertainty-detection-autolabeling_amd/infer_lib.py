@@ -137,6 +137,7 @@ class ServingDriver:
 
     # ------------------------------------------------------------------ serve / predict
     def _as_u8_batch(self, image_arrays):
+        """uint8 [N,h,w,3] (an array, or a list of equally sized images as the reference stacks them, infer_lib.py:139-151)."""
         if isinstance(image_arrays, (list, tuple)):
             image_arrays = np.stack([np.asarray(a) for a in image_arrays])
         a = np.asarray(image_arrays)
@@ -149,6 +150,37 @@ class ServingDriver:
         if a.shape[0] > self._cap:
             raise ValueError("batch of %d images exceeds batch_size=%d" % (a.shape[0], self._cap))
         return np.ascontiguousarray(a)
+
+    def _feed(self, image_arrays, prefetch=False):
+        """Hand a uint8 batch to the handle: one array [N,h,w,3], or a list of images whose raw sizes may differ (KITTI:
+        370-376 x 1224-1242, dataset_data.py:105 - the reference serves those one file at a time,
+        validate_model.py:479-483; here they form one batch, each image with its own resize scale).  prefetch=True uploads
+        into the second input slot on the copy stream (`swap_prefetched` makes it current).  Returns the image count."""
+        ragged = (isinstance(image_arrays, (list, tuple)) and len(image_arrays) > 0
+                  and len({np.shape(x) for x in image_arrays}) > 1)
+        if not ragged:
+            a = self._as_u8_batch(image_arrays)
+            n, h, w = a.shape[:3]
+            fn = self._lib.uda_prefetch_images_u8 if prefetch else self._lib.uda_set_images_u8
+            self._ck(fn(self._h, _ptr(a), n, h, w), "uda_prefetch_images_u8" if prefetch else "uda_set_images_u8")
+            return n
+        imgs = []
+        for x in image_arrays:
+            x = np.asarray(x)
+            if x.ndim != 3 or x.shape[-1] != 3:
+                raise ValueError("every image of a ragged batch must be [h, w, 3], got %s" % (x.shape,))
+            if x.dtype != np.uint8:
+                raise ValueError("serve() takes uint8 images, got %s" % x.dtype)
+            imgs.append(np.ascontiguousarray(x))
+        n = len(imgs)
+        if n > self._cap:
+            raise ValueError("batch of %d images exceeds batch_size=%d" % (n, self._cap))
+        ptrs = (C.c_void_p * n)(*[x.ctypes.data for x in imgs])
+        hs = np.asarray([x.shape[0] for x in imgs], np.int32)
+        ws = np.asarray([x.shape[1] for x in imgs], np.int32)
+        fn = self._lib.uda_prefetch_images_u8_ragged if prefetch else self._lib.uda_set_images_u8_ragged
+        self._ck(fn(self._h, ptrs, n, _ptr(hs), _ptr(ws)), "uda_set_images_u8_ragged")
+        return n
 
     def _mode(self, post_mode):
         if post_mode is None:
@@ -202,14 +234,41 @@ class ServingDriver:
         uncertainty columns are dropped there by the reference (postprocess.py:737) and its logits
         output in that mode is corrupted by a variable overwrite (:659-666), so none is returned."""
         mode = self._mode(post_mode)
-        a = self._as_u8_batch(image_arrays)
-        n, h, w = a.shape[:3]
+        n = self._feed(image_arrays)
         self._next_seed()
         self._run_id += 1
-        self._ck(self._lib.uda_set_images_u8(self._h, _ptr(a), n, h, w), "uda_set_images_u8")
         self._ck(self._lib.uda_run(self._h, mode, 1), "uda_run")
         self._last_n = n
         return self._collect(n, mode)
+
+    def serve_files(self, paths, post_mode=None):
+        """Decode image files and serve them as ONE batch (the reference reads and serves file by file,
+        validate_model.py:479-483, infer_model.py:554-581); raw sizes may differ."""
+        return self.serve(read_images(paths), post_mode=post_mode)
+
+    def serve_stream(self, batches, post_mode=None):
+        """Generator over batches (arrays or lists of images): yields each batch's detections, with the upload of batch
+        i + 1 (pinned staging buffer, copy stream) running under the network of batch i - the feed the reference pays
+        inside every serve() call (validate_model.py:154-158) costs no device time here."""
+        mode = self._mode(post_mode)
+        it = iter(batches)
+        try:
+            first = next(it)
+        except StopIteration:
+            return
+        n = self._feed(first)
+        while True:
+            self._next_seed()
+            self._run_id += 1
+            self._ck(self._lib.uda_run(self._h, mode, 1), "uda_run")          # queued, asynchronous
+            nxt = next(it, None)
+            n_next = self._feed(nxt, prefetch=True) if nxt is not None else 0  # overlaps the kernels queued above
+            self._last_n = n
+            yield self._collect(n, mode)                                      # waits for this batch
+            if nxt is None:
+                return
+            self._ck(self._lib.uda_swap_prefetched(self._h), "uda_swap_prefetched")
+            n = n_next
 
     def class_probs(self, n):
         """(probab [n, M, C], entropy [n, M]) of the last global post-process, computed on the device:
@@ -335,6 +394,15 @@ class ServingDriver:
         """(cls_outputs, box_outputs) of the last run as lazy sequences that stay on the device until indexed."""
         return DeviceHeads(self, n, 0), DeviceHeads(self, n, 1)
 
+    def heads_written_externally(self, n):
+        """Another producer (the ensemble exchange: device-to-device copies / RCCL receives into `head_outputs_device`
+        buffers) has filled the head outputs of `n` images: earlier `DeviceHeads` views become stale, the next
+        post-process works on n images."""
+        self._run_id += 1
+        if n > 0:
+            self._ck(self._lib.uda_set_num_images(self._h, int(n)), "uda_set_num_images")
+        self._last_n = int(n)
+
     def head_outputs_device(self, level, which):
         """(device address, floats per row, rows per image) of the handle's head-output buffer (capi.DevArray wraps it
         for torch / RCCL): rows are [image][sample]."""
@@ -411,6 +479,11 @@ class ServingDriver:
         candidate set (identical results either way; include/uda_hip.h uda_nms_prefix_fallbacks)."""
         return int(self._lib.uda_nms_prefix_fallbacks(self._h))
 
+    def nms_coop_not_launched(self):
+        """NMS runs that wanted the single-launch grid and did not get it (include/uda_hip.h uda_nms_coop_not_launched):
+        0 in normal operation."""
+        return int(self._lib.uda_nms_coop_not_launched(self._h))
+
     def nms_coop_fallbacks(self):
         """Post-process runs redone with two launches per epoch because the single-launch NMS grid timed out
         (include/uda_hip.h uda_nms_coop_fallbacks); 0 in normal operation."""
@@ -419,12 +492,21 @@ class ServingDriver:
     # ------------------------------------------------------------------ resident-input fast path (bench)
     def stage_images(self, image_arrays):
         """Upload uint8 images once (the PCIe leg); `run_resident` then re-runs the path on them."""
-        a = self._as_u8_batch(image_arrays)
-        n, h, w = a.shape[:3]
-        self._ck(self._lib.uda_set_images_u8(self._h, _ptr(a), n, h, w), "uda_set_images_u8")
+        n = self._feed(image_arrays)
         self._ck(self._lib.uda_synchronize(self._h), "uda_synchronize")
         self._last_n = n
         return n
+
+    def prefetch_images(self, image_arrays):
+        """Start the upload of the NEXT batch into the second input slot (copy stream); returns at once."""
+        self._prefetched_n = self._feed(image_arrays, prefetch=True)
+        return self._prefetched_n
+
+    def swap_prefetched(self):
+        """The prefetched batch becomes the input of the next run (the compute stream waits for its upload event)."""
+        self._ck(self._lib.uda_swap_prefetched(self._h), "uda_swap_prefetched")
+        self._last_n = self._prefetched_n
+        return self._last_n
 
     def run_resident(self, sync=True):
         self._next_seed()
@@ -478,6 +560,17 @@ class ServingDriver:
         """Visualize prediction on image (infer_lib.py:194-204): host drawing, not on the hot path."""
         from .visualize import visualize_image
         return visualize_image(image, boxes, np.asarray(classes).astype(int), scores, self.label_map, uncertainty, **kwargs)
+
+
+def read_images(paths):
+    """Decode image files into uint8 RGB arrays [h, w, 3] (host side, PIL) - the `np.array(Image.open(f))` of the
+    reference's callers (validate_model.py:479-483, infer_model.py:554-560).  Sizes may differ; `serve` takes the list."""
+    from PIL import Image
+    out = []
+    for f in paths:
+        with Image.open(f) as im:
+            out.append(np.ascontiguousarray(np.asarray(im.convert("RGB"), dtype=np.uint8)))
+    return out
 
 
 class KerasDriver(ServingDriver):
@@ -568,11 +661,9 @@ class EnsembleDriver:
         self.batch_size = batch_size
 
     def serve(self, image_arrays, post_mode=None):
-        a = self.members[0]._as_u8_batch(image_arrays)
-        n, h, w = a.shape[:3]
         lib = self.post._lib
         for m, drv in enumerate(self.members):
-            drv._ck(lib.uda_set_images_u8(drv._h, _ptr(a), n, h, w), "uda_set_images_u8")
+            n = drv._feed(image_arrays)
             drv._ck(lib.uda_run(drv._h, -1, 0), "uda_run")
             self.post._ck(lib.uda_copy_heads(self.post._h, drv._h, n, m), "uda_copy_heads")
         self.post._run_id += 1

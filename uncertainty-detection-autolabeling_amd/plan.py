@@ -74,9 +74,10 @@ def mbx_supported(cin, cmid, k, stride):
     import os
     if not (int(os.environ.get("UDA_FUSE_MBX", "1")) and cin % 8 == 0 and cmid % 4 == 0 and k in (3, 5)):
         return False
-    if int(os.environ.get("UDA_PW_TERMS", "3")) == 6:
-        # six cross terms = float32-equivalent products EVERYWHERE: the fused MBConv kernels carry two bf16 pieces per
-        # operand (three terms), so under this switch the expands run as stand-alone six-term 1x1 convs + depthwise
+    if int(os.environ.get("UDA_PW_TERMS", "3")) == 6 and not int(os.environ.get("UDA_FUSE_MBX6", "1")):
+        # six cross terms = float32-equivalent products EVERYWHERE.  The fused MBConv kernels have three-piece variants
+        # (mbxb_kernel / mbxd_kernel<..., PARTS = 3>, csrc/kernels_pwb.hip) and stay fused; UDA_FUSE_MBX6=0 restores the
+        # round-2 behaviour (stand-alone six-term 1x1 convs + depthwise) for A/B runs
         return False
     if mbx_deep(cin):       # mirror of mbxd_supported: stride 1, 16-deep k-steps of Cin + 1 in {6, 8, 13, 14}, split-bf16 path on
         return (int(os.environ.get("UDA_FUSE_MBXD", "1")) and int(os.environ.get("UDA_PW_TERMS", "3")) != 0

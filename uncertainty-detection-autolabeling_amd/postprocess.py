@@ -11,6 +11,7 @@ of this package return) are post-processed where they are; plain arrays are uplo
 handle that is created on first use and cached per configuration.  The legacy row formats are pure re-packing
 of <= 100 rows per image, which the reference does with tf.stack on the host side of the path.
 """
+import collections
 import json
 
 import numpy as np
@@ -18,23 +19,53 @@ import numpy as np
 from .hparams_config import parse_image_size
 
 CLASS_OFFSET = 1
-_POST_DRIVERS = {}
+# post-process-only handles for head outputs that arrive as arrays: keyed by what SHAPES a handle (geometry, sample axis,
+# classes, decode / NMS settings), least recently used first, at most _POST_CACHE_MAX alive (each holds head buffers of
+# n x T x all levels plus candidate and NMS workspaces - hundreds of MB at T = 30 or D2)
+_POST_DRIVERS = collections.OrderedDict()
+_POST_CACHE_MAX = 4
+_SHAPING_KEYS = ("name", "image_size", "min_level", "max_level", "num_scales", "aspect_ratios", "anchor_scale", "num_classes",
+                 "mc_dropout", "mc_dropoutsamp", "mc_dropoutrate", "mc_classheadrate", "mc_boxheadrate", "loss_attenuation",
+                 "enable_softmax", "uncert_adjust_method", "decode_nsamples", "nms_configs")
 
 
 def _params_dict(params):
     return params.as_dict() if hasattr(params, "as_dict") else dict(params)
 
 
+def _cache_key(p):
+    from . import arch
+    shaped = {k: p.get(k) for k in _SHAPING_KEYS}
+    # the dropout RATES do not shape a post-process handle, only which heads carry the sample axis does
+    cls_st, box_st, T = arch.mc_flags(p)
+    for k in ("mc_dropoutrate", "mc_classheadrate", "mc_boxheadrate", "mc_dropoutsamp"):
+        shaped.pop(k)
+    shaped["stacking"] = (bool(cls_st), bool(box_st), int(T))
+    return json.dumps(shaped, sort_keys=True, default=str)
+
+
+def close_cached():
+    """Close every cached post-process handle (frees their device buffers)."""
+    while _POST_DRIVERS:
+        _, d = _POST_DRIVERS.popitem(last=False)
+        d.close()
+
+
 def _post_driver(params, n):
-    """A post-process-only handle for `params` holding at least n images (cached)."""
+    """A post-process-only handle for `params` holding at least n images (LRU cache of _POST_CACHE_MAX handles)."""
     from .infer_lib import ServingDriver
     p = _params_dict(params)
-    key = json.dumps({k: p[k] for k in sorted(p) if k not in ("label_map",)}, sort_keys=True, default=str)
+    key = _cache_key(p)
     have = _POST_DRIVERS.get(key)
     if have is not None and have._cap >= n:
+        _POST_DRIVERS.move_to_end(key)
         return have
     if have is not None:
+        del _POST_DRIVERS[key]
         have.close()
+    while len(_POST_DRIVERS) >= _POST_CACHE_MAX:
+        _, old = _POST_DRIVERS.popitem(last=False)
+        old.close()
     d = ServingDriver(p.get("name") or "efficientdet-d0", max(int(n), 1), False, p, post_only=True, chunk_images=1)
     _POST_DRIVERS[key] = d
     return d

@@ -204,11 +204,14 @@ def resolve_weights(path, config):
                        seed = config["uda_seed"] (default 0)
       *.npz            a weight set saved by `save_weights` (reference variable names)
       anything else    a TF2 checkpoint prefix or directory (utils_keras.restore_ckpt, :125-235), read without
-                       TensorFlow by `ckpt_reader`."""
+                       TensorFlow by `ckpt_reader` the way the reference's driver restores (infer_lib.py:435:
+                       `restore_ckpt(model, ckpt, config.moving_average_decay, skip_mismatch=False)`): EMA shadows
+                       only when `moving_average_decay` > 0, a missing or mis-shaped variable raises."""
     if path is None or str(path) in ("", "_"):
         return init_weights(config, seed=int(config.get("uda_seed", 0)))
     path = str(path)
     if path.endswith(".npz"):
         return load_weights(path)
     from . import ckpt_reader
-    return ckpt_reader.load_checkpoint(path, config)
+    decay = config.get("moving_average_decay", 0) or 0
+    return ckpt_reader.load_checkpoint(path, config, use_ema=float(decay) > 0, skip_mismatch=False)
