@@ -259,6 +259,13 @@ static void launch_sep_nt(const SepMulti& m, int rows, int gy, hipStream_t s) {
 
 static void launch_sep_any(const SepMulti& m, int rows, hipStream_t s) {
   const int ntl = (m.one.Cout + 31) / 32;
+  // three pieces per operand (UDA_PW_TERMS=6) at 112 channels (D2's BiFPN): the A image (3 x 128 x 240 B) plus the weight
+  // fragments of three or four column tiles exceed the 160 KB of a CU - two column tiles per block, more column blocks
+  {
+    const int KS = (m.one.C + 15) / 16, arow = KS * 32 + 16;
+    const size_t need = (size_t)m.one.wparts * 128 * arow + (size_t)KS * (ntl < 4 ? ntl : 3) * m.one.wparts * 1024;
+    if (ntl > 2 && need > 140 * 1024) { launch_sep_nt<2>(m, rows, (ntl + 1) / 2, s); return; }
+  }
   // all columns in one block when they fit four 32-column tiles, else blocks of three
   if (ntl == 1) launch_sep_nt<1>(m, rows, 1, s);
   else if (ntl == 2) launch_sep_nt<2>(m, rows, 1, s);

@@ -1144,6 +1144,15 @@ static int run_network(uda_ctx* c, int post_mode = 0, bool chunk_post = false) {
       }
       const int rc = run_op(c, v, oi);
       if (rc) return rc;
+      static const bool check_each = getenv("UDA_CHECK_LAUNCH") != nullptr;      // debug: name the op whose launch was refused
+      if (check_each) {
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) {
+          const uda_op_t& o = c->ops[oi];
+          return fail(c, "op %d (kind %d, k %d, stride %d, in C %d, out C %d): launch failed: %s", oi, o.kind, o.k, o.stride,
+                      c->bufs[o.in[0]].C, c->bufs[o.out].C, hipGetErrorString(le));
+        }
+      }
     }
     c->last_chunk_i0 = i0;
     c->last_chunk_n = v.nc;
