@@ -100,9 +100,10 @@ def test_op_list_shape_d0():
     pl, _ = _plan(FULL_MC, chunk_images=2, max_images=4)
     kinds = [o["kind"] for o in pl.ops]
     fused = kinds.count(capi.OP_MBX)           # expand+depthwise as one op: blocks 1-5 (Cin <= 48) and the deep
-    shallow = 5 if plan_mod.mbx_supported(16, 96, 3, 2) else 0      # stride-1 blocks 6-10, 12-15 (block 11 is 5x5 stride 2)
+    shallow = 5 if plan_mod.mbx_supported(16, 96, 3, 2) else 0      # stride-1 blocks 6-10, 12-15; block 11 (5x5 stride 2): round 3
     deep = 9 if plan_mod.mbx_supported(112, 672, 5, 1) else 0
-    assert fused == shallow + deep
+    deep += 1 if plan_mod.mbx_supported(112, 672, 5, 2) else 0
+    assert fused == shallow + deep and fused == 15
     sep = kinds.count(capi.OP_SEP)             # 24 BiFPN nodes + 2 heads x 5 levels x (3 + 1) separable convs
     assert sep == (64 if pl.fuse_sep else 0)
     proj = sum(1 for o in pl.ops if o["kind"] == capi.OP_MBX and o["se_scale"] >= 0)   # block 0's projection inside block 1's op

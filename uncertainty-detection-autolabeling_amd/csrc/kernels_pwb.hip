@@ -933,25 +933,34 @@ void launch_mbxb(const MbxArgs& a, int rows, int k, int stride, hipStream_t s) {
 // blocks per CU = at most 128 VGPRs.  The 5x5 variants with up to 8 k-steps fit that once the 25 depthwise taps are read
 // from LDS at their use instead of living in registers; with two blocks per CU the expand phase of one block (MFMA +
 // transcendentals) overlaps the depthwise phase of the other (FMA + LDS) - with one block both phases run in lockstep.)
-template <int K, int KSF, int PARTS>
+struct MbxCfgD { int th, tw, xw; };
+// output tile and outputs per depthwise unit of the deep kernel: stride 1: 12 x 16 (3x3, 14 x 18 = 252 input pixels) / 8 x 16
+// (5x5, 12 x 20 = 240); stride 2 (the first block of a stage, e.g. EfficientNet-B0 block 11: 5x5, 112 -> 672): 4 x 10
+// (11 x 23 = 253) / 7 x 8 (3x3, 15 x 17 = 255) - the tiles of mbxb_kernel
+__host__ __device__ constexpr MbxCfgD mbxd_cfg(int k, int s) {
+  return s == 1 ? (k == 3 ? MbxCfgD{12, 16, 4} : MbxCfgD{8, 16, 8}) : (k == 3 ? MbxCfgD{7, 8, 8} : MbxCfgD{4, 10, 5});
+}
+
+template <int K, int KSF, int PARTS, int S>
 __global__ __launch_bounds__(512, (KSF <= 8 && PARTS == 2) ? 4 : 2) void mbxd_kernel(MbxArgs a) {
   constexpr bool WK_LDS = (K == 5 && (KSF <= 8 || PARTS == 3));     // the 25 taps from LDS at their use, not 25 registers
 
   constexpr int NW = 8;
-  constexpr int TH = (K == 3) ? 12 : 8, TW = 16;
-  constexpr int IH = TH + K - 1, IW = TW + K - 1;
+  constexpr int TH = mbxd_cfg(K, S).th, TW = mbxd_cfg(K, S).tw;
+  constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
   constexpr int NP = IH * IW;
   static_assert(NP <= 256, "input tile must fit 8 slices of 32 pixels");
   constexpr int NPP = 256;
   constexpr int NG = NW * 2;                  // depthwise thread groups (32 channels each)
   constexpr int ES = 33;
-  constexpr int ETW = mbx_et_w(K, 1);         // E transposed, [channel][pixel] (see mbx_et_w); 32 * CP <= NPP * ES floats
+  constexpr int ETW = mbx_et_w(K, S);         // E transposed, [channel][pixel] (stride 1 only, see mbx_et_w); 32 * CP <= NPP * ES floats
   constexpr bool ET = ETW != 0;
   constexpr int CP = mbx_et_pitch(ETW);
-  constexpr int XW = (K == 3) ? 4 : 8;        // outputs per unit along x
+  constexpr int XW = mbxd_cfg(K, S).xw;       // outputs per unit along x
   constexpr int UPR = TW / XW;                // units per output row
-  constexpr int NUNIT = TH * UPR;             // 48 (3x3) / 16 (5x5) units over 16 groups
-  constexpr int NCOL = XW + K - 1;
+  constexpr int NUNIT = TH * UPR;             // 48 (3x3) / 16 (5x5) units over 16 groups; stride 2: 7 / 8 (half of the groups idle)
+  static_assert(TW % XW == 0, "units must tile the output tile");
+  constexpr int NCOL = (XW - 1) * S + K;
   constexpr int BSLAB = KSF * PARTS * 64;     // uint4 per slab of packed expand weights
   extern __shared__ __attribute__((aligned(16))) float dlds[];
   float* E = dlds;                            // [NPP][ES]
@@ -965,7 +974,7 @@ __global__ __launch_bounds__(512, (KSF <= 8 && PARTS == 2) ? 4 : 2) void mbxd_ke
   const int li = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z / a.ch_groups, b_in = b / a.in_div;
   const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
-  const int iy0 = oy0 - a.pad_t, ix0 = ox0 - a.pad_l;
+  const int iy0 = oy0 * S - a.pad_t, ix0 = ox0 * S - a.pad_l;
   const float* xin = a.in + (size_t)b_in * a.H * a.W * a.Cin;
   const int NCH = (a.Cmid + 31) >> 5;
   // this block's slabs [chb, che): all of them, or one of ch_groups contiguous ranges (small grids, see MbxArgs)
@@ -1016,15 +1025,15 @@ __global__ __launch_bounds__(512, (KSF <= 8 && PARTS == 2) ? 4 : 2) void mbxd_ke
   constexpr int B_PER = (BSLAB + 511) / 512;  // uint4 of the next slab per thread
   // loop-invariant addressing of the depthwise stage (see mbxb_kernel): E window offsets, output offsets relative to the
   // block's uniform output base, and the block-uniform "whole tile" decision for the unguarded path
-  constexpr int UPT = NUNIT / NG;
-  static_assert(NUNIT % NG == 0, "units must tile the thread groups");
+  constexpr int UPT = (NUNIT + NG - 1) / NG;
+  constexpr bool UNIT_GUARD = (NUNIT % NG) != 0;      // stride 2: fewer units than thread groups
   int eoff[UPT];
   unsigned ooff[UPT];
 #pragma unroll
   for (int ui = 0; ui < UPT; ++ui) {
-    const int u = g + NG * ui;
+    const int u = (UNIT_GUARD && g + NG * ui >= NUNIT) ? 0 : g + NG * ui;
     const int orow = u / UPR, oxs = (u % UPR) * XW;
-    eoff[ui] = ET ? c * CP + orow * IW + oxs : (orow * IW + oxs) * ES + c;
+    eoff[ui] = ET ? c * CP + orow * S * IW + oxs * S : (orow * S * IW + oxs * S) * ES + c;
     ooff[ui] = (unsigned)((orow * a.Wo + oxs) * a.Cmid + c) * 4u;      // bytes
   }
   float* const obase = a.out + (((size_t)b * a.Ho + oy0) * a.Wo + ox0) * a.Cmid;
@@ -1106,6 +1115,9 @@ __global__ __launch_bounds__(512, (KSF <= 8 && PARTS == 2) ? 4 : 2) void mbxd_ke
       constexpr bool GUARD = decltype(guard)::value;
 #pragma unroll
       for (int ui = 0; ui < UPT; ++ui) {
+        if constexpr (UNIT_GUARD) {
+          if (g + NG * ui >= NUNIT) continue;
+        }
         if constexpr (GUARD) {
           if (oy0 + (g + NG * ui) / UPR >= a.Ho) continue;
         }
@@ -1130,7 +1142,7 @@ __global__ __launch_bounds__(512, (KSF <= 8 && PARTS == 2) ? 4 : 2) void mbxd_ke
           for (int kx = 0; kx < K; ++kx) {
             const float w = WK_LDS ? pcur[(ky * K + kx) * 32 + c] : wk[WK_LDS ? 0 : ky * K + kx];
 #pragma unroll
-            for (int o = 0; o < XW; ++o) acc[o] = fmaf(rowv[o + kx], w, acc[o]);
+            for (int o = 0; o < XW; ++o) acc[o] = fmaf(rowv[o * S + kx], w, acc[o]);
           }
         }
 #pragma unroll
@@ -1515,60 +1527,67 @@ static void launch_mbxp_t(const MbxArgs& a, int rows, hipStream_t s) {
 bool mbxd_supported(int Cin, int Cmid, int k, int stride) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("UDA_FUSE_MBXD"); on = e ? atoi(e) : 1; }
+  static int s2 = -1;            // UDA_FUSE_MBXD_S2=0: stride-2 deep blocks run unfused (1x1 expand + depthwise), as before round 3
+  if (s2 < 0) { const char* e = getenv("UDA_FUSE_MBXD_S2"); s2 = e ? atoi(e) : 1; }
   const int ksf = (Cin + 1 + 15) / 16;
   static int maxksf = -1;
   if (maxksf < 0) { const char* e = getenv("UDA_MBXD_MAXKSF"); maxksf = e ? atoi(e) : 14; }
-  return on && stride == 1 && (k == 3 || k == 5) && Cin % 8 == 0 && Cin > 48 && (ksf == 6 || ksf == 8 || ksf == 13 || ksf == 14) &&
-         ksf <= maxksf && Cmid % 4 == 0;
+  return on && (stride == 1 || (stride == 2 && s2)) && (k == 3 || k == 5) && Cin % 8 == 0 && Cin > 48 &&
+         (ksf == 6 || ksf == 8 || ksf == 13 || ksf == 14) && ksf <= maxksf && Cmid % 4 == 0;
 }
 
-int mbxd_tiles(int Ho, int Wo, int k) {
-  const int th = (k == 3) ? 12 : 8;
-  return ((Ho + th - 1) / th) * ((Wo + 15) / 16);
+int mbxd_tiles(int Ho, int Wo, int k, int stride) {
+  const MbxCfgD c = mbxd_cfg(k, stride);
+  return ((Ho + c.th - 1) / c.th) * ((Wo + c.tw - 1) / c.tw);
 }
 
-template <int K, int KSF, int PARTS>
+template <int K, int KSF, int PARTS, int S>
 static void launch_mbxd_t(const MbxArgs& a, int rows, hipStream_t s) {
-  constexpr int TH = (K == 3) ? 12 : 8;
+  constexpr int TH = mbxd_cfg(K, S).th, TW = mbxd_cfg(K, S).tw;
   const size_t lds = ((size_t)256 * 33 + 16 * 32 + 2 * (K * K + 2) * 32 + 2 * 32 * ((a.Cmid + 31) / 32)) * sizeof(float) +
                      (size_t)KSF * PARTS * 64 * sizeof(uint4);
   static size_t attr_lds = 64 * 1024;      // above the default limit the kernel needs an explicit opt-in
   if (lds > attr_lds) {
-    hipFuncSetAttribute((const void*)mbxd_kernel<K, KSF, PARTS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)mbxd_kernel<K, KSF, PARTS, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_lds = lds;
   }
-  dim3 grid((a.Wo + 15) / 16, (a.Ho + TH - 1) / TH, rows);
+  dim3 grid((a.Wo + TW - 1) / TW, (a.Ho + TH - 1) / TH, rows);
   MbxArgs b = a;
   b.ch_groups = mbx_ch_groups((long long)grid.x * grid.y * rows, (KSF <= 8 && PARTS == 2) ? 2 : 1, (a.Cmid + 31) / 32);
   grid.z = (unsigned)(rows * b.ch_groups);
-  hipLaunchKernelGGL((mbxd_kernel<K, KSF, PARTS>), grid, dim3(512), lds, s, b);
+  hipLaunchKernelGGL((mbxd_kernel<K, KSF, PARTS, S>), grid, dim3(512), lds, s, b);
 }
 
-template <int PARTS>
+template <int PARTS, int S>
 static void launch_mbxd_p(const MbxArgs& a, int rows, int k, int ksf, hipStream_t s) {
   if (k == 3) {
     switch (ksf) {
-      case 6: launch_mbxd_t<3, 6, PARTS>(a, rows, s); break;
-      case 8: launch_mbxd_t<3, 8, PARTS>(a, rows, s); break;
-      case 13: launch_mbxd_t<3, 13, PARTS>(a, rows, s); break;
-      default: launch_mbxd_t<3, 14, PARTS>(a, rows, s); break;
+      case 6: launch_mbxd_t<3, 6, PARTS, S>(a, rows, s); break;
+      case 8: launch_mbxd_t<3, 8, PARTS, S>(a, rows, s); break;
+      case 13: launch_mbxd_t<3, 13, PARTS, S>(a, rows, s); break;
+      default: launch_mbxd_t<3, 14, PARTS, S>(a, rows, s); break;
     }
   } else {
     switch (ksf) {
-      case 6: launch_mbxd_t<5, 6, PARTS>(a, rows, s); break;
-      case 8: launch_mbxd_t<5, 8, PARTS>(a, rows, s); break;
-      case 13: launch_mbxd_t<5, 13, PARTS>(a, rows, s); break;
-      default: launch_mbxd_t<5, 14, PARTS>(a, rows, s); break;
+      case 6: launch_mbxd_t<5, 6, PARTS, S>(a, rows, s); break;
+      case 8: launch_mbxd_t<5, 8, PARTS, S>(a, rows, s); break;
+      case 13: launch_mbxd_t<5, 13, PARTS, S>(a, rows, s); break;
+      default: launch_mbxd_t<5, 14, PARTS, S>(a, rows, s); break;
     }
   }
 }
 
-void launch_mbxd(const MbxArgs& a, int rows, int k, hipStream_t s) {
+void launch_mbxd(const MbxArgs& a, int rows, int k, int stride, hipStream_t s) {
   const int ksf = (a.Cin + 1 + 15) / 16;
+  if (stride == 2) {                // the first block of a stage: the two-phase kernel on the stride-2 tiles
+    if (a.wparts == 3) launch_mbxd_p<3, 2>(a, rows, k, ksf, s);
+    else launch_mbxd_p<2, 2>(a, rows, k, ksf, s);
+    return;
+  }
   static int pipe = -1;
   if (pipe < 0) { const char* e = getenv("UDA_MBXP"); pipe = e ? atoi(e) : 1; }
   if (a.wparts == 3) {              // six cross terms (UDA_PW_TERMS=6): three pieces per operand, the two-phase kernel
-    launch_mbxd_p<3>(a, rows, k, ksf, s);
+    launch_mbxd_p<3, 1>(a, rows, k, ksf, s);
     return;
   }
   if (pipe && ksf >= 13) {          // one block per CU anyway: the self-overlapping variant
@@ -1576,7 +1595,7 @@ void launch_mbxd(const MbxArgs& a, int rows, int k, hipStream_t s) {
     else { if (ksf == 13) launch_mbxp_t<5, 13>(a, rows, s); else launch_mbxp_t<5, 14>(a, rows, s); }
     return;
   }
-  launch_mbxd_p<2>(a, rows, k, ksf, s);
+  launch_mbxd_p<2, 1>(a, rows, k, ksf, s);
 }
 
 // depthwise-side operands of the fused kernels, one contiguous block per 32-channel slab:

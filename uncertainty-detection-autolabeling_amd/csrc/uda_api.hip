@@ -927,7 +927,7 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       a.pad_t = same_pad_before(ib.H, ob.H, o.k, o.stride);
       a.pad_l = same_pad_before(ib.W, ob.W, o.k, o.stride);
       a.in_div = v.div(ib, ob);
-      a.n_tiles = deep ? mbxd_tiles(ob.H, ob.W, o.k)
+      a.n_tiles = deep ? mbxd_tiles(ob.H, ob.W, o.k, o.stride)
                        : (c->wsplit_off[oi] >= 0 ? mbxb_tiles(ob.H, ob.W, o.k, o.stride) : mbx_tiles(ob.H, ob.W, o.k, o.stride));
       if (o.se_partial >= 0) {
         const uda_buf_desc_t& pb = c->bufs[o.se_partial];
@@ -948,7 +948,7 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
           a.w0t = a.wpar + mbx_par_floats(ob.C, o.k);
           a.sh0f = a.w0t + 32 * 32;
         }
-        if (deep) launch_mbxd(a, rows, o.k, v.stream());
+        if (deep) launch_mbxd(a, rows, o.k, o.stride, v.stream());
         else launch_mbxb(a, rows, o.k, o.stride, v.stream());
       } else {
         launch_mbx(a, rows, o.k, o.stride, v.stream());

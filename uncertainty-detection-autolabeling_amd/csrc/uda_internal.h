@@ -171,9 +171,9 @@ void mbxb_pack_proj(const float* w0, const float* sc, const float* sh, int c0, i
 size_t mbx_par_floats(int Cmid, int k);
 void mbx_pack_params(const float* wd, const float* sc1, const float* sh1, int Cmid, int k, float* out);
 void launch_mbxb(const MbxArgs& a, int rows, int k, int stride, hipStream_t s);
-void launch_mbxd(const MbxArgs& a, int rows, int k, hipStream_t s);     // deep stride-1 blocks (Cin > 48)
+void launch_mbxd(const MbxArgs& a, int rows, int k, int stride, hipStream_t s);     // deep blocks (Cin > 48), stride 1 or 2
 bool mbxd_supported(int Cin, int Cmid, int k, int stride);
-int mbxd_tiles(int Ho, int Wo, int k);
+int mbxd_tiles(int Ho, int Wo, int k, int stride = 1);
 bool mbxb_supported(int Cin, int Cmid, int k, int stride);
 int mbxb_tiles(int Ho, int Wo, int k, int stride);
 size_t mbxb_packed_elems(int Cin, int Cmid, int parts = 2);

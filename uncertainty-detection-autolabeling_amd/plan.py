@@ -56,8 +56,10 @@ def mbx_deep(cin):
 
 def mbx_tile(k, stride, cin=16):
     """(TH, TW) output tile of the fused expand+depthwise kernels (mirror of mbx_cfg / mbxd_kernel in csrc)."""
-    if mbx_deep(cin):
-        return (12, 16) if k == 3 else (8, 16)
+    if mbx_deep(cin):       # mirror of mbxd_cfg
+        if stride == 1:
+            return (12, 16) if k == 3 else (8, 16)
+        return (7, 8) if k == 3 else (4, 10)
     import os
     if int(os.environ.get("UDA_PW_TERMS", "3")) == 0 or not int(os.environ.get("UDA_MBX_BF16", "1")):
         return (8, 16) if stride == 1 else ((4, 16) if k == 3 else (4, 8))      # f32-MFMA fallback kernel (mbx_cfg)
@@ -79,9 +81,11 @@ def mbx_supported(cin, cmid, k, stride):
         # (mbxb_kernel / mbxd_kernel<..., PARTS = 3>, csrc/kernels_pwb.hip) and stay fused; UDA_FUSE_MBX6=0 restores the
         # round-2 behaviour (stand-alone six-term 1x1 convs + depthwise) for A/B runs
         return False
-    if mbx_deep(cin):       # mirror of mbxd_supported: stride 1, 16-deep k-steps of Cin + 1 in {6, 8, 13, 14}, split-bf16 path on
+    if mbx_deep(cin):       # mirror of mbxd_supported: 16-deep k-steps of Cin + 1 in {6, 8, 13, 14}, split-bf16 path on
         return (int(os.environ.get("UDA_FUSE_MBXD", "1")) and int(os.environ.get("UDA_PW_TERMS", "3")) != 0
-                and int(os.environ.get("UDA_MBX_BF16", "1")) and stride == 1 and (cin + 1 + 15) // 16 in (6, 8, 13, 14)
+                and int(os.environ.get("UDA_MBX_BF16", "1"))
+                and (stride == 1 or (stride == 2 and int(os.environ.get("UDA_FUSE_MBXD_S2", "1"))))
+                and (cin + 1 + 15) // 16 in (6, 8, 13, 14)
                 and (cin + 1 + 15) // 16 <= int(os.environ.get("UDA_MBXD_MAXKSF", "14")))
     return 16 <= cin and stride in (1, 2)
 
