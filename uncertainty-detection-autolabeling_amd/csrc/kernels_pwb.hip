@@ -934,19 +934,33 @@ void launch_mbxb(const MbxArgs& a, int rows, int k, int stride, hipStream_t s) {
 // from LDS at their use instead of living in registers; with two blocks per CU the expand phase of one block (MFMA +
 // transcendentals) overlaps the depthwise phase of the other (FMA + LDS) - with one block both phases run in lockstep.)
 struct MbxCfgD { int th, tw, xw; };
-// output tile and outputs per depthwise unit of the deep kernel: stride 1: 12 x 16 (3x3, 14 x 18 = 252 input pixels) / 8 x 16
+// output tile and outputs per depthwise unit of the deep kernels: stride 1: 12 x 16 (3x3, 14 x 18 = 252 input pixels) / 8 x 16
 // (5x5, 12 x 20 = 240); stride 2 (the first block of a stage, e.g. EfficientNet-B0 block 11: 5x5, 112 -> 672): 4 x 10
-// (11 x 23 = 253) / 7 x 8 (3x3, 15 x 17 = 255) - the tiles of mbxb_kernel
-__host__ __device__ constexpr MbxCfgD mbxd_cfg(int k, int s) {
-  return s == 1 ? (k == 3 ? MbxCfgD{12, 16, 4} : MbxCfgD{8, 16, 8}) : (k == 3 ? MbxCfgD{7, 8, 8} : MbxCfgD{4, 10, 5});
+// (11 x 23 = 253) / 7 x 8 (3x3, 15 x 17 = 255) - the tiles of mbxb_kernel.  WIDE (stride 1): 20 columns - 8 x 20 (3x3, 10 x 22 =
+// 220) / 6 x 20 (5x5, 10 x 24 = 240) for maps whose width 16 does not divide: the 24 x 40 maps of blocks 12-15 at 1280 x 768 take
+// 8 whole tiles per image instead of 9 of which 3 are half empty (and guarded output by output).
+__host__ __device__ constexpr MbxCfgD mbxd_cfg(int k, int s, bool wide = false) {
+  return s == 1 ? (wide ? (k == 3 ? MbxCfgD{8, 20, 10} : MbxCfgD{6, 20, 4}) : (k == 3 ? MbxCfgD{12, 16, 4} : MbxCfgD{8, 16, 8}))
+                : (k == 3 ? MbxCfgD{7, 8, 8} : MbxCfgD{4, 10, 5});
+}
+// the planner (plan.mbx_tile) and the launchers agree on this rule: the wide tile when it covers the map with fewer output slots
+__host__ __device__ constexpr long long mbxd_slots(int Ho, int Wo, int k, bool wide) {
+  return (long long)((Ho + mbxd_cfg(k, 1, wide).th - 1) / mbxd_cfg(k, 1, wide).th) * mbxd_cfg(k, 1, wide).th *
+         ((Wo + mbxd_cfg(k, 1, wide).tw - 1) / mbxd_cfg(k, 1, wide).tw) * mbxd_cfg(k, 1, wide).tw;
+}
+bool mbxd_wide(int Ho, int Wo, int k, int stride) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("UDA_MBXD_WIDE"); on = e ? atoi(e) : 1; }
+  return on && stride == 1 && mbxd_slots(Ho, Wo, k, true) < mbxd_slots(Ho, Wo, k, false);
 }
 
-template <int K, int KSF, int PARTS, int S>
+template <int K, int KSF, int PARTS, int S, bool WIDE>
 __global__ __launch_bounds__(512, (KSF <= 8 && PARTS == 2) ? 4 : 2) void mbxd_kernel(MbxArgs a) {
   constexpr bool WK_LDS = (K == 5 && (KSF <= 8 || PARTS == 3));     // the 25 taps from LDS at their use, not 25 registers
 
   constexpr int NW = 8;
-  constexpr int TH = mbxd_cfg(K, S).th, TW = mbxd_cfg(K, S).tw;
+  static_assert(!WIDE || S == 1, "wide tiles are a stride-1 variant");
+  constexpr int TH = mbxd_cfg(K, S, WIDE).th, TW = mbxd_cfg(K, S, WIDE).tw;
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
   constexpr int NP = IH * IW;
   static_assert(NP <= 256, "input tile must fit 8 slices of 32 pixels");
@@ -956,7 +970,8 @@ __global__ __launch_bounds__(512, (KSF <= 8 && PARTS == 2) ? 4 : 2) void mbxd_ke
   constexpr int ETW = mbx_et_w(K, S);         // E transposed, [channel][pixel] (stride 1 only, see mbx_et_w); 32 * CP <= NPP * ES floats
   constexpr bool ET = ETW != 0;
   constexpr int CP = mbx_et_pitch(ETW);
-  constexpr int XW = mbxd_cfg(K, S).xw;       // outputs per unit along x
+  static_assert(!ET || (IW % ETW == 0 && mbxd_cfg(K, S, WIDE).xw % ETW == 0), "aligned wide accesses of the transposed slab");
+  constexpr int XW = mbxd_cfg(K, S, WIDE).xw; // outputs per unit along x
   constexpr int UPR = TW / XW;                // units per output row
   constexpr int NUNIT = TH * UPR;             // 48 (3x3) / 16 (5x5) units over 16 groups; stride 2: 7 / 8 (half of the groups idle)
   static_assert(TW % XW == 0, "units must tile the output tile");
@@ -1183,10 +1198,10 @@ __global__ __launch_bounds__(512, (KSF <= 8 && PARTS == 2) ? 4 : 2) void mbxd_ke
 // region; the matrix core runs asynchronously to the VALU), then activates that accumulator into the other E buffer.
 // E, the packed weights and the SE sums are double-buffered, the per-slab depthwise block triple-buffered, and ONE
 // barrier per slab remains.
-template <int K, int KSF>
+template <int K, int KSF, bool WIDE>
 __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
   constexpr int NW = 8;
-  constexpr int TH = (K == 3) ? 12 : 8, TW = 16;
+  constexpr int TH = mbxd_cfg(K, 1, WIDE).th, TW = mbxd_cfg(K, 1, WIDE).tw;
   constexpr int IH = TH + K - 1, IW = TW + K - 1;
   constexpr int NP = IH * IW;
   static_assert(NP <= 256, "input tile must fit 8 slices of 32 pixels");
@@ -1196,10 +1211,12 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
   constexpr int ETW = mbx_et_w(K, 1);         // E transposed, [channel][pixel] (see mbx_et_w); 32 * CP <= NPP * ES floats per buffer
   constexpr bool ET = ETW != 0;
   constexpr int CP = mbx_et_pitch(ETW);
-  constexpr int XW = (K == 3) ? 4 : 8;
+  constexpr int XW = mbxd_cfg(K, 1, WIDE).xw;
+  static_assert(!ET || (IW % ETW == 0 && XW % ETW == 0), "aligned wide accesses of the transposed slab");
   constexpr int UPR = TW / XW;
   constexpr int NUNIT = TH * UPR;
-  constexpr int UPT = NUNIT / NG;             // units per thread: 3 (3x3) / 1 (5x5)
+  constexpr int UPT = (NUNIT + NG - 1) / NG;  // units per thread: 3 (3x3) / 1 (5x5); wide: 1 / 2 (30 units: two thread groups idle in the second round)
+  constexpr bool UNIT_GUARD = (NUNIT % NG) != 0;
   constexpr int NCOL = XW + K - 1;
   constexpr int BSLAB = KSF * 2 * 64;
   constexpr int NPAR = (K * K + 2) * 32;
@@ -1276,7 +1293,7 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
   unsigned ooff[UPT];
 #pragma unroll
   for (int ui = 0; ui < UPT; ++ui) {
-    const int u = g + NG * ui;
+    const int u = (UNIT_GUARD && g + NG * ui >= NUNIT) ? 0 : g + NG * ui;      // (an idle unit computes unit 0 again and stores nothing)
     const int orow = u / UPR, oxs = (u % UPR) * XW;
     eoff[ui] = ET ? c * CP + orow * IW + oxs : (orow * IW + oxs) * ES + c;
     ooff[ui] = (unsigned)((orow * a.Wo + oxs) * a.Cmid + c) * 4u;      // bytes
@@ -1439,6 +1456,9 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
       constexpr bool GUARD = decltype(guard)::value;
 #pragma unroll
       for (int ui = 0; ui < UPT; ++ui) {
+        if constexpr (UNIT_GUARD) {
+          if (g + NG * ui >= NUNIT) continue;
+        }
         if constexpr (GUARD) {
           if (oy0 + (g + NG * ui) / UPR >= a.Ho) continue;
         }
@@ -1507,21 +1527,27 @@ static int mbx_ch_groups(long long blocks, int per_cu, int n_slabs) {
   return g < 1 ? 1 : (int)g;
 }
 
-template <int K, int KSF>
-static void launch_mbxp_t(const MbxArgs& a, int rows, hipStream_t s) {
-  constexpr int TH = (K == 3) ? 12 : 8;
+template <int K, int KSF, bool WIDE>
+static void launch_mbxp_tw(const MbxArgs& a, int rows, hipStream_t s) {
+  constexpr int TH = mbxd_cfg(K, 1, WIDE).th, TW = mbxd_cfg(K, 1, WIDE).tw;
   const size_t lds = ((size_t)2 * 256 * 33 + 2 * 16 * 32 + 3 * (K * K + 2) * 32 + 2 * 32 * ((a.Cmid + 31) / 32)) * sizeof(float) +
                      (size_t)2 * KSF * 2 * 64 * sizeof(uint4);
   static size_t attr_lds = 64 * 1024;
   if (lds > attr_lds) {
-    hipFuncSetAttribute((const void*)mbxp_kernel<K, KSF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)mbxp_kernel<K, KSF, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_lds = lds;
   }
-  dim3 grid((a.Wo + 15) / 16, (a.Ho + TH - 1) / TH, rows);
+  dim3 grid((a.Wo + TW - 1) / TW, (a.Ho + TH - 1) / TH, rows);
   MbxArgs b = a;
   b.ch_groups = mbx_ch_groups((long long)grid.x * grid.y * rows, 1, (a.Cmid + 31) / 32);
   grid.z = (unsigned)(rows * b.ch_groups);
-  hipLaunchKernelGGL((mbxp_kernel<K, KSF>), grid, dim3(512), lds, s, b);
+  hipLaunchKernelGGL((mbxp_kernel<K, KSF, WIDE>), grid, dim3(512), lds, s, b);
+}
+
+template <int K, int KSF>
+static void launch_mbxp_t(const MbxArgs& a, int rows, hipStream_t s) {
+  if (mbxd_wide(a.Ho, a.Wo, K, 1)) launch_mbxp_tw<K, KSF, true>(a, rows, s);
+  else launch_mbxp_tw<K, KSF, false>(a, rows, s);
 }
 
 bool mbxd_supported(int Cin, int Cmid, int k, int stride) {
@@ -1537,25 +1563,33 @@ bool mbxd_supported(int Cin, int Cmid, int k, int stride) {
 }
 
 int mbxd_tiles(int Ho, int Wo, int k, int stride) {
-  const MbxCfgD c = mbxd_cfg(k, stride);
+  const MbxCfgD c = mbxd_cfg(k, stride, mbxd_wide(Ho, Wo, k, stride));
   return ((Ho + c.th - 1) / c.th) * ((Wo + c.tw - 1) / c.tw);
 }
 
-template <int K, int KSF, int PARTS, int S>
-static void launch_mbxd_t(const MbxArgs& a, int rows, hipStream_t s) {
-  constexpr int TH = mbxd_cfg(K, S).th, TW = mbxd_cfg(K, S).tw;
+template <int K, int KSF, int PARTS, int S, bool WIDE>
+static void launch_mbxd_tw(const MbxArgs& a, int rows, hipStream_t s) {
+  constexpr int TH = mbxd_cfg(K, S, WIDE).th, TW = mbxd_cfg(K, S, WIDE).tw;
   const size_t lds = ((size_t)256 * 33 + 16 * 32 + 2 * (K * K + 2) * 32 + 2 * 32 * ((a.Cmid + 31) / 32)) * sizeof(float) +
                      (size_t)KSF * PARTS * 64 * sizeof(uint4);
   static size_t attr_lds = 64 * 1024;      // above the default limit the kernel needs an explicit opt-in
   if (lds > attr_lds) {
-    hipFuncSetAttribute((const void*)mbxd_kernel<K, KSF, PARTS, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)mbxd_kernel<K, KSF, PARTS, S, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_lds = lds;
   }
   dim3 grid((a.Wo + TW - 1) / TW, (a.Ho + TH - 1) / TH, rows);
   MbxArgs b = a;
   b.ch_groups = mbx_ch_groups((long long)grid.x * grid.y * rows, (KSF <= 8 && PARTS == 2) ? 2 : 1, (a.Cmid + 31) / 32);
   grid.z = (unsigned)(rows * b.ch_groups);
-  hipLaunchKernelGGL((mbxd_kernel<K, KSF, PARTS, S>), grid, dim3(512), lds, s, b);
+  hipLaunchKernelGGL((mbxd_kernel<K, KSF, PARTS, S, WIDE>), grid, dim3(512), lds, s, b);
+}
+
+template <int K, int KSF, int PARTS, int S>
+static void launch_mbxd_t(const MbxArgs& a, int rows, hipStream_t s) {
+  if constexpr (S == 1) {
+    if (mbxd_wide(a.Ho, a.Wo, K, 1)) { launch_mbxd_tw<K, KSF, PARTS, 1, true>(a, rows, s); return; }
+  }
+  launch_mbxd_tw<K, KSF, PARTS, S, false>(a, rows, s);
 }
 
 template <int PARTS, int S>

@@ -799,6 +799,7 @@ struct ChunkView {
   uda_ctx* c;
   int i0, nc;
   int lane = 0;
+  int sub0 = 0;      // first image of a sub-chunk inside the chunk (experiment UDA_MALL_IMAGES: a block's ops on a few images at a time)
   hipStream_t stream() const { return c->lane_stream[lane]; }
   int rows(const uda_buf_desc_t& b) const { return nc * (b.per_sample ? c->model.mc_samples : 1); }
   float* ptr(int id) const {
@@ -806,16 +807,16 @@ struct ChunkView {
     const size_t per = (size_t)b.H * b.W * b.C;
     const int T = c->model.mc_samples;
     switch (b.kind) {
-      case 1: return c->d_images + (size_t)i0 * per;
-      case 2: return c->d_cls[b.level] + (size_t)i0 * (b.per_sample ? T : 1) * per;
-      case 3: return c->d_box[b.level] + (size_t)i0 * (b.per_sample ? T : 1) * per;
-      default: return c->lane_arena[lane] + b.offset;
+      case 1: return c->d_images + (size_t)(i0 + sub0) * per;
+      case 2: return c->d_cls[b.level] + (size_t)(i0 + sub0) * (b.per_sample ? T : 1) * per;
+      case 3: return c->d_box[b.level] + (size_t)(i0 + sub0) * (b.per_sample ? T : 1) * per;
+      default: return c->lane_arena[lane] + b.offset + (size_t)sub0 * (b.per_sample ? T : 1) * per;
     }
   }
   const float* wt(int64_t off) const { return off < 0 ? nullptr : c->d_weights + off; }
   const float* mask(int site) const {
     if (site < 0) return nullptr;
-    return c->d_masks + c->site_off[site] + (size_t)i0 * c->model.mc_samples * c->sites[site].channels;
+    return c->d_masks + c->site_off[site] + (size_t)(i0 + sub0) * c->model.mc_samples * c->sites[site].channels;
   }
   int div(const uda_buf_desc_t& in, const uda_buf_desc_t& out) const {
     return (out.per_sample && !in.per_sample) ? c->model.mc_samples : 1;
@@ -1136,6 +1137,24 @@ static int run_network(uda_ctx* c, int post_mode = 0, bool chunk_post = false) {
     ChunkView v{c, i0, (n - i0 < m.chunk_images) ? n - i0 : m.chunk_images};
     v.lane = ci % lanes;
     for (int oi = 0; oi < (int)c->ops.size(); ++oi) {
+      // experiment (UDA_MALL_BLOCKS in the planner + UDA_MALL_IMAGES here): the ops of one backbone block on a few images
+      // at a time, so that the projection reads the expanded depthwise output back out of the Infinity Cache
+      static const int mall_images = getenv("UDA_MALL_IMAGES") ? atoi(getenv("UDA_MALL_IMAGES")) : 0;
+      if (mall_images > 0 && c->ops[oi].reserved0 != 0) {
+        int oe = oi;
+        while (oe < (int)c->ops.size() && c->ops[oe].reserved0 == c->ops[oi].reserved0) ++oe;
+        for (int j = 0; j < v.nc; j += mall_images) {
+          ChunkView sv = v;
+          sv.sub0 = j;
+          sv.nc = v.nc - j < mall_images ? v.nc - j : mall_images;
+          for (int ok = oi; ok < oe; ++ok) {
+            const int rc = run_op(c, sv, ok);
+            if (rc) return rc;
+          }
+        }
+        oi = oe - 1;
+        continue;
+      }
       const int grp = c->ops[oi].launch_group;
       if (grp > 1) {
         const int rg = run_sep_group(c, v, oi, grp);

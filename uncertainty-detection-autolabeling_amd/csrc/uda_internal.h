@@ -174,6 +174,7 @@ void launch_mbxb(const MbxArgs& a, int rows, int k, int stride, hipStream_t s);
 void launch_mbxd(const MbxArgs& a, int rows, int k, int stride, hipStream_t s);     // deep blocks (Cin > 48), stride 1 or 2
 bool mbxd_supported(int Cin, int Cmid, int k, int stride);
 int mbxd_tiles(int Ho, int Wo, int k, int stride = 1);
+bool mbxd_wide(int Ho, int Wo, int k, int stride);     // 20-column tiles for this map (mirror: plan.mbx_tile)
 bool mbxb_supported(int Cin, int Cmid, int k, int stride);
 int mbxb_tiles(int Ho, int Wo, int k, int stride);
 size_t mbxb_packed_elems(int Cin, int Cmid, int parts = 2);

@@ -54,11 +54,17 @@ def mbx_deep(cin):
     return cin > 48
 
 
-def mbx_tile(k, stride, cin=16):
-    """(TH, TW) output tile of the fused expand+depthwise kernels (mirror of mbx_cfg / mbxd_kernel in csrc)."""
+def mbx_tile(k, stride, cin=16, Ho=None, Wo=None):
+    """(TH, TW) output tile of the fused expand+depthwise kernels (mirror of mbx_cfg / mbxd_cfg / mbxd_wide in csrc)."""
     if mbx_deep(cin):       # mirror of mbxd_cfg
         if stride == 1:
-            return (12, 16) if k == 3 else (8, 16)
+            import os
+            normal, wide = ((12, 16), (8, 20)) if k == 3 else ((8, 16), (6, 20))
+            if Ho is not None and int(os.environ.get("UDA_MBXD_WIDE", "1")):
+                slots = lambda t: -(-Ho // t[0]) * t[0] * -(-Wo // t[1]) * t[1]
+                if slots(wide) < slots(normal):      # mbxd_wide: 20-column tiles cover the map with fewer output slots
+                    return wide
+            return normal
         return (7, 8) if k == 3 else (4, 10)
     import os
     if int(os.environ.get("UDA_PW_TERMS", "3")) == 0 or not int(os.environ.get("UDA_MBX_BF16", "1")):
@@ -68,7 +74,7 @@ def mbx_tile(k, stride, cin=16):
 
 
 def mbx_tiles(Ho, Wo, k, stride, cin=16):
-    th, tw = mbx_tile(k, stride, cin)
+    th, tw = mbx_tile(k, stride, cin, Ho, Wo)
     return -(-Ho // th) * -(-Wo // tw)
 
 
@@ -304,7 +310,14 @@ class Plan:
         reductions = []
         red_ids = set(arch.reduction_block_ids(blocks))
         pending_proj = None      # (gate buffer, projection kernel, BN name) of a block whose 1x1 projection the next block absorbs
+        # experiment (UDA_MALL_BLOCKS="first-last", executor: UDA_MALL_IMAGES): the ops of these blocks carry a sub-chunk group
+        # id; the executor runs each such block (fused front half -> SE -> projection) on a few images at a time, so that the
+        # 6x-expanded depthwise output is read back by the projection while the Infinity Cache still holds it
+        import os
+        mall = os.environ.get("UDA_MALL_BLOCKS", "")
+        mall_lo, mall_hi = ([int(v) for v in mall.split("-")] if mall else (1, 0))
         for i, b in enumerate(blocks):
+            first_op = len(self.ops)
             p = "%s/blocks_%d/" % (bb, i)
             bn_names = [p + "tpu_batch_normalization" + ("" if j == 0 else "_%d" % j) for j in range(3)]
             inp, nb = x, 0
@@ -377,6 +390,9 @@ class Plan:
                 continue
             x = self._pw(x, b["cout"], proj, "blocks_%d/out" % i, bn=bn_names[nb], se=gate,
                          residual=inp if b["skip"] else -1)
+            if mall_lo <= i <= mall_hi:
+                for o in self.ops[first_op:]:
+                    o["sub_group"] = i + 1
             if i in red_ids:
                 reductions.append(x)
         lo, hi = cfg["min_level"], cfg["max_level"]
@@ -629,6 +645,7 @@ class Plan:
                       "bn_scale_off", "bn_shift_off", "se_w1_off", "se_b1_off", "se_w2_off", "se_b2_off",
                       "se_mid", "drop_site", "drop_site2", "w2_off", "bn2_scale_off", "bn2_shift_off", "launch_group"):
                 setattr(c, k, int(o[k]))
+            c.reserved0 = int(o.get("sub_group", 0))
         sites = (capi.DropSite * max(1, len(self.sites)))()
         for i, (_, ch, r) in enumerate(self.sites):
             sites[i].channels, sites[i].rate = ch, np.float32(r)
