@@ -165,6 +165,9 @@ int uda_prefetch_images_u8_ragged(uda_ctx_t* ctx, const uint8_t* const* images, 
 int uda_swap_prefetched(uda_ctx_t* ctx);
 /* Same, from a device pointer the caller owns (device-to-device copy on the stream). */
 int uda_set_images_u8_device(uda_ctx_t* ctx, const void* images_dev, int32_t n, int32_t h, int32_t w);
+/* The handle's own device copy of the current uint8 batch (one raw size): lets the members of a deep ensemble share ONE
+ * upload - member 0 takes the host batch, the others uda_set_images_u8_device from its buffer (BASELINE configs[3]). */
+int uda_input_u8_device(uda_ctx_t* ctx, const void** images_dev, int32_t* n, int32_t* h, int32_t* w);
 /* Preprocessed float images [n,H,W,3] (the `only_network` input); scales default to 1. */
 int uda_set_images_f32(uda_ctx_t* ctx, const float* images, int32_t n, const float* image_scales);
 

@@ -414,15 +414,15 @@ def test_image_sharded_serve_equals_unsharded(tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "det")
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="1")
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1", UDA_TEST_MEMBERS=str(members))
         procs.append(subprocess.Popen([sys.executable, "-c", SHARD_WORKER % {"root": ROOT}, out], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     for pr in procs:
         o = pr.communicate(timeout=300)[0]
         assert pr.returncode == 0, o
-    for rank in range(2):
+    for rank in range(world):
         z = np.load(out + ".rank%d.npz" % rank)
         got = [z["arr_%d" % i] for i in range(len(want))]
         for g, r in zip(got, want):
@@ -468,7 +468,7 @@ from uda_amd.infer_lib import KerasDriver, ServingDriver
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 p = make_params(**LOSS_ATT)
-M = 3
+M = int(os.environ.get("UDA_TEST_MEMBERS", "3"))
 imgs = make_images(3, 100, 180, seed=44)
 mine = {m: KerasDriver("_", False, p["name"], batch_size=3, model_params=p, weights=make_weights(p, seed=40 + m, cls_spread=20.0))
         for m in range(M) if udist.member_owner(m, world) == rank}
@@ -482,14 +482,17 @@ for d in list(mine.values()) + [post]:
 '''
 
 
-def test_ensemble_striped_over_ranks_equals_single_process(tmp_path):
-    """BASELINE configs[3] across ranks: members striped over two ranks (gloo, both on GPU 0), heads re-sharded by
-    image, aggregate + NMS per shard, all-gather: bit-identical to the single-process EnsembleDriver."""
+@pytest.mark.parametrize("members,world", [(3, 2), (2, 3)], ids=["3-members-2-ranks", "2-members-3-ranks"])
+def test_ensemble_striped_over_ranks_equals_single_process(tmp_path, members, world):
+    """BASELINE configs[3] across ranks: members striped over the ranks (gloo, all on GPU 0), heads re-sharded by
+    image, aggregate + NMS per shard, all-gather: bit-identical to the single-process EnsembleDriver.  With fewer members
+    than ranks (as `bench.py --gpus 8 --config 3`: 5 members, 8 ranks) the last rank owns no member and still receives,
+    aggregates and gathers its image shard."""
     import os, socket, subprocess, sys
     from common import ROOT
     from uda_amd.infer_lib import EnsembleDriver
     p = make_params(**LOSS_ATT)
-    ws = [make_weights(p, seed=40 + m, cls_spread=20.0) for m in range(3)]
+    ws = [make_weights(p, seed=40 + m, cls_spread=20.0) for m in range(members)]
     imgs = make_images(3, 100, 180, seed=44)
     ens = EnsembleDriver(ws, p["name"], batch_size=3, model_params=p)
     want = ens.serve(imgs)
@@ -497,15 +500,15 @@ def test_ensemble_striped_over_ranks_equals_single_process(tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "ens")
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="1")
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1", UDA_TEST_MEMBERS=str(members))
         procs.append(subprocess.Popen([sys.executable, "-c", STRIPE_WORKER % {"root": ROOT}, out], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     for pr in procs:
         o = pr.communicate(timeout=300)[0]
         assert pr.returncode == 0, o
-    for rank in range(2):
+    for rank in range(world):
         z = np.load(out + ".rank%d.npz" % rank)
         got = [z["arr_%d" % i] for i in range(len(want))]
         for g, r in zip(got, want):

@@ -74,6 +74,7 @@ _SIGNATURES = {
     "uda_set_images_u8": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32]),
     "uda_set_images_u8_device": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32]),
     "uda_set_images_u8_ragged": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
+    "uda_input_u8_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "uda_prefetch_images_u8": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32]),
     "uda_prefetch_images_u8_ragged": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     "uda_swap_prefetched": (C.c_int, [_P]),

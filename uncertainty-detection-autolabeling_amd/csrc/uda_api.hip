@@ -639,7 +639,7 @@ static int ensure_input_streams(uda_ctx* c) {
 // DMA never reads pageable memory (a pageable hipMemcpyAsync is a synchronous, chunked copy) and the caller's arrays are
 // free as soon as this returns.
 static int fill_slot(uda_ctx* c, int si, const void* images, const uint8_t* const* ragged, int n, const int32_t* hs, const int32_t* ws,
-                     hipMemcpyKind kind, hipStream_t st) {
+                     hipMemcpyKind kind, hipStream_t st, bool staged) {
   if (n < 1 || n > c->model.max_images) return fail(c, "set_images: n=%d outside [1, %d]", n, c->model.max_images);
   HIPC(c, hipSetDevice(c->device));
   if (ensure_input_streams(c)) return 1;
@@ -671,7 +671,19 @@ static int fill_slot(uda_ctx* c, int si, const void* images, const uint8_t* cons
   if (kind == hipMemcpyDeviceToDevice) {
     HIPC(c, hipMemcpyAsync(sl.d_img, images, total, kind, st));
     HIPC(c, hipMemcpyAsync(sl.d_geo, sl.geo.data(), (size_t)n * sizeof(PreGeo), hipMemcpyHostToDevice, st));
+  } else if (!staged) {
+    // the feed of a synchronous serve(): the runtime's own pageable-memory path (it stages and pipelines in chunks: 94 MB in
+    // ~2 ms; gathering into the pinned buffer first costs a host memcpy that nothing hides here: 4.6 ms)
+    if (ragged) {
+      for (int i = 0; i < n; ++i)
+        HIPC(c, hipMemcpyAsync(sl.d_img + sl.geo[i].off, ragged[i], (size_t)sl.geo[i].h * sl.geo[i].w * 3, hipMemcpyHostToDevice, st));
+    } else {
+      HIPC(c, hipMemcpyAsync(sl.d_img, images, total, hipMemcpyHostToDevice, st));
+    }
+    HIPC(c, hipMemcpyAsync(sl.d_geo, sl.geo.data(), (size_t)n * sizeof(PreGeo), hipMemcpyHostToDevice, st));
   } else {
+    // prefetch: the host bytes are gathered into the slot's pinned buffer (this memcpy runs while the GPU computes the
+    // current batch) and leave by ONE DMA on the copy stream that never blocks on pageable memory
     if (hdr + total > sl.pcap) {
       if (sl.pinned) HIPC(c, hipHostFree(sl.pinned));
       sl.pinned = nullptr; sl.pcap = 0;
@@ -708,34 +720,45 @@ static int make_current(uda_ctx* c, int si) {
 extern "C" int uda_set_images_u8(uda_ctx_t* c, const uint8_t* images, int32_t n, int32_t h, int32_t w) {
   if (!c || !images) return c ? fail(c, "set_images_u8: NULL images") : 1;
   const int si = c->cur;
-  const int rc = fill_slot(c, si, images, nullptr, n, &h, &w, hipMemcpyHostToDevice, c->stream);
+  const int rc = fill_slot(c, si, images, nullptr, n, &h, &w, hipMemcpyHostToDevice, c->stream, false);
   return rc ? rc : make_current(c, si);
 }
 
 extern "C" int uda_set_images_u8_device(uda_ctx_t* c, const void* images_dev, int32_t n, int32_t h, int32_t w) {
   if (!c || !images_dev) return c ? fail(c, "set_images_u8_device: NULL images") : 1;
   const int si = c->cur;
-  const int rc = fill_slot(c, si, images_dev, nullptr, n, &h, &w, hipMemcpyDeviceToDevice, c->stream);
+  const int rc = fill_slot(c, si, images_dev, nullptr, n, &h, &w, hipMemcpyDeviceToDevice, c->stream, false);
   return rc ? rc : make_current(c, si);
 }
 
 extern "C" int uda_set_images_u8_ragged(uda_ctx_t* c, const uint8_t* const* images, int32_t n, const int32_t* h, const int32_t* w) {
   if (!c || !images || !h || !w) return c ? fail(c, "set_images_u8_ragged: NULL argument") : 1;
   const int si = c->cur;
-  const int rc = fill_slot(c, si, nullptr, images, n, h, w, hipMemcpyHostToDevice, c->stream);
+  const int rc = fill_slot(c, si, nullptr, images, n, h, w, hipMemcpyHostToDevice, c->stream, false);
   return rc ? rc : make_current(c, si);
 }
 
 extern "C" int uda_prefetch_images_u8(uda_ctx_t* c, const uint8_t* images, int32_t n, int32_t h, int32_t w) {
   if (!c || !images) return c ? fail(c, "prefetch_images_u8: NULL images") : 1;
   if (ensure_input_streams(c)) return 1;
-  return fill_slot(c, c->cur ^ 1, images, nullptr, n, &h, &w, hipMemcpyHostToDevice, c->copy_stream);
+  return fill_slot(c, c->cur ^ 1, images, nullptr, n, &h, &w, hipMemcpyHostToDevice, c->copy_stream, true);
 }
 
 extern "C" int uda_prefetch_images_u8_ragged(uda_ctx_t* c, const uint8_t* const* images, int32_t n, const int32_t* h, const int32_t* w) {
   if (!c || !images || !h || !w) return c ? fail(c, "prefetch_images_u8_ragged: NULL argument") : 1;
   if (ensure_input_streams(c)) return 1;
-  return fill_slot(c, c->cur ^ 1, nullptr, images, n, h, w, hipMemcpyHostToDevice, c->copy_stream);
+  return fill_slot(c, c->cur ^ 1, nullptr, images, n, h, w, hipMemcpyHostToDevice, c->copy_stream, true);
+}
+
+extern "C" int uda_input_u8_device(uda_ctx_t* c, const void** images_dev, int32_t* n, int32_t* h, int32_t* w) {
+  if (!c || !images_dev || !n || !h || !w) return c ? fail(c, "input_u8_device: NULL argument") : 1;
+  const uda_ctx::U8Slot& sl = c->u8[c->cur];
+  if (!c->have_u8 || !sl.valid) return fail(c, "input_u8_device: no uint8 batch is set");
+  for (int i = 1; i < sl.n; ++i)
+    if (sl.geo[i].h != sl.geo[0].h || sl.geo[i].w != sl.geo[0].w) return fail(c, "input_u8_device: the batch has several raw sizes");
+  HIPC(c, hipEventSynchronize(sl.ev));      // the upload has landed: another handle's stream may read the buffer now
+  *images_dev = sl.d_img; *n = sl.n; *h = sl.geo[0].h; *w = sl.geo[0].w;
+  return 0;
 }
 
 extern "C" int uda_swap_prefetched(uda_ctx_t* c) {

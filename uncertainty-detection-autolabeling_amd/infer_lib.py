@@ -662,8 +662,16 @@ class EnsembleDriver:
 
     def serve(self, image_arrays, post_mode=None):
         lib = self.post._lib
+        shared = None           # (device pointer, n, h, w) of member 0's uploaded batch: ONE upload, the others copy device-to-device
         for m, drv in enumerate(self.members):
-            n = drv._feed(image_arrays)
+            if m == 0 or shared is None:
+                n = drv._feed(image_arrays)
+                if m == 0 and all(d.device == drv.device for d in self.members):
+                    ptr, nn, hh, ww = C.c_void_p(), C.c_int32(), C.c_int32(), C.c_int32()
+                    if lib.uda_input_u8_device(drv._h, C.byref(ptr), C.byref(nn), C.byref(hh), C.byref(ww)) == 0:   # (one raw size)
+                        shared = (ptr, nn.value, hh.value, ww.value)
+            else:
+                drv._ck(lib.uda_set_images_u8_device(drv._h, *shared), "uda_set_images_u8_device")
             drv._ck(lib.uda_run(drv._h, -1, 0), "uda_run")
             self.post._ck(lib.uda_copy_heads(self.post._h, drv._h, n, m), "uda_copy_heads")
         self.post._run_id += 1
