@@ -183,6 +183,14 @@ def test_serve_calibrate_write_parse_chain(tmp_path):
                 np.testing.assert_allclose(np.float32(L[m + "_entropy"]), r4(ent[row]), atol=3e-4)
                 np.testing.assert_allclose(np.asarray(L[m + "_mcclass"], np.float32), r4(unc[row]), atol=1.5e-4)
 
+    # ---- the same flow as one call over two batches (feed hidden, calibration while each batch is resident): same lines
+    path2 = str(tmp_path / "prediction_data_stream.txt")
+    d.set_dropout_seed(5)
+    nrec = W.predict_to_file(d, [imgs, imgs[:2]], [names, ["a", "b"]], path2, thr, bc, cc, tuple(box_models), tuple(cls_models))
+    lines2 = open(path2).read().splitlines()
+    assert nrec == len(lines2) and lines2[:len(lines)] == open(path).read().splitlines()
+    assert len(lines2) > len(lines) and ast.literal_eval(lines2[len(lines)])["image_name"] == "a.jpg"
+
     # ---- validate_results.txt: detections "matched" to synthetic ground truth (the assignment itself is host analysis)
     keep = [(i, s) for i in range(3) for s in np.where(det[1][i] > thr)[0]][:7]
     filt = dict(names=[names[i] for i, _ in keep], scores=np.array([det[1][i][s] for i, s in keep]),

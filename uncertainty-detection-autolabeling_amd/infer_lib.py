@@ -246,10 +246,13 @@ class ServingDriver:
         validate_model.py:479-483, infer_model.py:554-581); raw sizes may differ."""
         return self.serve(read_images(paths), post_mode=post_mode)
 
-    def serve_stream(self, batches, post_mode=None):
+    def serve_stream(self, batches, post_mode=None, while_resident=None):
         """Generator over batches (arrays or lists of images): yields each batch's detections, with the upload of batch
         i + 1 (pinned staging buffer, copy stream) running under the network of batch i - the feed the reference pays
-        inside every serve() call (validate_model.py:154-158) costs no device time here."""
+        inside every serve() call (validate_model.py:154-158) costs no device time here.
+        while_resident(detections): optional callable run while the batch's outputs are still resident in the handle
+        (softmax / entropy, calibrators: everything `class_probs`, `BoxCalibrator`, `ClassCalibrator` read); its return
+        value is yielded instead of the detection tuple."""
         mode = self._mode(post_mode)
         it = iter(batches)
         try:
@@ -264,7 +267,8 @@ class ServingDriver:
             nxt = next(it, None)
             n_next = self._feed(nxt, prefetch=True) if nxt is not None else 0  # overlaps the kernels queued above
             self._last_n = n
-            yield self._collect(n, mode)                                      # waits for this batch
+            det = self._collect(n, mode)                                      # waits for this batch
+            yield det if while_resident is None else while_resident(det)
             if nxt is None:
                 return
             self._ck(self._lib.uda_swap_prefetched(self._h), "uda_swap_prefetched")

@@ -94,6 +94,46 @@ def write_prediction_data(path, records):
             f.write(str(r) + "\n")
 
 
+def predict_to_file(driver, batches, names, path, min_score, box_calibrator=None, class_calibrator=None,
+                    box_methods=(), class_methods=()):
+    """The inference flow of `Infer.iterate_infer` (infer_model.py:554-960) as ONE loop over batches of images (arrays, or
+    lists of images of different raw sizes): serve (feed of the next batch hidden under this one) -> unpack + softmax /
+    entropy (device) -> calibrated box / class uncertainties (device, `calibration.BoxCalibrator` / `ClassCalibrator`)
+    -> `prediction_data.txt` lines appended to `path`.  `names`: one list of image names per batch.  Returns the number
+    of records written."""
+    from . import postprocess as pp
+    names = list(names)
+    state = {"i": 0, "written": 0}
+
+    def per_batch(det):
+        n = det[0].shape[0]
+        probs = ent = None
+        if driver.params["enable_softmax"]:
+            probs, ent = driver.class_probs(n)
+        un = pp.unpack_detections(driver.params, det, probs, ent)
+        cal = {}
+        if box_calibrator is not None:
+            for m in box_methods:
+                for which in ("albox", "mcbox"):
+                    if un.get(which) is not None:
+                        cal["%s_%s" % (m, which)] = box_calibrator.calibrate_boxuncert(n, which, m)
+        if class_calibrator is not None and un.get("logits") is not None:
+            for m in class_methods:
+                r = class_calibrator.perform_class_calib(n, m)
+                cal[m + "_entropy"], cal[m + "_probab"] = r[0], r[1]
+                if len(r) > 2:
+                    cal[m + "_mcclass"] = r[2]
+        recs = prediction_records(un, names[state["i"]], min_score, cal)
+        write_prediction_data(path, recs)
+        state["i"] += 1
+        state["written"] += len(recs)
+        return len(recs)
+
+    for _ in driver.serve_stream(batches, while_resident=per_batch):
+        pass
+    return state["written"]
+
+
 def validate_records(filtered, params, calibrated=None):
     """Records of `validate_results.txt` (validate_model.py:524-681) from the per-detection arrays the validation
     harness keeps after ground-truth assignment (CPU numpy analysis outside the hot path).
