@@ -414,9 +414,10 @@ def test_image_sharded_serve_equals_unsharded(tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "det")
     procs = []
+    world = 2
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="1", UDA_TEST_MEMBERS=str(members))
+                   OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, "-c", SHARD_WORKER % {"root": ROOT}, out], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     for pr in procs:
