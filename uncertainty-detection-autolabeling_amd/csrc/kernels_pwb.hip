@@ -579,15 +579,25 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF, PARTS)) void mbxb_ker
   bf16x8 w0p[2][PARTS];
   float sh0v[8];
   if constexpr (FUSE0) {
-    const float* gp = a.gate + (size_t)(b / a.g_div) * a.c0;
+    if (a.w0frag) {
+      // the gated, split projection kernel of this sample row comes ready-made from w0gate_kernel: every one of the ~1100 tiles
+      // of a row used to redo the same 16 multiplies + 2 splits (a tenth of this kernel's vector instructions)
+      const uint4* fp = a.w0frag + (size_t)(b / a.g_div) * (2 * PARTS * 64) + lane;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int k = ks * 16 + 8 * lh;
-      float4 w0 = *(const float4*)(a.w0t + li * 32 + k), w1 = *(const float4*)(a.w0t + li * 32 + k + 4);
-      const float4 g0 = *(const float4*)(gp + k), g1 = *(const float4*)(gp + k + 4);
-      w0.x *= g0.x; w0.y *= g0.y; w0.z *= g0.z; w0.w *= g0.w;
-      w1.x *= g1.x; w1.y *= g1.y; w1.z *= g1.z; w1.w *= g1.w;
-      split_parts<PARTS>(w0, w1, w0p[ks]);
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int p_ = 0; p_ < PARTS; ++p_) w0p[ks][p_] = __builtin_bit_cast(bf16x8, fp[(ks * PARTS + p_) * 64]);
+    } else {
+      const float* gp = a.gate + (size_t)(b / a.g_div) * a.c0;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int k = ks * 16 + 8 * lh;
+        float4 w0 = *(const float4*)(a.w0t + li * 32 + k), w1 = *(const float4*)(a.w0t + li * 32 + k + 4);
+        const float4 g0 = *(const float4*)(gp + k), g1 = *(const float4*)(gp + k + 4);
+        w0.x *= g0.x; w0.y *= g0.y; w0.z *= g0.z; w0.w *= g0.w;
+        w1.x *= g1.x; w1.y *= g1.y; w1.z *= g1.z; w1.w *= g1.w;
+        split_parts<PARTS>(w0, w1, w0p[ks]);
+      }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) sh0v[j] = a.sh0f[(j & 3) + 8 * (j >> 2) + 4 * lh];
@@ -863,6 +873,34 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF, PARTS)) void mbxb_ker
         for (int p_ = 0; p_ < PARTS; ++p_) rb[ks][p_] = nbr[ks][p_];
     }
   }
+}
+
+// FUSE0 operand prep: A' = W0^T x gate of every gate row, split into PARTS bf16 pieces and laid out as the A fragments the
+// fused kernel's prologue wants ([row][k-step][piece][lane] x 16 B) - the same arithmetic, once per sample row instead of once
+// per tile.  One wave per gate row.
+template <int PARTS>
+__global__ __launch_bounds__(64) void w0gate_kernel(const float* gate, const float* w0t, int c0, uint4* out) {
+  const int row = blockIdx.x, lane = threadIdx.x, li = lane & 31, lh = lane >> 5;
+  const float* gp = gate + (size_t)row * c0;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int k = ks * 16 + 8 * lh;
+    float4 w0 = *(const float4*)(w0t + li * 32 + k), w1 = *(const float4*)(w0t + li * 32 + k + 4);
+    const float4 g0 = *(const float4*)(gp + k), g1 = *(const float4*)(gp + k + 4);
+    w0.x *= g0.x; w0.y *= g0.y; w0.z *= g0.z; w0.w *= g0.w;
+    w1.x *= g1.x; w1.y *= g1.y; w1.z *= g1.z; w1.w *= g1.w;
+    bf16x8 pc[PARTS];
+    split_parts<PARTS>(w0, w1, pc);
+#pragma unroll
+    for (int p_ = 0; p_ < PARTS; ++p_) out[((size_t)row * 2 * PARTS + ks * PARTS + p_) * 64 + lane] = __builtin_bit_cast(uint4, pc[p_]);
+  }
+}
+
+// gate rows x (2 k-steps x parts x 64 lanes) uint4
+size_t mbxb_w0frag_elems(int gate_rows, int parts) { return (size_t)gate_rows * 2 * parts * 64; }
+void launch_w0gate(const float* gate, const float* w0t, int c0, int gate_rows, int parts, uint4* out, hipStream_t s) {
+  if (parts == 3) hipLaunchKernelGGL(w0gate_kernel<3>, dim3(gate_rows), dim3(64), 0, s, gate, w0t, c0, out);
+  else hipLaunchKernelGGL(w0gate_kernel<2>, dim3(gate_rows), dim3(64), 0, s, gate, w0t, c0, out);
 }
 
 int mbxb_tiles(int Ho, int Wo, int k, int stride) {

@@ -41,6 +41,8 @@ struct uda_ctx {
   std::vector<int64_t> wpar_off;   // MBX: offset (uint16 units) of the per-slab depthwise operand block inside d_wsplit
   int pw_parts = 2;            // UDA_PW_TERMS: 3 -> 2 pieces (default), 6 -> 3 pieces, 0 -> f32 MFMA everywhere
   float* d_arena = nullptr;
+  uint4* d_w0frag = nullptr;       // gated, split projection kernel per gate row for the fused block-1 kernel (launch_w0gate)
+  size_t w0frag_cap = 0;
   // chunk lanes: consecutive chunks alternate between independent (stream, arena) pairs so that the
   // barrier-heavy kernels of one chunk overlap the streaming kernels of the other
   int n_lanes = 1;
@@ -238,6 +240,7 @@ extern "C" void uda_destroy(uda_ctx_t* c) {
   }
   for (auto& e : c->ev_pre_done) if (e) hipEventDestroy(e);
   if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+  if (c->d_w0frag) hipFree(c->d_w0frag);
   void* ptrs[] = {c->d_weights, c->d_wsplit, c->d_arena, c->d_anchors, c->d_images, c->d_scales, c->d_masks,
                   c->d_site_off, c->d_site_ch, c->d_site_rate, c->d_cboxes, c->d_cscores, c->d_clogits,
                   c->d_cclasses, c->d_ucls, c->d_ual, c->d_uep, c->d_clsmean, c->d_cand_flat, c->d_merge_keys,
@@ -971,6 +974,20 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
           a.c0 = ib.C;
           a.w0t = a.wpar + mbx_par_floats(ob.C, o.k);
           a.sh0f = a.w0t + 32 * 32;
+          static const bool pre = !(getenv("UDA_W0GATE") && atoi(getenv("UDA_W0GATE")) == 0);   // 0: every block redoes the prep
+          if (pre && ib.C == 32) {
+            const int gate_rows = v.rows(gb);
+            const size_t need = mbxb_w0frag_elems(gate_rows, c->pw_parts);
+            if (need > c->w0frag_cap) {
+              HIPC(c, hipStreamSynchronize(v.stream()));
+              if (c->d_w0frag) HIPC(c, hipFree(c->d_w0frag));
+              c->d_w0frag = nullptr; c->w0frag_cap = 0;
+              HIPC(c, hipMalloc((void**)&c->d_w0frag, need * sizeof(uint4)));
+              c->w0frag_cap = need;
+            }
+            launch_w0gate(a.gate, a.w0t, a.c0, gate_rows, c->pw_parts, c->d_w0frag, v.stream());
+            a.w0frag = c->d_w0frag;
+          }
         }
         if (deep) launch_mbxd(a, rows, o.k, o.stride, v.stream());
         else launch_mbxb(a, rows, o.k, o.stride, v.stream());

@@ -158,6 +158,7 @@ struct MbxArgs {
   const float* gate;      // [rows / g_div, c0] per-sample gate on D (SE gate x deferred dropout), null = not fused
   const float* w0t;       // [32][32] projection kernel^T x BN scale (mbxb_pack_proj)
   const float* sh0f;      // [32] projection BN shift
+  const uint4* w0frag;    // [rows / g_div][2 k-steps][wparts][64 lanes]: W0^T x gate, split, in A-fragment order (launch_w0gate) or null
   int c0, g_div;
   // block order of launches whose input is shared by the in_div samples of an image (mbxb_kernel): 1-D grid, the
   // in_div blocks of one tile adjacent and on ONE XCD (ids = tile slot + 8 t), so that the shared tile is fetched into
@@ -178,6 +179,8 @@ bool mbxd_wide(int Ho, int Wo, int k, int stride);     // 20-column tiles for th
 bool mbxb_supported(int Cin, int Cmid, int k, int stride);
 int mbxb_tiles(int Ho, int Wo, int k, int stride);
 size_t mbxb_packed_elems(int Cin, int Cmid, int parts = 2);
+size_t mbxb_w0frag_elems(int gate_rows, int parts);
+void launch_w0gate(const float* gate, const float* w0t, int c0, int gate_rows, int parts, uint4* out, hipStream_t s);
 void mbxb_pack_weights(const float* we, const float* sc0, const float* sh0, int Cin, int Cmid, uint16_t* out, bool perm16 = false, int parts = 2);
 void launch_mbx(const MbxArgs& a, int rows, int k, int stride, hipStream_t s);
 int mbx_tiles(int Ho, int Wo, int k, int stride);
