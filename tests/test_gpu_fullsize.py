@@ -175,14 +175,18 @@ def test_three_term_products_stay_within_1e3_of_exact_f32_at_full_size(tmp_path)
     exact = runs["0"]
     for terms in ("3", "6"):
         got = runs[terms]
-        tol = 1e-3
+        # three terms (shipped): north_star's 1e-3 on what reaches the caller, the 1e-4 / 2e-4 head bars; six terms
+        # (float32-equivalent, every fusion kept): ten to fifty times tighter - measured at this size (tools/precision_probe.py):
+        # heads 2e-8..2e-7 relative RMS, scores 1e-6, boxes 3e-6 of the box size
+        tol = 1e-3 if terms == "3" else 1e-4
+        head_rms, head_max = (1e-4, 2e-4) if terms == "3" else (2e-6, 1e-5)
         # --- head outputs, per channel group (box deltas | sigma share a tensor: judge each group on its own scale)
         for key, groups in (("h_cls", [(0, 63)]), ("h_box", [(0, 36), (36, 72)])):
             for lo, hi in groups:
                 g, r = got[key][..., lo:hi].astype(np.float64), exact[key][..., lo:hi].astype(np.float64)
                 rel_rms = np.sqrt(np.mean((g - r) ** 2)) / np.sqrt(np.mean(r * r))
-                assert rel_rms <= 1e-4, (terms, key, lo, rel_rms)
-                assert np.abs(g - r).max() <= 2e-4 * np.abs(r).max(), (terms, key, lo)
+                assert rel_rms <= head_rms, (terms, key, lo, rel_rms)
+                assert np.abs(g - r).max() <= head_max * np.abs(r).max(), (terms, key, lo)
         # --- every candidate (index-aligned: the argmax path keeps all anchors)
         same_cls = got["cc"] == exact["cc"]
         assert same_cls.mean() > 0.999                                  # an argmax may flip only between near-tied classes
