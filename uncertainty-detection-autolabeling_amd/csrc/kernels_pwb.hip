@@ -515,8 +515,11 @@ __host__ __device__ constexpr MbxCfgB mbxb_cfg(int k, int s) {
 #endif
 // Three pieces per operand (PARTS = 3, six cross terms, UDA_PW_TERMS=6): half as many operand fragments again per wave, so a
 // block per CU less than the three-term variant.
+#ifndef UDA_MBXB6_W
+#define UDA_MBXB6_W 3      // (four would fit the registers of the 3x3 stride-1 variant, but 43 KB of LDS per block hold three anyway)
+#endif
 #ifndef UDA_MBXB_MINW
-#define UDA_MBXB_MINW(K, S, KSF, PARTS) ((PARTS) == 3 ? (((KSF) <= 2 && (K) == 3) ? 3 : 2) : \
+#define UDA_MBXB_MINW(K, S, KSF, PARTS) ((PARTS) == 3 ? (((KSF) <= 2 && (K) == 3) ? UDA_MBXB6_W : 2) : \
     ((KSF) <= 2 ? ((K) == 3 ? 4 : 3) : (((KSF) <= 3 && ((K) == 3 ? (S) == 2 : UDA_MBXB_WK_LDS)) ? 3 : 2)))
 #endif
 template <int K, int S, int KSF, bool FUSE0, int PARTS>   // KSF = 16-deep MFMA k-steps covering Cin + 1
