@@ -15,6 +15,9 @@ namespace uda {
 // for its 8 x 16 pixel tile and all C channels on the VALU (3-row sliding window per thread, every input element
 // fetched once per block column), splits it into bf16 pieces and writes it straight into the LDS image the MFMA
 // stage reads as its A operand.  One barrier between the two stages; epilogue as in pwb_kernel.
+// Six-term products (PARTS = 3, UDA_PW_TERMS=6): three bf16 images would be 55 KB (two blocks per CU); there the depthwise
+// result goes to LDS as float32 (35 KB: three blocks per CU, as the three-term kernel) and a wave splits the 8 values of a
+// fragment into its three pieces when it loads them - every wave owns its 32 pixel rows, so an element is still split once.
 constexpr int SEP_TH = 8, SEP_TW = 16;
 
 template <int NT, int PARTS, int OCC>     // NT = 32-column tiles of the 1x1 output handled per block (each wave: all of them)
@@ -35,9 +38,11 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
   extern __shared__ __attribute__((aligned(16))) unsigned char slds[];
   const int C = a.C, C4 = C >> 2;
   const int KS = (C + 15) >> 4;            // MFMA k-steps
-  const int arow = KS * 32 + 16;           // bytes per A image row: KS * 16 bf16 + 16 pad (conflict-free ds_read_b128)
-  unsigned char* As = slds;                // [PARTS][BM][arow]
-  uint4* Bs = (uint4*)(slds + (size_t)PARTS * BM * arow);   // [KS][NT][PARTS][64 lanes] x 16 B
+  constexpr bool F32A = PARTS == 3;        // A image kept as float32, split at the fragment loads
+  // bytes per A image row: KS * 16 bf16 (float32) + 16 pad (conflict-free ds_read_b128: 36- / 68-dword pitch at C = 64)
+  const int arow = F32A ? KS * 64 + 16 : KS * 32 + 16;
+  unsigned char* As = slds;                // [PARTS][BM][arow] bf16 pieces, or [BM][arow] float32
+  uint4* Bs = (uint4*)(slds + (size_t)(F32A ? 1 : PARTS) * BM * arow);   // [KS][NT][PARTS][64 lanes] x 16 B
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, b_in = b / a.in_div;
@@ -107,6 +112,10 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
         }
       // split into bf16 pieces -> A image row m = ry * 16 + x, channels 4q .. 4q + 3
       const int m = ry * SEP_TW + x;
+      if constexpr (F32A) {
+        *(float4*)(As + (size_t)m * arow + q * 16) = acc;
+        continue;
+      }
       float r0 = acc.x, r1 = acc.y, r2 = acc.z, r3 = acc.w;
 #pragma unroll
       for (int p = 0; p < PARTS; ++p) {
@@ -121,7 +130,11 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
   }
   // channels beyond C inside the last k-step (C % 16 == 8): zero them once
   if (C & 15) {
-    for (int e = tid; e < PARTS * BM; e += 256) *(uint4*)(As + (size_t)e * arow + (C >> 3) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (F32A) {
+      for (int e = tid; e < 2 * BM; e += 256) *(uint4*)(As + (size_t)(e >> 1) * arow + (C >> 3) * 32 + (e & 1) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+      for (int e = tid; e < PARTS * BM; e += 256) *(uint4*)(As + (size_t)e * arow + (C >> 3) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
   }
   __syncthreads();
 
@@ -133,9 +146,24 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
     for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
   for (int ks = 0; ks < KS; ++ks) {
     bf16x8 af[PARTS];
+    if constexpr (F32A) {
+      const unsigned char* ap = As + (size_t)(wave * 32 + li) * arow + ks * 64 + lh * 32;     // 8 channels of pixel row li
+      const float4 v0 = *(const float4*)ap, v1 = *(const float4*)(ap + 16);
+      float r0 = v0.x, r1 = v0.y, r2 = v0.z, r3 = v0.w, r4 = v1.x, r5 = v1.y, r6 = v1.z, r7 = v1.w;
 #pragma unroll
-    for (int p = 0; p < PARTS; ++p)
-      af[p] = *(const bf16x8*)(As + (size_t)(p * BM + wave * 32 + li) * arow + ks * 32 + lh * 16);
+      for (int p = 0; p < PARTS; ++p) {
+        const unsigned u0 = pack_bf16(r0, r1), u1 = pack_bf16(r2, r3), u2 = pack_bf16(r4, r5), u3 = pack_bf16(r6, r7);
+        af[p] = __builtin_bit_cast(bf16x8, make_uint4(u0, u1, u2, u3));
+        if (p + 1 < PARTS) {
+          r0 -= bf16_lo_f32(u0); r1 -= bf16_hi_f32(u0); r2 -= bf16_lo_f32(u1); r3 -= bf16_hi_f32(u1);
+          r4 -= bf16_lo_f32(u2); r5 -= bf16_hi_f32(u2); r6 -= bf16_lo_f32(u3); r7 -= bf16_hi_f32(u3);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < PARTS; ++p)
+        af[p] = *(const bf16x8*)(As + (size_t)(p * BM + wave * 32 + li) * arow + ks * 32 + lh * 16);
+    }
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       bf16x8 bf[PARTS];
@@ -237,8 +265,9 @@ static int sep_tiles(int H, int W) { return ((W + SEP_TW - 1) / SEP_TW) * ((H + 
 template <int NT>
 static void launch_sep_nt(const SepMulti& m, int rows, int gy, hipStream_t s) {
   const SepArgs& a = m.one;
-  const int KS = (a.C + 15) / 16, arow = KS * 32 + 16;
-  size_t lds = (size_t)a.wparts * 128 * arow + (size_t)KS * NT * a.wparts * 1024;
+  const int KS = (a.C + 15) / 16;
+  const size_t a_img = a.wparts == 3 ? (size_t)128 * (KS * 64 + 16) : (size_t)a.wparts * 128 * (KS * 32 + 16);   // float32 image | bf16 pieces
+  size_t lds = a_img + (size_t)KS * NT * a.wparts * 1024;
   const size_t stg = 4 * 32 * PWB_STG * 4;
   if (lds < stg) lds = stg;
   const dim3 grid(m.n_lv > 0 ? m.tile0[m.n_lv] : sep_tiles(a.H, a.W), gy, rows);
@@ -252,19 +281,20 @@ static void launch_sep_nt(const SepMulti& m, int rows, int gy, hipStream_t s) {
   };
   static int occ = -1;
   if (occ < 0) { const char* e = getenv("UDA_SEP_OCC"); occ = e ? atoi(e) : 3; }   // 3 blocks per CU: measured 14 % faster than 2
-  if (a.wparts == 3) go(sep_kernel<NT, 3, 2>);
+  if (a.wparts == 3) { if (occ >= 3 && NT <= 2) go(sep_kernel<NT, 3, 3>); else go(sep_kernel<NT, 3, 2>); }
   else if (occ >= 3 && NT <= 2) go(sep_kernel<NT, 2, 3>);
   else go(sep_kernel<NT, 2, 2>);
 }
 
 static void launch_sep_any(const SepMulti& m, int rows, hipStream_t s) {
   const int ntl = (m.one.Cout + 31) / 32;
-  // three pieces per operand (UDA_PW_TERMS=6) at 112 channels (D2's BiFPN): the A image (3 x 128 x 240 B) plus the weight
-  // fragments of three or four column tiles exceed the 160 KB of a CU - two column tiles per block, more column blocks
+  // three pieces per operand (UDA_PW_TERMS=6) at 112 channels (D2's BiFPN): the A image (128 x 464 B) plus the weight
+  // fragments of four column tiles (7 x 4 x 3 KB) are 142 KB - two column tiles per block there, more column blocks
   {
-    const int KS = (m.one.C + 15) / 16, arow = KS * 32 + 16;
-    const size_t need = (size_t)m.one.wparts * 128 * arow + (size_t)KS * (ntl < 4 ? ntl : 3) * m.one.wparts * 1024;
-    if (ntl > 2 && need > 140 * 1024) { launch_sep_nt<2>(m, rows, (ntl + 1) / 2, s); return; }
+    const int KS = (m.one.C + 15) / 16;
+    const size_t a_img = m.one.wparts == 3 ? (size_t)128 * (KS * 64 + 16) : (size_t)m.one.wparts * 128 * (KS * 32 + 16);
+    const size_t need = a_img + (size_t)KS * (ntl < 4 ? ntl : 3) * m.one.wparts * 1024;
+    if (ntl > 2 && need > 120 * 1024) { launch_sep_nt<2>(m, rows, (ntl + 1) / 2, s); return; }
   }
   // all columns in one block when they fit four 32-column tiles, else blocks of three
   if (ntl == 1) launch_sep_nt<1>(m, rows, 1, s);
