@@ -147,6 +147,10 @@ void uda_destroy(uda_ctx_t* ctx);
 /* last error of `ctx` (or of the last failed uda_create when ctx == NULL) */
 const char* uda_last_error(const uda_ctx_t* ctx);
 
+/* CRC-32C of a host buffer (continue from `crc`, 0 to start): the per-tensor checksum of the TensorFlow checkpoint bundles
+ * `utils_keras.restore_ckpt` reads (utils_keras.py:125-235); host code, no GPU call. */
+uint32_t uda_crc32c(const void* data, uint64_t n, uint32_t crc);
+
 /* Raw uint8 images [n,h,w,3] from host memory into the handle's device staging buffer (replaces the feed of
  * ServingDriver.serve, infer_lib.py:139-151,232-249).  The bytes are gathered into a pinned host buffer owned by the
  * handle and leave by one DMA: the caller's array is free as soon as the call returns. */

@@ -16,13 +16,18 @@ from uda_amd import ckpt_reader as CR, utils_keras, weights as W
 def test_crc32c_known_answers():
     assert CR._crc32c(b"123456789") == 0xE3069283                    # the standard CRC-32C check value
     assert CR._crc32c(b"") == 0 and CR._crc32c(bytes(32)) == 0x8A9136AA
+    # the library's host-side slicing-by-8 CRC (used when the library is built) and the pure-Python table CRC agree, also
+    # on unaligned lengths and when continued from a running value
+    data = np.random.default_rng(0).integers(0, 256, 100003, dtype=np.uint8).tobytes()
+    assert CR._crc32c_py(b"123456789") == 0xE3069283 and CR._crc32c(data) == CR._crc32c_py(data)
+    assert CR._crc32c(data[1000:], CR._crc32c(data[:1000])) == CR._crc32c_py(data)
     assert CR._masked(0) == 0xA282EAD8                               # LevelDB: rotate right by 15, add the constant
 
 
 def test_name_based_checkpoint_round_trip(tmp_path):
     p = make_params(loss_attenuation=True)
     w = W.init_weights(p, seed=3)
-    prefix = CR.save_checkpoint(str(tmp_path / "model"), w, checksum=False)
+    prefix = CR.save_checkpoint(str(tmp_path / "model"), w, checksum=True)     # every restored tensor is CRC-checked
     raw = open(prefix + ".index", "rb").read()
     assert struct.unpack("<Q", raw[-8:])[0] == 0xDB4775248B80FB57 and os.path.getsize(prefix + ".data-00000-of-00001") == sum(v.nbytes for v in w.values())
     r = CR.BundleReader(prefix)

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "uda_nms_np": (C.c_int, [C.c_int32, _P, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, _P, C.POINTER(C.c_int32)]),
     "uda_per_class_nms_np": (C.c_int, [C.c_int32, _P, _P, _P, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_float, C.c_float, C.c_float, _P]),
+    "uda_crc32c": (C.c_uint32, [_P, C.c_uint64, C.c_uint32]),
     "uda_profile_enable": (C.c_int, [_P, C.c_uint32]),
     "uda_profile_read": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
 }

@@ -14,9 +14,9 @@ and a 40-line protobuf wire decoder, maps the variables to the reference names `
 Pinning: there is no TensorFlow and no checkpoint file in this environment, so the format is restated from
 the published TensorBundle / LevelDB table layouts and exercised only against this module's own writer -
 **format parity unpinned**.  Integrity on read: a tensor whose byte range runs past the end of its data shard raises
-(truncated files never load silently); the per-tensor crc32c (masked as LevelDB does) is verified when `verify_crc` is
-set - always for bundles up to 4 MB, on request for larger ones (pure-Python CRC, ~1 s per MB), and a log line says so
-when it is skipped.
+(truncated files never load silently); the per-tensor crc32c (masked as LevelDB does) is verified on every restore through
+the library's host-side `uda_crc32c` (slicing-by-8; without the built library: bundles up to 4 MB with the pure-Python
+table CRC, ~1 s per MB, and a log line says so when it is skipped).
 """
 import logging
 import os
@@ -190,7 +190,7 @@ class BundleReader:
         if e["sliced"]:
             raise ValueError("partitioned variable %s is not supported" % name)
         raw = self._raw(name)
-        if verify_crc and e["crc32c"] is not None and e["dtype"] != _DT_STRING:
+        if verify_crc and e["crc32c"] and e["dtype"] != _DT_STRING:      # (0 = written without a checksum: save_checkpoint(checksum=False))
             if _masked(_crc32c(raw)) != e["crc32c"]:
                 raise ValueError("checkpoint %s: crc32c mismatch in tensor %s (corrupt data shard)" % (self.prefix, name))
         if e["dtype"] == _DT_STRING:
@@ -246,7 +246,8 @@ def load_checkpoint(path, config, use_ema=True, skip_mismatch=False, verify_crc=
     mismatch raises (KeyError / ValueError, :213-233) - the reference's driver restores with `skip_mismatch=False`
     (infer_lib.py:435).  With `skip_mismatch` the variable keeps its initial value and every such variable is logged.
     Shapes must be equal; only the scalar fusion weights (WSM) may be stored as () or (1,).
-    verify_crc: None = check the per-tensor crc32c for bundles up to 4 MB, True / False = always / never."""
+    verify_crc: None = check the per-tensor crc32c whenever the HIP library is built (its host-side `uda_crc32c`), and for
+    bundles up to 4 MB with the pure-Python fallback; True / False = always / never."""
     path = str(path)
     if os.path.isdir(path):
         path = latest_checkpoint(path) or path
@@ -256,7 +257,7 @@ def load_checkpoint(path, config, use_ema=True, skip_mismatch=False, verify_crc=
     reader = BundleReader(path)
     names = reader.name_map()
     if verify_crc is None:
-        verify_crc = reader.total_bytes() <= _CRC_AUTO_BYTES
+        verify_crc = reader.total_bytes() <= _CRC_AUTO_BYTES or _native_crc() is not None
         if not verify_crc:
             logging.getLogger(__name__).warning(
                 "%s: per-tensor crc32c NOT verified (%.1f MB; pass verify_crc=True to check, ~1 s per MB)",
@@ -294,7 +295,25 @@ def load_checkpoint(path, config, use_ema=True, skip_mismatch=False, verify_crc=
 _CRC_TABLE = None
 
 
+def _native_crc():
+    """uda_crc32c of the HIP library (host code, slicing-by-8: hundreds of MB/s) when the library is built; else None."""
+    try:
+        from . import capi
+        return capi.load().uda_crc32c
+    except Exception:
+        return None
+
+
 def _crc32c(data, crc=0):
+    fn = _native_crc()
+    if fn is not None:
+        buf = np.frombuffer(bytes(data) if not isinstance(data, (bytes, bytearray, np.ndarray)) else data, np.uint8)
+        buf = np.ascontiguousarray(buf)
+        return int(fn(buf.ctypes.data, buf.size, crc))
+    return _crc32c_py(data, crc)
+
+
+def _crc32c_py(data, crc=0):
     global _CRC_TABLE
     if _CRC_TABLE is None:
         tab = []

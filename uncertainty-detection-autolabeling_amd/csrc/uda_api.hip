@@ -1700,6 +1700,35 @@ extern "C" int uda_calibrate_class(uda_ctx_t* c, int32_t mode, int32_t n_tables,
   return 0;
 }
 
+// CRC-32C (Castagnoli, reflected polynomial 0x82F63B78), slicing-by-8 on the host: the per-tensor checksum of TensorFlow
+// checkpoint bundles (ckpt_reader.py verifies every tensor it restores; a pure-Python table CRC manages ~1 MB/s).
+extern "C" uint32_t uda_crc32c(const void* data, uint64_t n, uint32_t crc) {
+  static uint32_t T[8][256];
+  static bool ready = false;
+  if (!ready) {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+      T[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xFFu];
+    ready = true;
+  }
+  const uint8_t* p = (const uint8_t*)data;
+  crc = ~crc;
+  while (n >= 8) {
+    uint64_t w;
+    memcpy(&w, p, 8);
+    w ^= crc;
+    crc = T[7][w & 0xFF] ^ T[6][(w >> 8) & 0xFF] ^ T[5][(w >> 16) & 0xFF] ^ T[4][(w >> 24) & 0xFF] ^
+          T[3][(w >> 32) & 0xFF] ^ T[2][(w >> 40) & 0xFF] ^ T[1][(w >> 48) & 0xFF] ^ T[0][(w >> 56) & 0xFF];
+    p += 8; n -= 8;
+  }
+  while (n--) crc = T[0][(crc ^ *p++) & 0xFFu] ^ (crc >> 8);
+  return ~crc;
+}
+
 extern "C" int uda_serve(uda_ctx_t* c, const uint8_t* images, int32_t n, int32_t h, int32_t w,
                          float* boxes, float* scores, float* classes, int32_t* valid, float* logits) {
   int rc = uda_set_images_u8(c, images, n, h, w);
