@@ -14,14 +14,25 @@ KITTI-resolution images (1280x768), T=10, full MC dropout + loss attenuation, C=
 `--config 2|3|4` selects the per-GPU share of BASELINE configs[2] (BDD-like, C=10, T=20), [3]
 (5-member deep ensemble, members striped over the ranks) or [4] (D2 at 1024x1024, T=30, per-class NMS).
 
+The main leg (value, ms_per_step, roofline, kernel_ms_per_step) runs the shipped default: float32 tensors and accumulators,
+1x1 products as two fp16 pieces per operand with three cross terms on the matrix cores (UDA_PW_SCHEME=f16x2, ~2^-22 per
+product: float32-class arithmetic, held to the same parity bars as the six-term bf16 scheme - tests/test_gpu_ops.py,
+tests/test_gpu_round3.py, tests/test_gpu_fullsize.py).
+
 Prints ONE JSON line (rank 0) with the driver's contract plus
   roofline       dominant kernel kind: algorithmic bytes / HIP-event device time vs the 8 TB/s HBM peak
   cpu_baseline   the CPU oracle (restatement, not TF) timed on a bounded sample in a subprocess
-  precision      ms_per_step of the same workload with six-term ("float32-equivalent") and exact f32-input
-                 MFMA products, each measured in a child process that sets the switch before its first GPU call
-  h2d_inclusive  ms_per_step with a fresh uint8 batch fed inside every step (the reference times serve(image) including
-                 the feed, validate_model.py:154-158): host bytes -> pinned staging -> DMA on the copy stream into the
-                 second input slot while the current batch computes (uda_prefetch_images_u8 / uda_swap_prefetched)
+  precision      the same workload under the other schemes - bf16x3 (three bf16 pieces, six cross terms), bf16x2 (two bf16
+                 pieces, three terms: narrower than float32, a side figure only) and exact f32-input MFMA - each measured in
+                 a child process that carries the switch in its environment before its first GPU call
+  configs        BASELINE configs[2], [3], [4] (per-GPU share) with the main protocol, each in a child process
+  head_only      head-only MC dropout (configs/train/*_head.yaml; SURVEY 8d: 1.545 GMAC per image x sample)
+  nms_spread_scores   the headline workload with a spread score distribution (--cls-spread 20: few confident clusters)
+  rccl_world1    the headline through the process-group path (device-resident all-gather of the detections) in a world of one
+  h2d_inclusive_pipelined / h2d_inclusive_serial   ms_per_step with a fresh uint8 batch fed inside every step (the reference
+                 times serve(image) including the feed, validate_model.py:154-158): pipelined = host bytes -> pinned staging ->
+                 DMA on the copy stream into the second input slot while the current batch computes
+                 (uda_prefetch_images_u8 / uda_swap_prefetched); serial = the upload inside the step, nothing hidden
   ranks          (N > 1) what RCCL actually formed: world size and every rank's device (name, uuid, PCI bus id)
   p50_detect_latency_ms   batch-1 serve() of one image, T as configured, upload and download included
 """
@@ -119,20 +130,30 @@ def cpu_baseline(a):
                 "sample": "failed: %r" % (e,)}
 
 
-def precision_child(a, terms):
-    """ms_per_step of the same workload with UDA_PW_TERMS=<terms>, in a child started with the switch in its environment
-    (the library reads it once, at its first call)."""
-    env = dict(os.environ, UDA_PW_TERMS=str(terms))
+SCHEME_NOTE = {"f16x2": "two fp16 pieces per operand, 3 cross terms (~2^-22 per product; float32-class, the default)",
+               "bf16x3": "three bf16 pieces per operand, 6 cross terms (~2^-24 per product; float32-equivalent)",
+               "bf16x2": "two bf16 pieces per operand, 3 cross terms (~2^-17 per product; narrower than float32)",
+               "f32": "exact f32-input MFMA (unfused deep blocks and separable convs: a debugging reference)"}
+
+
+def child_leg(a, extra=(), env=None, same_shape=True):
+    """One more measurement with the main leg's protocol (--steps / --warmup) in a child process: the library reads its
+    switches once, at its first call, and every leg starts from a fresh GPU context.  Returns the child's short JSON."""
     cmd = [sys.executable, os.path.abspath(__file__), "--child", "--no-cpu-baseline", "--no-side", "--steps", str(a.steps),
-           "--warmup", str(a.warmup), "--config", str(a.config), "--batch", str(a.batch), "--samples", str(a.samples), "--image-size", a.image_size,
-           "--raw-size", a.raw_size, "--classes", str(a.classes), "--variant", a.variant, "--chunk", str(a.chunk), "--model", a.model,
-           "--post-mode", a.post_mode, "--ensemble", str(a.ensemble)]
+           "--warmup", str(a.warmup)]
+    if same_shape:
+        cmd += ["--config", str(a.config), "--batch", str(a.batch), "--samples", str(a.samples), "--image-size", a.image_size,
+                "--raw-size", a.raw_size, "--classes", str(a.classes), "--variant", a.variant, "--chunk", str(a.chunk), "--model", a.model,
+                "--post-mode", a.post_mode, "--ensemble", str(a.ensemble)]
+    cmd += list(extra)
+    e = dict(os.environ)
+    e.update(env or {})
     try:
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=e)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
         return json.loads(line)
-    except Exception as e:
-        return {"ms_per_step": None, "error": repr(e)}
+    except Exception as ex:
+        return {"ms_per_step": None, "error": repr(ex)}
 
 
 def rank_devices(dist, torch, rank, local_rank):
@@ -197,7 +218,7 @@ def main():
     params = make_params(a)
     W_, H_ = [int(v) for v in a.raw_size.lower().split("x")]
     images = np.random.default_rng(2 + rank).integers(0, 256, (a.batch, H_, W_, 3), dtype=np.uint8)
-    terms = os.environ.get("UDA_PW_TERMS", "3")
+    scheme = plan_mod.pw_scheme()
 
     if a.ensemble:
         return ensemble_main(a, params, images, rank, world, local_rank, dist, tdev, ranks_info)
@@ -267,9 +288,14 @@ def main():
 
     if a.child:
         if rank == 0:
-            print(json.dumps({"ms_per_step": round(elapsed / a.steps * 1e3, 2), "value": round(value, 2), "steps": a.steps,
-                              "warmup": a.warmup, "UDA_PW_TERMS": terms,
-                              "kernel_ms_per_step": {KIND_NAMES.get(k, str(k)): round(v[0], 2) for k, v in calib.items()}}), flush=True)
+            print(json.dumps({"ms_per_step": round(elapsed / a.steps * 1e3, 2), "value": round(value, 2), "unit": "images*MC-samples/s",
+                              "steps": a.steps, "warmup": a.warmup, "UDA_PW_SCHEME": scheme,
+                              "workload": "%s, %d images (%s raw, %s network), T=%d (%s), C=%d, %s" % (
+                                  a.model, a.batch, a.raw_size, a.image_size, a.samples, a.variant, a.classes, a.post_mode) +
+                                          ("" if a.cls_spread == 1.0 else ", class-predict kernel x %g" % a.cls_spread) +
+                                          (", process-group path (RCCL, world %d)" % world if dist is not None else ""),
+                              "kernel_ms_per_step": {KIND_NAMES.get(k, str(k)): round(v[0], 2) for k, v in calib.items()},
+                              "nms_coop_fallbacks": drv.nms_coop_fallbacks(), "nms_coop_not_launched": drv.nms_coop_not_launched()}), flush=True)
         drv.close()
         return
 
@@ -287,13 +313,20 @@ def main():
             drv._collect(a.batch)                          # this step's detections (synchronises the compute stream)
             drv.swap_prefetched()
         drv.synchronize()
-        side["h2d_inclusive"] = {"ms_per_step": round((time.perf_counter() - t1) / k_side * 1e3, 2),
-                                 "note": "a fresh uint8 batch (%.0f MB, pageable host memory) fed in every step: gathered into the "
-                                         "handle's pinned staging buffer and uploaded on the copy stream under the previous step's "
-                                         "kernels (uda_prefetch_images_u8 / uda_swap_prefetched)" % (images.nbytes / 1e6)}
+        side["h2d_inclusive_pipelined"] = {"ms_per_step": round((time.perf_counter() - t1) / k_side * 1e3, 2),
+                                           "note": "a fresh uint8 batch (%.0f MB, pageable host memory) fed in every step: gathered into the "
+                                                   "handle's pinned staging buffer and uploaded on the copy stream under the previous step's "
+                                                   "kernels (uda_prefetch_images_u8 / uda_swap_prefetched)" % (images.nbytes / 1e6)}
+        step(upload=True)                                   # warm-up of the serial path (first-touch of its staging path)
+        drv.synchronize()
         t2 = time.perf_counter()
-        drv.stage_images(fresh[0])
-        side["h2d_serial_upload_ms"] = round((time.perf_counter() - t2) * 1e3, 2)
+        for k in range(k_side):
+            drv.stage_images(fresh[k & 1])                  # the upload inside the step, nothing hidden (what serve(images) does)
+            drv.run_resident(sync=True)
+            drv._collect(a.batch)
+        side["h2d_inclusive_serial"] = {"ms_per_step": round((time.perf_counter() - t2) / k_side * 1e3, 2),
+                                        "note": "the same with the upload serial inside every step (the reference's protocol, "
+                                                "validate_model.py:154-158): comparable with rounds 1-2's h2d_inclusive"}
     coop_fb, pfx_fb, coop_nl = drv.nms_coop_fallbacks(), drv.nms_prefix_fallbacks(), drv.nms_coop_not_launched()
     summary = drv.plan.summary()
     drv.close()
@@ -355,7 +388,7 @@ def main():
             "value": round(value, 2), "unit": "images*MC-samples/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "warmup_steps_run": n_warm, "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (tensors and accumulators float32; 1x1 products split-bf16 MFMA x%s)" % terms if terms != "0" else "f32",
+            "dtype": "f32" if scheme == "f32" else "f32 (tensors and accumulators float32; 1x1 products on the matrix cores as %s)" % SCHEME_NOTE[scheme],
             "data": "synthetic",
             "p50_step_ms": round(float(np.median(lat)) * 1e3, 2),
             "config": {"workload": "%s: %s, %d synthetic images (%s raw, %s network) per GPU, MC-dropout T=%d (%s), loss attenuation, "
@@ -364,8 +397,7 @@ def main():
                        "images_per_gpu": a.batch, "mc_samples": a.samples, "chunk_images": a.chunk,
                        "weights": "random init (reference initialisers), seed 0" +
                                   ("" if a.cls_spread == 1.0 else ", class-predict kernel x %g" % a.cls_spread),
-                       "contraction": "float32 tensors and accumulators; 1x1 products as split-bf16 MFMA with %s cross terms "
-                                      "(UDA_PW_TERMS; 6 = float32-equivalent everywhere, 0 = exact f32-input MFMA)" % terms,
+                       "contraction": "UDA_PW_SCHEME=%s: %s" % (scheme, SCHEME_NOTE[scheme]),
                        "sharding": "images across ranks, all-gather of detections", "plan": summary},
             "kernel_ms_per_step": {KIND_NAMES.get(k, str(k)): round(v[0], 2) for k, v in calib.items()},
             "h2d_upload_ms": round(upload_s * 1e3, 1),
@@ -378,15 +410,35 @@ def main():
         }
         line.update(side)
         if world == 1 and not a.no_side:
-            log("GPU part done (%.2f units/s); precision children (UDA_PW_TERMS=6, 0) ..." % value)
-            six, exact = precision_child(a, 6), precision_child(a, 0)
-            line["precision"] = {"default_terms": terms,
-                                 "six_terms_float32_equivalent": six,
-                                 "exact_f32_mfma": exact,
-                                 "note": "same workload and the same --steps / --warmup protocol, each in a child process whose "
-                                         "environment carries the switch before its first GPU call; detection-level effect of 3 "
-                                         "terms vs exact: tests/test_gpu_fullsize.py"}
-            line["value_fp32_equivalent"] = six.get("value")      # images*MC-samples/s with float32-equivalent (six-term) products
+            log("GPU part done (%.2f units/s); child legs: other schemes, other BASELINE configs, side regimes ..." % value)
+            prec = {"main_leg_scheme": scheme,
+                    "note": "same workload and the same --steps / --warmup protocol, each in a child process whose environment "
+                            "carries the switch before its first GPU call; what each scheme does to heads, candidates and "
+                            "detections: tests/test_gpu_fullsize.py (margin-aware), tests/test_gpu_round3.py"}
+            for sch in ("bf16x3", "bf16x2", "f32"):
+                if sch != scheme:
+                    prec[sch] = child_leg(a, env={"UDA_PW_SCHEME": sch})
+                    prec[sch]["scheme"] = SCHEME_NOTE[sch]
+                    log("scheme %s: %s ms/step" % (sch, prec[sch].get("ms_per_step")))
+            line["precision"] = prec
+            if scheme in ("f16x2", "bf16x3"):
+                line["value_fp32_equivalent"] = line["value"]           # the main leg already runs float32-class products
+            line["value_bf16x2"] = prec.get("bf16x2", {}).get("value")  # narrower than float32: a side figure, never `value`
+            if a.config == 1 and a.variant == "full" and a.cls_spread == 1.0:
+                cfgs = {}
+                for n in (2, 3, 4):
+                    cfgs[str(n)] = child_leg(a, ["--config", str(n)], same_shape=False)
+                    cfgs[str(n)]["config"] = CONFIG_NAMES[n]
+                    log("configs[%d]: %s ms/step" % (n, cfgs[str(n)].get("ms_per_step")))
+                line["configs"] = cfgs
+                ho = child_leg(a, ["--variant", "head"], same_shape=False)
+                ho["algorithmic_GMAC_per_unit"] = 1.545      # (backbone + FPN) / T + heads at D0, T = 10
+                ho["note"] = "head-only MC dropout (mc_classheadrate = mc_boxheadrate = 0.05, mc_dropoutrate = 0): backbone + BiFPN once per image"
+                line["head_only"] = ho
+                line["nms_spread_scores"] = child_leg(a, ["--cls-spread", "20"], same_shape=False)
+                line["rccl_world1"] = child_leg(a, ["--force-dist"], same_shape=False)
+                log("head-only %s, spread scores %s, process-group path %s ms/step" % (
+                    ho.get("ms_per_step"), line["nms_spread_scores"].get("ms_per_step"), line["rccl_world1"].get("ms_per_step")))
         if world == 1 and not a.no_cpu_baseline:
             log("timing the CPU oracle on a bounded sample ...")
             line["cpu_baseline"] = cpu_baseline(a)
@@ -438,12 +490,17 @@ def ensemble_main(a, params, images, rank, world, local_rank, dist, tdev, ranks_
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     units = n_total * M * a.steps
-    if rank == 0:
+    if rank == 0 and a.child:
+        print(json.dumps({"ms_per_step": round(elapsed / a.steps * 1e3, 2), "value": round(units / elapsed, 2), "unit": "images*members/s",
+                          "steps": a.steps, "warmup": a.warmup, "UDA_PW_SCHEME": __import__("uda_amd.plan", fromlist=["x"]).pw_scheme(),
+                          "workload": "%d-member deep ensemble of %s, %d images (%s) per GPU, uploads included" % (M, a.model, a.batch, a.image_size)}),
+              flush=True)
+    elif rank == 0:
         print(json.dumps({
             "metric": "images*ensemble-members/sec, 5-member deep ensemble of EfficientDet-D0 (preprocess+net+aggregate+decode+NMS)",
             "value": round(units / elapsed, 2), "unit": "images*members/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (1x1 products split-bf16 MFMA x%s)" % os.environ.get("UDA_PW_TERMS", "3"), "data": "synthetic",
+            "dtype": "f32 (1x1 products: UDA_PW_SCHEME=%s)" % __import__("uda_amd.plan", fromlist=["x"]).pw_scheme(), "data": "synthetic",
             "config": {"workload": "%s: %d-member deep ensemble of %s, %d synthetic images (%s) per GPU, members striped over %d rank(s), "
                                    "uploads included" % (CONFIG_NAMES[3], M, a.model, a.batch, a.image_size, world),
                        "images_per_gpu": a.batch, "members": M}, "ranks": ranks_info}), flush=True)

@@ -292,8 +292,10 @@ int uda_nms(uda_ctx_t* ctx, const float* boxes, const float* scores, int32_t n_i
 /* Standalone 1x1 convolution on host arrays (op-level parity tests and timing of the pointwise kernels):
  * out[r, p, :] = (act(bn(in[r / in_div, p, :] * se[r / in_div, :] @ w + bias)) * mask[r, :]) + res[r, p, :]
  * in [rows/in_div, hw, cin], w [cin, cout], se [rows/in_div, cin], mask [rows, cout], res/out [rows, hw, cout];
- * optional arguments may be NULL.  terms: 0 = f32-input MFMA, 3 / 6 = split-bf16 MFMA with 3 / 6 cross terms
- * (kernels_pwb.hip).  The launch is repeated `reps` times for *avg_ms (HIP events). */
+ * optional arguments may be NULL.  terms: 0 = f32-input MFMA, 3 / 6 = split-bf16 MFMA with 3 / 6 cross terms, 16 = two fp16
+ * pieces per operand with 3 cross terms (the default scheme of the network, UDA_PW_SCHEME=f16x2; fails - it does not
+ * return infinities - when an input exceeds fp16's 65504) (kernels_pwb.hip).  The launch is repeated `reps` times for
+ * *avg_ms (HIP events). */
 int uda_debug_pw(int32_t device, const float* in, const float* w, const float* bias, const float* bn_scale,
                  const float* bn_shift, const float* se, const float* mask, const float* res,
                  int32_t rows, int32_t in_div, int32_t hw, int32_t cin, int32_t cout, int32_t act,

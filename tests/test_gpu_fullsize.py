@@ -147,46 +147,112 @@ print("saved")
 """
 
 
-def _iou(a, b):
-    y0, x0 = np.maximum(a[:, None, 0], b[None, :, 0]), np.maximum(a[:, None, 1], b[None, :, 1])
-    y1, x1 = np.minimum(a[:, None, 2], b[None, :, 2]), np.minimum(a[:, None, 3], b[None, :, 3])
-    inter = np.clip(y1 - y0, 0, None) * np.clip(x1 - x0, 0, None)
-    area = lambda z: (z[:, 2] - z[:, 0]) * (z[:, 3] - z[:, 1])
-    return inter / (area(a)[:, None] + area(b)[None, :] - inter + 1e-9)
+def _iou_1n(box, boxes):
+    """NonMaxSuppressionV5's IoU (float32, corners normalised, empty boxes -> 0) of one box against many."""
+    f = np.float32
+    y0, x0 = np.minimum(boxes[:, 0], boxes[:, 2]), np.minimum(boxes[:, 1], boxes[:, 3])
+    y1, x1 = np.maximum(boxes[:, 0], boxes[:, 2]), np.maximum(boxes[:, 1], boxes[:, 3])
+    by0, bx0, by1, bx1 = min(box[0], box[2]), min(box[1], box[3]), max(box[0], box[2]), max(box[1], box[3])
+    area = (y1 - y0) * (x1 - x0)
+    barea = f((by1 - by0) * (bx1 - bx0))
+    ih = np.maximum(np.minimum(y1, by1) - np.maximum(y0, by0), f(0))
+    iw = np.maximum(np.minimum(x1, bx1) - np.maximum(x0, bx0), f(0))
+    inter = ih * iw
+    with np.errstate(divide="ignore", invalid="ignore"):
+        iou = inter / (area + barea - inter)
+    return np.where((area > 0) & (barea > 0), iou, f(0)).astype(f)
 
 
-def test_three_term_products_stay_within_1e3_of_exact_f32_at_full_size(tmp_path):
-    """The shipped contraction (split-bf16, 3 cross terms) against the exact f32-input MFMA path (UDA_PW_TERMS=0) and the
-    six-term one on the SAME full-size batch: what reaches the caller - scores, boxes, aleatoric / epistemic sigma of
-    every one of the 184 140 candidates per image, and the final detections - stays within north_star's 1e-3.
-    The switch is read once per process, so each mode runs in its own interpreter."""
+def _selection_margins(ex_boxes, ex_scores, te_boxes, te_scores, sel, scale):
+    """Replays the exact run's selection sequence `sel` on BOTH candidate sets with fully updated scores (the score a
+    candidate has when NonMaxSuppressionV5 compares it: its stale score times the weights of every box selected so far,
+    oracle/post_ref.py:239-278).  Per epoch k returns
+      margin[k]  exact run: score of the selected candidate minus the best score of any other live candidate that
+                 OVERLAPS it (IoU > 0: every candidate whose selection before / after it would change its output score - a
+                 superset of the same-object runner-ups with IoU > 0.5),
+      pert[k]    the largest difference between the two runs' updated scores of any candidate at that epoch (measured, it
+                 includes what perturbed boxes do to the decay weights),
+      runner[k]  the index of that best overlapping runner-up (-1: none)."""
+    f = np.float32
+    cur_e, cur_t = ex_scores.astype(f).copy(), te_scores.astype(f).copy()
+    live = np.ones(cur_e.shape, bool)
+    margin, pert, runner = [], [], []
+    for i in sel:
+        iou_e = _iou_1n(ex_boxes[i], ex_boxes)
+        iou_t = _iou_1n(te_boxes[i], te_boxes)
+        live[i] = False
+        over = live & (iou_e > 0)
+        if over.any():
+            j = int(np.argmax(np.where(over, cur_e, -np.inf)))
+            margin.append(float(cur_e[i] - cur_e[j]))
+            runner.append(j)
+        else:
+            margin.append(np.inf)
+            runner.append(-1)
+        pert.append(float(np.abs(cur_t - cur_e)[live | (np.arange(live.size) == i)].max()))
+        cur_e = np.where(live, cur_e * np.exp(np.float64(scale) * iou_e.astype(np.float64) ** 2).astype(f), cur_e)
+        cur_t = np.where(live, cur_t * np.exp(np.float64(scale) * iou_t.astype(np.float64) ** 2).astype(f), cur_t)
+    return np.array(margin), np.array(pert), np.array(runner)
+
+
+SCHEMES = {"bf16x2": (1e-3, 1e-4, 2e-4), "bf16x3": (1e-4, 2e-6, 1e-5), "f16x2": (1e-4, 2e-6, 1e-5)}   # tol, head rel. RMS, head max
+# of the top 20 detections of an image (measured, round 4: f16x2 20 / 20 on both images, bf16x2 20 / 20, bf16x3 20 / 20 and 12 / 10 -
+# one near-tie (margins of 1e-7 against perturbations of 2e-8) flips in the six-term run of image 1 and takes its neighbours along)
+MIN_QUALIFY = {"bf16x2": 8, "bf16x3": 8, "f16x2": 12}      # same anchor AND decayed by the same earlier selections
+MIN_SAME = {"bf16x2": 10, "bf16x3": 10, "f16x2": 15}       # same anchors kept
+
+
+def test_split_products_stay_within_north_star_of_exact_f32_at_full_size(tmp_path, capsys):
+    """Every split scheme of the 1x1 contractions against the exact f32-input MFMA path (UDA_PW_SCHEME=f32) on the SAME
+    full-size batch: what reaches the caller - scores, boxes, aleatoric / epistemic sigma of every one of the 184 140
+    candidates per image, and the final detections - stays within north_star's 1e-3 for two bf16 pieces (three cross
+    terms), and ten times tighter (1e-4; heads 2e-6 relative RMS / 1e-5 max) for the float32-class schemes: three bf16
+    pieces (six terms) and two fp16 pieces (the shipped default).  The switch is read once per process, so each scheme
+    runs in its own interpreter.
+    Detections (postprocess.py:392-413): soft-NMS is discontinuous in the candidates - it keeps ONE of several overlapping
+    anchors whose scores differ in the 5th digit - so the detection-level statement is margin-aware: for every detection of
+    the exact run that the other run represents by the SAME ANCHOR, decayed by the same earlier selections, score, box and
+    both sigmas agree within the tolerance; and a detection the other run represents by a different anchor must be explained
+    by a selection margin (gap to the best overlapping runner-up, computed on fully updated scores) that twice the MEASURED
+    perturbation of those scores can cross - its own or an earlier one."""
     import os
     import subprocess
     import sys
     from common import ROOT
+    from oracle import post_ref as P
     runs = {}
-    for terms in ("3", "0", "6"):
-        out = str(tmp_path / ("t%s.npz" % terms))
-        e = dict(os.environ, UDA_PW_TERMS=terms)
+    for scheme in ["f32"] + list(SCHEMES):
+        out = str(tmp_path / ("t_%s.npz" % scheme))
+        e = dict(os.environ, UDA_PW_SCHEME=scheme)
+        e.pop("UDA_PW_TERMS", None)
         r = subprocess.run([sys.executable, "-c", PRECISION_WORKER % {"root": ROOT}, out], cwd=ROOT, env=e, capture_output=True,
                            text=True, timeout=600)
-        assert r.returncode == 0 and "saved" in r.stdout, (terms, r.stdout[-1500:], r.stderr[-1500:])
-        runs[terms] = dict(np.load(out))
-    exact = runs["0"]
-    for terms in ("3", "6"):
-        got = runs[terms]
-        # three terms (shipped): north_star's 1e-3 on what reaches the caller, the 1e-4 / 2e-4 head bars; six terms
-        # (float32-equivalent, every fusion kept): ten to fifty times tighter - measured at this size (tools/precision_probe.py):
-        # heads 2e-8..2e-7 relative RMS, scores 1e-6, boxes 3e-6 of the box size
-        tol = 1e-3 if terms == "3" else 1e-4
-        head_rms, head_max = (1e-4, 2e-4) if terms == "3" else (2e-6, 1e-5)
+        assert r.returncode == 0 and "saved" in r.stdout, (scheme, r.stdout[-1500:], r.stderr[-1500:])
+        runs[scheme] = dict(np.load(out))
+    exact = runs["f32"]
+    p = make_params(**FULL)
+    soft_sigma, iou_thr, score_thr = P.nms_params(p)
+    M = p["nms_configs"]["max_output_size"] or 100
+    # the exact run's keep list per image, from the oracle's NonMaxSuppressionV5 on the device's own candidates; it must
+    # reproduce the device's detections (ties the anchor indices to what the caller got)
+    keep = {}
+    for name, run in runs.items():
+        keep[name] = []
+        for n in range(2):
+            idx, sc, valid = P.nms_v5(run["cb"][n], run["cs"][n], M, iou_thr, score_thr, soft_sigma, True)
+            np.testing.assert_array_equal(sc, run["s"][n])
+            assert valid == run["v"][n]
+            keep[name].append(idx)
+    report, counts = [], []
+    for scheme, (tol, head_rms, head_max) in SCHEMES.items():
+        got = runs[scheme]
         # --- head outputs, per channel group (box deltas | sigma share a tensor: judge each group on its own scale)
         for key, groups in (("h_cls", [(0, 63)]), ("h_box", [(0, 36), (36, 72)])):
             for lo, hi in groups:
                 g, r = got[key][..., lo:hi].astype(np.float64), exact[key][..., lo:hi].astype(np.float64)
                 rel_rms = np.sqrt(np.mean((g - r) ** 2)) / np.sqrt(np.mean(r * r))
-                assert rel_rms <= head_rms, (terms, key, lo, rel_rms)
-                assert np.abs(g - r).max() <= head_max * np.abs(r).max(), (terms, key, lo)
+                assert rel_rms <= head_rms, (scheme, key, lo, rel_rms)
+                assert np.abs(g - r).max() <= head_max * np.abs(r).max(), (scheme, key, lo)
         # --- every candidate (index-aligned: the argmax path keeps all anchors)
         same_cls = got["cc"] == exact["cc"]
         assert same_cls.mean() > 0.999                                  # an argmax may flip only between near-tied classes
@@ -195,28 +261,55 @@ def test_three_term_products_stay_within_1e3_of_exact_f32_at_full_size(tmp_path)
         assert (np.abs(got["cb"] - exact["cb"]) <= tol * np.maximum(box_scale, 1.0)).all()
         for key in ("ual", "uep"):
             d = np.abs(got[key] - exact[key])
-            assert (d <= tol * np.maximum(exact[key], 1e-2 * np.maximum(box_scale, 1.0))).mean() > 0.999, (terms, key)
-            assert np.sqrt(np.mean(d ** 2)) <= tol * np.sqrt(np.mean(exact[key] ** 2)), (terms, key)
-        # --- final detections.  They are a deterministic function of the candidates (the post-process is bit-exact against the
-        # oracle on identical head outputs), and soft-NMS is discontinuous in them: it keeps ONE of several overlapping
-        # anchors whose scores differ in the 5th digit, so a 1e-7 perturbation of a candidate score can swap the anchor that
-        # represents an object and with it the decay of its neighbours - even the six-term (float32-equivalent) run
-        # differs from the exact one in which anchors it keeps.  What must hold: the same objects are found (a kept box of
-        # the other run overlaps every confident detection), the best detection of an image is the same anchor, and
-        # wherever the same anchor was kept its score / box / sigma agree within the tolerance.
+            assert (d <= tol * np.maximum(exact[key], 1e-2 * np.maximum(box_scale, 1.0))).mean() > 0.999, (scheme, key)
+            assert np.sqrt(np.mean(d ** 2)) <= tol * np.sqrt(np.mean(exact[key] ** 2)), (scheme, key)
+        # --- final detections, margin-aware
         np.testing.assert_array_equal(got["v"], exact["v"])
         for n in range(2):
-            k = 20
-            iou = _iou(exact["b"][n, :k, :4], got["b"][n, :, :4])
-            j = iou.argmax(1)
-            assert (iou.max(1) > 0.3).mean() >= 0.8, (terms, n, iou.max(1))
-            assert iou[0].max() > 0.98, (terms, n)
-            ok = iou.max(1) > 0.98
-            rows = np.nonzero(ok)[0]
-            np.testing.assert_array_equal(got["c"][n, j[rows], 0], exact["c"][n, rows, 0])
-            scale = np.maximum(exact["b"][n, rows, 2] - exact["b"][n, rows, 0], exact["b"][n, rows, 3] - exact["b"][n, rows, 1])[:, None]
-            assert (np.abs(got["b"][n, j[rows], :4] - exact["b"][n, rows, :4]) <= tol * np.maximum(scale, 1.0)).all()
-            sig = np.abs(got["b"][n, j[rows], 4:] - exact["b"][n, rows, 4:])
-            assert (sig <= tol * np.maximum(exact["b"][n, rows, 4:], 1e-2 * scale)).mean() > 0.99
-            # undecayed scores (the first detection of an image has no earlier selection to decay it)
-            np.testing.assert_allclose(got["s"][n, 0], exact["s"][n, 0], rtol=tol)
+            top = 20
+            eb_all, gb_all = exact["cb"][n], got["cb"][n]
+            sel = keep["f32"][n][:top]
+            margin, pert, runner = _selection_margins(eb_all, exact["cs"][n], gb_all, got["cs"][n], sel, -0.5 / soft_sigma)
+            decided = margin > 2.0 * pert
+            rows_other = {int(a): r for r, a in enumerate(keep[scheme][n])}
+            # overlapping predecessors of a kept anchor in a run: the selected boxes that decayed its score
+            def preds(order, pos, boxes):
+                a = int(order[pos])
+                ov = _iou_1n(boxes[a], boxes[order[:pos]]) > 0 if pos else np.zeros(0, bool)
+                return frozenset(int(x) for x in order[:pos][ov])
+            n_q = 0
+            for k in range(top):
+                a = int(sel[k])
+                if a not in rows_other:
+                    continue
+                r = rows_other[a]
+                if preds(keep["f32"][n], k, eb_all) != preds(keep[scheme][n], r, gb_all):
+                    continue
+                # same anchor, decayed by the same earlier selections: everything the caller gets for it must agree
+                n_q += 1
+                eb, gb = exact["b"][n, k], got["b"][n, r]
+                assert got["c"][n, r, 0] == exact["c"][n, k, 0]
+                np.testing.assert_allclose(got["s"][n, r], exact["s"][n, k], rtol=tol, atol=0, err_msg=str((scheme, n, k)))
+                scale = max(eb[2] - eb[0], eb[3] - eb[1], 1.0)
+                assert np.abs(gb[:4] - eb[:4]).max() <= tol * scale, (scheme, n, k)
+                assert (np.abs(gb[4:] - eb[4:]) <= tol * np.maximum(eb[4:], 1e-2 * scale)).all(), (scheme, n, k)
+            same = sum(int(a) in rows_other for a in sel)
+            lost = [k for k in range(top) if int(sel[k]) not in rows_other]
+            # a detection that is NOT the same anchor in the other run must be explained by a margin the perturbation can
+            # cross: its own, or that of an earlier selection (any of them can change what decays it)
+            for k in lost:
+                assert (~decided[:k + 1]).any(), (scheme, n, k, margin[:k + 1], pert[:k + 1])
+            report.append("%s image %d: of the top %d detections %d are the same anchors, %d of them decayed by the same earlier "
+                          "selections (all within %.0e on score / box / sigma); selection margins: median %.2e, measured perturbation "
+                          "of the updated scores: median %.2e, %d margins above 2 x perturbation" % (
+                              scheme, n, top, same, n_q, tol, float(np.median(margin)), float(np.median(pert)), int(decided.sum())))
+            counts.append((scheme, n, n_q, same))
+            assert int(keep[scheme][n][0]) == int(sel[0])            # the best detection of an image is the same anchor
+    with capsys.disabled():
+        print()
+        for line in report:
+            print("[margin-aware detection parity] " + line)
+    # the statement must not be vacuous: a good share of the confident detections is decided by margins above the perturbation
+    for scheme, n, q, same in counts:
+        assert q >= MIN_QUALIFY[scheme], (scheme, n, q)
+        assert same >= MIN_SAME[scheme], (scheme, n, same)

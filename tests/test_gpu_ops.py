@@ -5,6 +5,7 @@ backbone/efficientnet_model.py:358-373,403-418,471-486; efficientdet_keras.py:20
 Tolerances (relative to max|ref| of the op's output, stated per variant):
   f32-input MFMA (terms 0)      2e-6   (float32 summation order)
   split-bf16, 6 cross terms     2e-6   (float32-equivalent)
+  split-fp16, 3 cross terms     2e-6   (terms = 16: two fp16 pieces, ~2^-22 per product - the shipped default; SAME bar as six terms)
   split-bf16, 3 cross terms     4e-5   (~2^-17 per product; the network-level bar stays 2e-4)
 """
 import ctypes as C
@@ -14,7 +15,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-TOL = {0: 2e-6, 6: 2e-6, 3: 4e-5}
+TOL = {0: 2e-6, 6: 2e-6, 16: 2e-6, 3: 4e-5}
 
 
 def _ref(x, w, bias, sc, sh, se, mask, res, in_div, act):
@@ -37,7 +38,7 @@ def _ref(x, w, bias, sc, sh, se, mask, res, in_div, act):
     return y
 
 
-def _run(x, w, bias, sc, sh, se, mask, res, in_div, act, terms, reps=0):
+def _run(x, w, bias, sc, sh, se, mask, res, in_div, act, terms, reps=0, expect_rc=None):
     from uda_amd import capi
     lib = capi.load()
     rows = x.shape[0] * in_div
@@ -48,6 +49,8 @@ def _run(x, w, bias, sc, sh, se, mask, res, in_div, act, terms, reps=0):
     arrs = [np.ascontiguousarray(a, np.float32) if a is not None else None for a in (x, w, bias, sc, sh, se, mask, res)]
     ptr = [a.ctypes.data if a is not None else None for a in arrs]
     rc = lib.uda_debug_pw(0, *ptr, rows, in_div, hw, cin, cout, act, terms, reps, out.ctypes.data, C.byref(ms))
+    if expect_rc is not None:
+        return rc, (lib.uda_last_error(None) or b"").decode()
     assert rc == 0, lib.uda_last_error(None)
     return out, ms.value
 
@@ -73,7 +76,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("terms", [0, 3, 6])
+@pytest.mark.parametrize("terms", [0, 3, 6, 16])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%d_hw%d_%d-%d_%s" % c)
 def test_pointwise_matches_float64(case, terms):
     rows_in, in_div, hw, cin, cout, flags = case
@@ -101,6 +104,42 @@ def test_pointwise_a_identity_asymmetric_b():
     cin = cout = 64
     x = np.eye(64, dtype=np.float32)[None]                       # [1, 64 pixels, 64 channels]
     w = (np.arange(64)[:, None] * 3 + np.arange(64)[None, :] * 7 % 11).astype(np.float32)
-    for terms in (0, 3, 6):
+    for terms in (0, 3, 6, 16):
         got, _ = _run(x, w, None, None, None, None, None, None, 1, 0, terms)
         np.testing.assert_array_equal(got[0], w)
+
+
+@pytest.mark.parametrize("w_std,x_std", [(0.3, 1.0), (0.04, 1.0), (0.04, 0.05), (0.005, 1.0), (1e-4, 30.0), (3.0, 300.0)])
+def test_fp16_pieces_hold_the_float32_bar_across_operand_magnitudes(w_std, x_std):
+    """Two fp16 pieces resolve an operand to 2^-22 only while its low piece is a normal fp16 number (|x| >= 2^-3); below,
+    the resolution is 2^-25 ABSOLUTE.  The 1x1 / separable kernels therefore pre-scale the weights by a power of two on
+    the host (largest entry in [2^13, 2^14), undone exactly in the epilogue), which makes the result independent of the
+    weights' magnitude; what is left is the activations' absolute 2^-25: the six-term bar (2e-6 of max|ref|) holds for
+    swish-shaped activations from 0.05 to 300 rms and weights from 1e-4 to 3 rms, K = 1152."""
+    rng = np.random.default_rng(11)
+    hw, cin, cout = 96, 1152, 320
+    pre = rng.normal(0, x_std, (1, hw, cin))
+    x = (pre / (1.0 + np.exp(-pre))).astype(np.float32)
+    w = rng.normal(0, w_std, (cin, cout)).astype(np.float32)
+    got, _ = _run(x, w, None, None, None, None, None, None, 1, 0, 16)
+    want = _ref(x, w, None, None, None, None, None, None, 1, False)
+    six, _ = _run(x, w, None, None, None, None, None, None, 1, 0, 6)
+    scale = np.abs(want).max()
+    err, err6 = np.abs(got - want).max(), np.abs(six - want).max()
+    assert err <= TOL[16] * scale, (err / scale, err6 / scale)
+
+
+def test_fp16_pieces_report_an_operand_above_65504():
+    """fp16 ends at 65504: an activation above it cannot be split.  The kernels track the largest operand they split and
+    raise the launch's range flag - the call fails with a message, it does not return infinities (or a flushed value)."""
+    rng = np.random.default_rng(3)
+    x = rng.normal(0, 1, (1, 200, 64)).astype(np.float32)
+    w = (rng.normal(0, 1, (64, 32)) / 8).astype(np.float32)
+    rc, msg = _run(x, w, None, None, None, None, None, None, 1, 0, 16, expect_rc=True)
+    assert rc == 0
+    x[0, 137, 5] = 7.0e4
+    rc, msg = _run(x, w, None, None, None, None, None, None, 1, 0, 16, expect_rc=True)
+    assert rc != 0 and "65504" in msg, (rc, msg)
+    got, _ = _run(x, w, None, None, None, None, None, None, 1, 0, 6)          # three bf16 pieces: float32's exponent range
+    want = _ref(x, w, None, None, None, None, None, None, 1, False)
+    assert np.abs(got - want).max() <= TOL[6] * np.abs(want).max()

@@ -577,18 +577,24 @@ def test_class_probs_entropy_and_unpacking():
     d.close()
 
 
-@pytest.mark.parametrize("env", [dict(UDA_PW_TERMS="0"), dict(UDA_PW_TERMS="6"),
+@pytest.mark.parametrize("env", [dict(UDA_PW_SCHEME="f32"), dict(UDA_PW_SCHEME="bf16x3"), dict(UDA_PW_SCHEME="bf16x2"),
+                                 dict(UDA_PW_TERMS="6"),
                                  dict(UDA_FUSE_MBXD="0", UDA_FUSE_SEP="0", UDA_DEFER_DROPOUT="0"),
-                                 dict(UDA_FUSE_MBX="0", UDA_POST_OVERLAP="0"), dict(UDA_FUSE_PROJ="0", UDA_PW_SHARED="0")],
-                         ids=["f32-mfma", "six-terms", "no-deep-fusion", "unfused-serial-post", "no-absorbed-projection"])
+                                 dict(UDA_FUSE_MBX="0", UDA_POST_OVERLAP="0"), dict(UDA_FUSE_PROJ="0", UDA_PW_SHARED="0"),
+                                 dict(UDA_F16_MIN_RMS="1e9")],
+                         ids=["f32-mfma", "bf16x3", "bf16x2", "legacy-terms-switch", "no-deep-fusion", "unfused-serial-post",
+                              "no-absorbed-projection", "fp16-unfit-ops-demoted-to-bf16x3"])
 def test_fallback_paths_stay_parity_green(env):
-    """Every switchable path (exact-f32 MFMA kernels, 6-term split, each fusion off) passes the smoke parity check.
+    """Every switchable path (exact-f32 MFMA kernels, the bf16 split schemes beside the default fp16 one, each fusion off,
+    fused MBConv ops whose weights do not suit fp16 pieces kept on three bf16 pieces) passes the smoke parity check.
     The switches are read once per process, so each configuration runs in its own interpreter."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     e = dict(os.environ)
+    if "UDA_PW_TERMS" in env:
+        e.pop("UDA_PW_SCHEME", None)          # the older switch only speaks when the newer one is silent
     e.update(env)
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=root, env=e,
                        capture_output=True, text=True, timeout=600)

@@ -383,6 +383,7 @@ print("RESULT " + json.dumps(out))
 
 def _six_run(env):
     e = dict(os.environ)
+    e.pop("UDA_PW_TERMS", None)
     e.update(env)
     r = subprocess.run([sys.executable, "-c", SIX_WORKER % {"root": ROOT}], cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
@@ -391,16 +392,20 @@ def _six_run(env):
 
 
 def test_six_term_products_keep_the_fused_kernels_and_are_float32_equivalent():
-    """UDA_PW_TERMS=6 (three bf16 pieces per operand, six cross terms: the reference computes in float32, utils.py:595-609)
-    used to switch the fused MBConv kernels off; now mbxb_kernel / mbxd_kernel<..., PARTS = 3> keep every block fused.
-    Heads of D0 (all 15 fused blocks incl. the deep ones) and D2 against the float32 CPU oracle: an order of magnitude
-    tighter than the shipped three-term products, and no worse than the unfused six-term path."""
-    six = _six_run(dict(UDA_PW_TERMS="6"))
-    unfused = _six_run(dict(UDA_PW_TERMS="6", UDA_FUSE_MBX6="0"))
-    three = _six_run(dict(UDA_PW_TERMS="3"))
+    """The float32-class split schemes (the reference computes in float32, utils.py:595-609): UDA_PW_SCHEME=bf16x3 (three bf16
+    pieces per operand, six cross terms) used to switch the fused MBConv kernels off; mbxb_kernel / mbxd_kernel<..., PARTS = 3>
+    keep every block fused.  UDA_PW_SCHEME=f16x2 (two fp16 pieces, three cross terms: the shipped default) must meet the
+    SAME bars.  Heads of D0 (all 15 fused blocks incl. the deep ones) and D2 against the float32 CPU oracle: an order of
+    magnitude tighter than two bf16 pieces, and no worse than the unfused six-term path."""
+    six = _six_run(dict(UDA_PW_SCHEME="bf16x3"))
+    half = _six_run(dict(UDA_PW_SCHEME="f16x2"))
+    unfused = _six_run(dict(UDA_PW_SCHEME="bf16x3", UDA_FUSE_MBX6="0"))
+    three = _six_run(dict(UDA_PW_SCHEME="bf16x2"))
+    print("head error vs the float32 oracle (max / rel. rms): bf16x3 %s  f16x2 %s  bf16x2 %s" % (six, half, three))
     for m in ("d0", "d2"):
         assert six[m]["n_mbx"] >= 14 and unfused[m]["n_mbx"] == 0, (m, six[m], unfused[m])
-        assert six[m]["n_mbx"] == three[m]["n_mbx"]
-        assert six[m]["max"] <= 2e-5 and six[m]["rms"] <= 1e-5, (m, six[m])             # vs 2e-4 / 1e-4 for three terms
-        assert six[m]["rms"] <= 2.0 * unfused[m]["rms"] + 1e-7, (m, six[m], unfused[m])
-        assert six[m]["rms"] < 0.5 * three[m]["rms"], (m, six[m], three[m])
+        assert six[m]["n_mbx"] == three[m]["n_mbx"] == half[m]["n_mbx"]
+        for name, run in (("bf16x3", six), ("f16x2", half)):
+            assert run[m]["max"] <= 2e-5 and run[m]["rms"] <= 1e-5, (name, m, run[m])  # vs 2e-4 / 1e-4 for two bf16 pieces
+            assert run[m]["rms"] <= 2.0 * unfused[m]["rms"] + 1e-7, (name, m, run[m], unfused[m])
+            assert run[m]["rms"] < 0.5 * three[m]["rms"], (name, m, run[m], three[m])

@@ -5,8 +5,10 @@
 // every f32 operand x is written as a sum of bf16 pieces, x = x0 + x1 (+ x2), each piece the
 // round-to-nearest bf16 of what the previous pieces left over, and the product is accumulated in f32 on
 // v_mfma_f32_32x32x16_bf16 from the significant cross terms:
-//     PARTS = 2 ("x3"): a0*b0 + a0*b1 + a1*b0                       (rel. error per product ~2^-17)
-//     PARTS = 3 ("x6"): a0*b0 + a0*b1 + a1*b0 + a0*b2 + a2*b0 + a1*b1   (~2^-24: float32-equivalent)
+//     PARTS = 2 (bf16 x2): a0*b0 + a0*b1 + a1*b0                       (rel. error per product ~2^-17)
+//     PARTS = 3 (bf16 x3): a0*b0 + a0*b1 + a1*b0 + a0*b2 + a2*b0 + a1*b1   (~2^-24: float32-equivalent)
+//     PARTS = 4 (fp16 x2): the three terms of PARTS = 2 on v_mfma_f32_32x32x16_f16 with 11-bit pieces (~2^-22; the default:
+//                          float32-class accuracy at the matrix-core cost of the three-term scheme, mfma_common.h)
 // Weights are split and laid out in MFMA B-fragment order ONCE on the host (uda_create); activations are
 // split while they are staged through LDS, so HBM still holds plain float32 tensors.
 // (reference: the Conv2D 1x1 / SeparableConv2D pointwise call sites, backbone/efficientnet_model.py:358-373,
@@ -20,6 +22,7 @@
 //   next chunk's global loads are in flight during the MFMAs of the current one (register prefetch);
 //   epilogue        : accumulators through a wave-private LDS tile so that every lane stores 16 contiguous
 //                     bytes, with bias / BN / swish / dropout keep-scale / residual applied on the float4.
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -32,14 +35,15 @@ namespace uda {
 template <int MT, int NT, int WM, int WN, int PARTS, int OCC>
 __global__ __launch_bounds__(256, OCC) void pwb_kernel(PwArgs a) {
   static_assert(WM * WN == 4, "four waves per block");
+  constexpr int NPC = split_np(PARTS);     // pieces per operand (PARTS names the scheme: UDA_SPLIT_*)
   constexpr int BM = 32 * MT * WM, NTB = NT * WN, BN = 32 * NTB;
-  constexpr int A_BYTES = PARTS * BM * PWB_AROW;
-  constexpr int B_BYTES = 2 * NTB * PARTS * 1024;
+  constexpr int A_BYTES = NPC * BM * PWB_AROW;
+  constexpr int B_BYTES = 2 * NTB * NPC * 1024;
   constexpr int STG_BYTES = 4 * 32 * PWB_STG * 4;
   constexpr int LDS_BYTES = (A_BYTES + B_BYTES) > STG_BYTES ? (A_BYTES + B_BYTES) : STG_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
-  unsigned char* As = lds;                 // [PARTS][BM][80 B]
-  uint4* Bs = (uint4*)(lds + A_BYTES);     // [2 k-steps][NTB][PARTS][64 lanes] x 16 B
+  unsigned char* As = lds;                 // [NPC][BM][80 B]
+  uint4* Bs = (uint4*)(lds + A_BYTES);     // [2 k-steps][NTB][NPC][64 lanes] x 16 B
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -64,11 +68,12 @@ __global__ __launch_bounds__(256, OCC) void pwb_kernel(PwArgs a) {
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
   constexpr int A_ITERS = BM * 8 / 256;
-  constexpr int B_TOTAL = 2 * NTB * PARTS * 64;
+  constexpr int B_TOTAL = 2 * NTB * NPC * 64;
   constexpr int B_ITERS = (B_TOTAL + 255) / 256;
   float4 ra[A_ITERS];
   uint4 rb[B_ITERS];
   float4 rg = make_float4(1.f, 1.f, 1.f, 1.f);
+  float amax = 0.f;                        // fp16 pieces: largest operand magnitude this lane has split
 
   auto load_chunk = [&](int k0) {
 #pragma unroll
@@ -88,11 +93,11 @@ __global__ __launch_bounds__(256, OCC) void pwb_kernel(PwArgs a) {
     for (int i = 0; i < B_ITERS; ++i) {
       const int f = tid + 256 * i;
       int q = f >> 6;
-      const int part = q % PARTS; q /= PARTS;
+      const int part = q % NPC; q /= NPC;
       const int nt = q % NTB, ks = q / NTB;
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
       if (f < B_TOTAL && ks0 + ks < KS && nt0 + nt < NTL)
-        v = Wp[(((size_t)(ks0 + ks) * NTL + (nt0 + nt)) * PARTS + part) * 64 + (f & 63)];
+        v = Wp[(((size_t)(ks0 + ks) * NTL + (nt0 + nt)) * NPC + part) * 64 + (f & 63)];
       rb[i] = v;
     }
   };
@@ -102,13 +107,15 @@ __global__ __launch_bounds__(256, OCC) void pwb_kernel(PwArgs a) {
       const int f = tid + 256 * i;
       const int m = f >> 3, kq = f & 7;
       float r0 = ra[i].x * rg.x, r1 = ra[i].y * rg.y, r2 = ra[i].z * rg.z, r3 = ra[i].w * rg.w;
+      split_track<PARTS>(amax, r0, r1);
+      split_track<PARTS>(amax, r2, r3);
 #pragma unroll
-      for (int p = 0; p < PARTS; ++p) {
-        const unsigned u0 = pack_bf16(r0, r1), u1 = pack_bf16(r2, r3);
+      for (int p = 0; p < NPC; ++p) {
+        const unsigned u0 = pack_piece<PARTS>(r0, r1), u1 = pack_piece<PARTS>(r2, r3);
         *(uint2*)(As + (size_t)(p * BM + m) * PWB_AROW + kq * 8) = make_uint2(u0, u1);
-        if (p + 1 < PARTS) {
-          r0 -= bf16_lo_f32(u0); r1 -= bf16_hi_f32(u0);
-          r2 -= bf16_lo_f32(u1); r3 -= bf16_hi_f32(u1);
+        if (p + 1 < NPC) {
+          r0 -= piece_lo<PARTS>(u0); r1 -= piece_hi<PARTS>(u0);
+          r2 -= piece_lo<PARTS>(u1); r3 -= piece_hi<PARTS>(u1);
         }
       }
     }
@@ -126,35 +133,28 @@ __global__ __launch_bounds__(256, OCC) void pwb_kernel(PwArgs a) {
     if (k0 + PWB_BK < a.Cin) load_chunk(k0 + PWB_BK);   // in flight during the MFMAs below
     const int nks = (a.Cin - k0 > 16) ? 2 : 1;
     for (int ks = 0; ks < nks; ++ks) {
-      bf16x8 af[MT][PARTS];
+      bf16x8 af[MT][NPC];
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int p = 0; p < PARTS; ++p)
+        for (int p = 0; p < NPC; ++p)
           af[m][p] = *(const bf16x8*)(As + (size_t)(p * BM + (wr * MT + m) * 32 + li) * PWB_AROW + ks * 32 + lh * 16);
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        bf16x8 bf[PARTS];
+        bf16x8 bf[NPC];
 #pragma unroll
-        for (int p = 0; p < PARTS; ++p)
-          bf[p] = __builtin_bit_cast(bf16x8, Bs[((ks * NTB + wc * NT + n) * PARTS + p) * 64 + lane]);
+        for (int p = 0; p < NPC; ++p)
+          bf[p] = __builtin_bit_cast(bf16x8, Bs[((ks * NTB + wc * NT + n) * NPC + p) * 64 + lane]);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          if constexpr (PARTS == 3) {
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][2], bf[0], acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][0], bf[2], acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][1], bf[1], acc[m][n], 0, 0, 0);
-          }
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][1], bf[0], acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][0], bf[1], acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][0], bf[0], acc[m][n], 0, 0, 0);
-        }
+        for (int m = 0; m < MT; ++m) acc[m][n] = mfma_terms<PARTS>(af[m], bf, acc[m][n]);
       }
     }
     __syncthreads();
   }
+  split_report<PARTS>(amax, a.oor);
 
   const size_t out_base = (size_t)b * a.HW;
+  const float un = a.wunscale;             // the packed weights carry a power-of-two factor 1 / un (fp16 pieces; else 1)
   const size_t res_base = a.res ? (size_t)(b / a.res_div) * a.HW : 0;
 
   if ((a.Cout & 3) != 0) {
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, OCC) void pwb_kernel(PwArgs a) {
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + (wr * MT + m_) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           if (m >= a.HW) continue;
-          float v = acc[m_][n][r] + bias;
+          float v = fmaf(acc[m_][n][r], un, bias);
           v = fmaf(v, sc, sh);
           if (a.act == UDA_ACT_SWISH) v = swishf_b(v);
           v *= mk;
@@ -219,10 +219,10 @@ __global__ __launch_bounds__(256, OCC) void pwb_kernel(PwArgs a) {
         const int m = m0 + (wr * MT + m_) * 32 + row;
         if (colok && m < a.HW) {
           float4 v = *(const float4*)(stg + row * PWB_STG + 4 * c4);
-          v.x = fmaf(v.x + bias.x, sc.x, sh.x);
-          v.y = fmaf(v.y + bias.y, sc.y, sh.y);
-          v.z = fmaf(v.z + bias.z, sc.z, sh.z);
-          v.w = fmaf(v.w + bias.w, sc.w, sh.w);
+          v.x = fmaf(fmaf(v.x, un, bias.x), sc.x, sh.x);
+          v.y = fmaf(fmaf(v.y, un, bias.y), sc.y, sh.y);
+          v.z = fmaf(fmaf(v.z, un, bias.z), sc.z, sh.z);
+          v.w = fmaf(fmaf(v.w, un, bias.w), sc.w, sh.w);
           if (a.act == UDA_ACT_SWISH) {
             v.x = swishf_b(v.x); v.y = swishf_b(v.y); v.z = swishf_b(v.z); v.w = swishf_b(v.w);
           }
@@ -351,7 +351,8 @@ static void launch_pwb_cfg(const PwArgs& a, int rows, hipStream_t s) {
   constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
   const dim3 grid((a.HW + BM - 1) / BM, (a.Cout + BN - 1) / BN, rows), block(256);
   // three blocks per CU (<= 168 registers): measured 10-20 % faster than the unconstrained allocation (2 per CU)
-  if (a.wparts == 3) hipLaunchKernelGGL((pwb_kernel<MT, NT, WM, WN, 3, 2>), grid, block, 0, s, a);
+  if (a.wparts == UDA_SPLIT_BF16X3) hipLaunchKernelGGL((pwb_kernel<MT, NT, WM, WN, 3, 2>), grid, block, 0, s, a);
+  else if (a.wparts == UDA_SPLIT_F16X2) hipLaunchKernelGGL((pwb_kernel<MT, NT, WM, WN, 4, (MT * NT > 4 ? 2 : 3)>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((pwb_kernel<MT, NT, WM, WN, 2, (MT * NT > 4 ? 2 : 3)>), grid, block, 0, s, a);   // (5-6 accumulator tiles per wave: 168 registers spill)
 }
 
@@ -451,35 +452,6 @@ __device__ __forceinline__ void et_read(float* dst, const float* er, int jj) {
   }
 }
 
-// 8 consecutive channels of a pixel -> PARTS bf16 pieces (piece p = round-to-nearest bf16 of what pieces 0..p-1 left over)
-template <int PARTS>
-__device__ __forceinline__ void split_parts(const float4& v0, const float4& v1, bf16x8* out) {
-  float r0 = v0.x, r1 = v0.y, r2 = v0.z, r3 = v0.w, r4 = v1.x, r5 = v1.y, r6 = v1.z, r7 = v1.w;
-#pragma unroll
-  for (int p = 0; p < PARTS; ++p) {
-    const unsigned u0 = pack_bf16(r0, r1), u1 = pack_bf16(r2, r3), u2 = pack_bf16(r4, r5), u3 = pack_bf16(r6, r7);
-    out[p] = __builtin_bit_cast(bf16x8, make_uint4(u0, u1, u2, u3));
-    if (p + 1 < PARTS) {
-      r0 -= bf16_lo_f32(u0); r1 -= bf16_hi_f32(u0); r2 -= bf16_lo_f32(u1); r3 -= bf16_hi_f32(u1);
-      r4 -= bf16_lo_f32(u2); r5 -= bf16_hi_f32(u2); r6 -= bf16_lo_f32(u3); r7 -= bf16_hi_f32(u3);
-    }
-  }
-}
-// the significant cross terms of (sum a[i]) x (sum b[j]), smallest first: PARTS = 2 -> a1 b0 + a0 b1 + a0 b0 (~2^-17 per
-// product), PARTS = 3 -> + a2 b0 + a0 b2 + a1 b1 in front (~2^-24: float32-equivalent, UDA_PW_TERMS=6)
-template <int PARTS>
-__device__ __forceinline__ f32x16 mfma_terms(const bf16x8* a, const bf16x8* b, f32x16 acc) {
-  if constexpr (PARTS == 3) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
-  }
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
-  return acc;
-}
-
 namespace {
 struct MbxCfgB { int th, tw; };
 __host__ __device__ constexpr MbxCfgB mbxb_cfg(int k, int s) {
@@ -525,6 +497,7 @@ __host__ __device__ constexpr MbxCfgB mbxb_cfg(int k, int s) {
 template <int K, int S, int KSF, bool FUSE0, int PARTS>   // KSF = 16-deep MFMA k-steps covering Cin + 1
 __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF, PARTS)) void mbxb_kernel(MbxArgs a) {
   constexpr int NW = 4;
+  constexpr int NPC = split_np(PARTS);        // pieces per operand (PARTS names the scheme: UDA_SPLIT_*)
   constexpr int TH = mbxb_cfg(K, S).th, TW = mbxb_cfg(K, S).tw;
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
   constexpr int NP = IH * IW;
@@ -549,8 +522,8 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF, PARTS)) void mbxb_ker
   constexpr int NPAR = (K * K + 2) * 32;      // per slab: depthwise taps [K*K][32] | BN scale | BN shift (host-packed, a.wpar)
   float* par = red + NG * 32;                 // [2][NPAR]
   constexpr bool B_LDS = KSF <= 2;            // packed expand weights of a slab: LDS image (else registers, one slab ahead)
-  constexpr int BSLAB = KSF * PARTS * 64;     // uint4 per slab of packed expand weights
-  uint4* Bs = (uint4*)(par + 2 * NPAR);       // [KSF][PARTS][64 lanes]: rewritten between the two barriers of a slab
+  constexpr int BSLAB = KSF * NPC * 64;     // uint4 per slab of packed expand weights
+  uint4* Bs = (uint4*)(par + 2 * NPAR);       // [KSF][NPC][64 lanes]: rewritten between the two barriers of a slab
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -578,18 +551,19 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF, PARTS)) void mbxb_ker
   const int cin_mem = FUSE0 ? a.c0 : a.Cin;   // channels of the tensor that is actually read
   const float* xin = a.in + (size_t)b_in * a.H * a.W * cin_mem;
 
+  float amax = 0.f;                           // fp16 pieces: largest operand magnitude this lane has split
   // FUSE0: A' = W0^T (row = projected channel li) x gate of this sample row, both k-steps of the 32 input channels
-  bf16x8 w0p[2][PARTS];
+  bf16x8 w0p[2][NPC];
   float sh0v[8];
   if constexpr (FUSE0) {
     if (a.w0frag) {
       // the gated, split projection kernel of this sample row comes ready-made from w0gate_kernel: every one of the ~1100 tiles
       // of a row used to redo the same 16 multiplies + 2 splits (a tenth of this kernel's vector instructions)
-      const uint4* fp = a.w0frag + (size_t)(b / a.g_div) * (2 * PARTS * 64) + lane;
+      const uint4* fp = a.w0frag + (size_t)(b / a.g_div) * (2 * NPC * 64) + lane;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int p_ = 0; p_ < PARTS; ++p_) w0p[ks][p_] = __builtin_bit_cast(bf16x8, fp[(ks * PARTS + p_) * 64]);
+        for (int p_ = 0; p_ < NPC; ++p_) w0p[ks][p_] = __builtin_bit_cast(bf16x8, fp[(ks * NPC + p_) * 64]);
     } else {
       const float* gp = a.gate + (size_t)(b / a.g_div) * a.c0;
 #pragma unroll
@@ -599,7 +573,7 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF, PARTS)) void mbxb_ker
         const float4 g0 = *(const float4*)(gp + k), g1 = *(const float4*)(gp + k + 4);
         w0.x *= g0.x; w0.y *= g0.y; w0.z *= g0.z; w0.w *= g0.w;
         w1.x *= g1.x; w1.y *= g1.y; w1.z *= g1.z; w1.w *= g1.w;
-        split_parts<PARTS>(w0, w1, w0p[ks]);
+        split_parts<PARTS>(w0, w1, w0p[ks], amax);
       }
     }
 #pragma unroll
@@ -607,7 +581,7 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF, PARTS)) void mbxb_ker
   }
 
   // ---- this wave's operand fragments: pixel = slice * 32 + li, channels 16 ks + 8 lh .. + 7
-  bf16x8 ap[MTW][KSF][PARTS];
+  bf16x8 ap[MTW][KSF][NPC];
 #pragma unroll
   for (int t = 0; t < MTW; ++t) {
     const int mt = wave + NW * t;
@@ -628,8 +602,8 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF, PARTS)) void mbxb_ker
           d0 = *(const float4*)(px + k);
           d1 = *(const float4*)(px + k + 4);
         }
-        bf16x8 dp[PARTS];
-        split_parts<PARTS>(d0, d1, dp);
+        bf16x8 dp[NPC];
+        split_parts<PARTS>(d0, d1, dp, amax);
         xacc = mfma_terms<PARTS>(w0p[ks], dp, xacc);
       }
       // registers 0..7 = channels (j & 3) + 8 (j >> 2) + 4 lh of pixel li: BN shift, zero outside the image
@@ -638,7 +612,7 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF, PARTS)) void mbxb_ker
       v0.z = in ? xacc[2] + sh0v[2] : 0.f; v0.w = in ? xacc[3] + sh0v[3] : 0.f;
       v1.x = in ? xacc[4] + sh0v[4] : 0.f; v1.y = in ? xacc[5] + sh0v[5] : 0.f;
       v1.z = in ? xacc[6] + sh0v[6] : 0.f; v1.w = in ? xacc[7] + sh0v[7] : 0.f;
-      split_parts<PARTS>(v0, v1, ap[t][0]);
+      split_parts<PARTS>(v0, v1, ap[t][0], amax);
       float4 f0 = make_float4((lh == 0 && in) ? 1.f : 0.f, 0.f, 0.f, 0.f), f1 = make_float4(0.f, 0.f, 0.f, 0.f);
       split_parts<PARTS>(f0, f1, ap[t][1]);     // k-step 1: only the "inside the image" channel
       continue;
@@ -652,9 +626,10 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF, PARTS)) void mbxb_ker
         v1 = *(const float4*)(px + k + 4);
       }
       if (k == a.Cin) v0.x = in ? 1.f : 0.f;          // the "inside the image" channel that carries the BN shift
-      split_parts<PARTS>(v0, v1, ap[t][ks]);
+      split_parts<PARTS>(v0, v1, ap[t][ks], amax);
     }
   }
+  split_report<PARTS>(amax, a.oor);
 
   const int c = tid & 31, g = tid >> 5;       // depthwise stage: channel within the slab, thread group
   const size_t tile = (size_t)tby * ((a.Wo + TW - 1) / TW) + tbx;
@@ -689,16 +664,16 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF, PARTS)) void mbxb_ker
   constexpr int P_PER = (NPAR + 255) / 256;
   constexpr int B_PER = (BSLAB + 255) / 256;
   auto b_src = [&](int ch, int f) -> const uint4* {       // element f of slab ch in the [ks][part][lane] image
-    const int ks = f / (PARTS * 64), rest = f - ks * (PARTS * 64);
-    return Wp + (((size_t)ks * NCH + ch) * PARTS + (rest >> 6)) * 64 + (rest & 63);
+    const int ks = f / (NPC * 64), rest = f - ks * (NPC * 64);
+    return Wp + (((size_t)ks * NCH + ch) * NPC + (rest >> 6)) * 64 + (rest & 63);
   };
   constexpr int KR = B_LDS ? 1 : KSF;         // register copies (B_LDS: unused)
-  uint4 rb[KR][PARTS], nbr[KR][PARTS];
-  auto load_regs = [&](int ch, uint4 (*dst)[PARTS]) {
+  uint4 rb[KR][NPC], nbr[KR][NPC];
+  auto load_regs = [&](int ch, uint4 (*dst)[NPC]) {
 #pragma unroll
     for (int ks = 0; ks < KR; ++ks)
 #pragma unroll
-      for (int p_ = 0; p_ < PARTS; ++p_) dst[ks][p_] = Wp[(((size_t)ks * NCH + ch) * PARTS + p_) * 64 + lane];
+      for (int p_ = 0; p_ < NPC; ++p_) dst[ks][p_] = Wp[(((size_t)ks * NCH + ch) * NPC + p_) * 64 + lane];
   };
   if constexpr (B_LDS) {
     for (int f = tid; f < BSLAB; f += 256) Bs[f] = *b_src(0, f);
@@ -743,12 +718,12 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF, PARTS)) void mbxb_ker
     mk0n = mask_at(a.mask0, chn);
     mk1n = mask_at(a.mask1, chn);
     // this slab's weight fragments: one LDS image for the block, read once per wave and used for both of its slices
-    bf16x8 bp[KSF][PARTS];
+    bf16x8 bp[KSF][NPC];
 #pragma unroll
     for (int ks = 0; ks < KSF; ++ks)
 #pragma unroll
-      for (int p_ = 0; p_ < PARTS; ++p_) {
-        if constexpr (B_LDS) bp[ks][p_] = __builtin_bit_cast(bf16x8, Bs[(ks * PARTS + p_) * 64 + lane]);
+      for (int p_ = 0; p_ < NPC; ++p_) {
+        if constexpr (B_LDS) bp[ks][p_] = __builtin_bit_cast(bf16x8, Bs[(ks * NPC + p_) * 64 + lane]);
         else bp[ks][p_] = __builtin_bit_cast(bf16x8, rb[ks < KR ? ks : 0][p_]);
       }
     // ---- expand: E[p][j] = swish(sum_k X[p][k] We'[k][32 ch + j]) / (-ln 2)   (dropout scale: after the depthwise)
@@ -785,7 +760,7 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF, PARTS)) void mbxb_ker
 #pragma unroll
         for (int ks = 0; ks < KR; ++ks)
 #pragma unroll
-          for (int p_ = 0; p_ < PARTS; ++p_)
+          for (int p_ = 0; p_ < NPC; ++p_)
             asm volatile("" : "+v"(nbr[ks][p_].x), "+v"(nbr[ks][p_].y), "+v"(nbr[ks][p_].z), "+v"(nbr[ks][p_].w));
       }
       float* pnext = par + ((ch + 1) & 1) * NPAR;
@@ -873,7 +848,7 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF, PARTS)) void mbxb_ker
 #pragma unroll
       for (int ks = 0; ks < KR; ++ks)
 #pragma unroll
-        for (int p_ = 0; p_ < PARTS; ++p_) rb[ks][p_] = nbr[ks][p_];
+        for (int p_ = 0; p_ < NPC; ++p_) rb[ks][p_] = nbr[ks][p_];
     }
   }
 }
@@ -882,9 +857,11 @@ __global__ __launch_bounds__(256, UDA_MBXB_MINW(K, S, KSF, PARTS)) void mbxb_ker
 // fused kernel's prologue wants ([row][k-step][piece][lane] x 16 B) - the same arithmetic, once per sample row instead of once
 // per tile.  One wave per gate row.
 template <int PARTS>
-__global__ __launch_bounds__(64) void w0gate_kernel(const float* gate, const float* w0t, int c0, uint4* out) {
+__global__ __launch_bounds__(64) void w0gate_kernel(const float* gate, const float* w0t, int c0, uint4* out, unsigned* oor) {
+  constexpr int NPC = split_np(PARTS);
   const int row = blockIdx.x, lane = threadIdx.x, li = lane & 31, lh = lane >> 5;
   const float* gp = gate + (size_t)row * c0;
+  float amax = 0.f;
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     const int k = ks * 16 + 8 * lh;
@@ -892,18 +869,20 @@ __global__ __launch_bounds__(64) void w0gate_kernel(const float* gate, const flo
     const float4 g0 = *(const float4*)(gp + k), g1 = *(const float4*)(gp + k + 4);
     w0.x *= g0.x; w0.y *= g0.y; w0.z *= g0.z; w0.w *= g0.w;
     w1.x *= g1.x; w1.y *= g1.y; w1.z *= g1.z; w1.w *= g1.w;
-    bf16x8 pc[PARTS];
-    split_parts<PARTS>(w0, w1, pc);
+    bf16x8 pc[NPC];
+    split_parts<PARTS>(w0, w1, pc, amax);
 #pragma unroll
-    for (int p_ = 0; p_ < PARTS; ++p_) out[((size_t)row * 2 * PARTS + ks * PARTS + p_) * 64 + lane] = __builtin_bit_cast(uint4, pc[p_]);
+    for (int p_ = 0; p_ < NPC; ++p_) out[((size_t)row * 2 * NPC + ks * NPC + p_) * 64 + lane] = __builtin_bit_cast(uint4, pc[p_]);
   }
+  split_report<PARTS>(amax, oor);
 }
 
 // gate rows x (2 k-steps x parts x 64 lanes) uint4
-size_t mbxb_w0frag_elems(int gate_rows, int parts) { return (size_t)gate_rows * 2 * parts * 64; }
-void launch_w0gate(const float* gate, const float* w0t, int c0, int gate_rows, int parts, uint4* out, hipStream_t s) {
-  if (parts == 3) hipLaunchKernelGGL(w0gate_kernel<3>, dim3(gate_rows), dim3(64), 0, s, gate, w0t, c0, out);
-  else hipLaunchKernelGGL(w0gate_kernel<2>, dim3(gate_rows), dim3(64), 0, s, gate, w0t, c0, out);
+size_t mbxb_w0frag_elems(int gate_rows, int scheme) { return (size_t)gate_rows * 2 * uda_split_pieces(scheme) * 64; }
+void launch_w0gate(const float* gate, const float* w0t, int c0, int gate_rows, int scheme, uint4* out, unsigned* oor, hipStream_t s) {
+  if (scheme == UDA_SPLIT_BF16X3) hipLaunchKernelGGL(w0gate_kernel<3>, dim3(gate_rows), dim3(64), 0, s, gate, w0t, c0, out, oor);
+  else if (scheme == UDA_SPLIT_F16X2) hipLaunchKernelGGL(w0gate_kernel<4>, dim3(gate_rows), dim3(64), 0, s, gate, w0t, c0, out, oor);
+  else hipLaunchKernelGGL(w0gate_kernel<2>, dim3(gate_rows), dim3(64), 0, s, gate, w0t, c0, out, oor);
 }
 
 int mbxb_tiles(int Ho, int Wo, int k, int stride) {
@@ -921,7 +900,7 @@ static void launch_mbxb_t(const MbxArgs& a, int rows, hipStream_t s) {
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
   constexpr int NPP = (IH * IW + 31) / 32 * 32;
   const size_t lds = ((mbx_et_w(K, S) ? (size_t)32 * mbx_et_pitch(mbx_et_w(K, S)) : (size_t)NPP * 32) + 8 * 32 + 2 * (K * K + 2) * 32) * sizeof(float) +
-                     (size_t)KSF * PARTS * 64 * sizeof(uint4);
+                     (size_t)KSF * split_np(PARTS) * 64 * sizeof(uint4);
   dim3 grid((a.Wo + TW - 1) / TW, (a.Ho + TH - 1) / TH, rows);
   MbxArgs b = a;
   static int remap = -1;
@@ -958,9 +937,10 @@ static void launch_mbxb_p(const MbxArgs& a, int rows, int k, int stride, hipStre
   else launch_mbxb_ks<5, 2, PARTS>(a, rows, s);
 }
 
-// a.wparts: bf16 pieces per operand in the packed expand weights (2 = three cross terms, 3 = six: UDA_PW_TERMS=6)
+// a.wparts: split scheme of the packed expand weights (UDA_SPLIT_*)
 void launch_mbxb(const MbxArgs& a, int rows, int k, int stride, hipStream_t s) {
-  if (a.wparts == 3) launch_mbxb_p<3>(a, rows, k, stride, s);
+  if (a.wparts == UDA_SPLIT_BF16X3) launch_mbxb_p<3>(a, rows, k, stride, s);
+  else if (a.wparts == UDA_SPLIT_F16X2) launch_mbxb_p<4>(a, rows, k, stride, s);
   else launch_mbxb_p<2>(a, rows, k, stride, s);
 }
 
@@ -996,10 +976,11 @@ bool mbxd_wide(int Ho, int Wo, int k, int stride) {
 }
 
 template <int K, int KSF, int PARTS, int S, bool WIDE>
-__global__ __launch_bounds__(512, (KSF <= 8 && PARTS == 2) ? 4 : 2) void mbxd_kernel(MbxArgs a) {
+__global__ __launch_bounds__(512, (KSF <= 8 && PARTS != 3) ? 4 : 2) void mbxd_kernel(MbxArgs a) {
   constexpr bool WK_LDS = (K == 5 && (KSF <= 8 || PARTS == 3));     // the 25 taps from LDS at their use, not 25 registers
 
   constexpr int NW = 8;
+  constexpr int NPC = split_np(PARTS);        // pieces per operand (PARTS names the scheme: UDA_SPLIT_*)
   static_assert(!WIDE || S == 1, "wide tiles are a stride-1 variant");
   constexpr int TH = mbxd_cfg(K, S, WIDE).th, TW = mbxd_cfg(K, S, WIDE).tw;
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
@@ -1017,7 +998,7 @@ __global__ __launch_bounds__(512, (KSF <= 8 && PARTS == 2) ? 4 : 2) void mbxd_ke
   constexpr int NUNIT = TH * UPR;             // 48 (3x3) / 16 (5x5) units over 16 groups; stride 2: 7 / 8 (half of the groups idle)
   static_assert(TW % XW == 0, "units must tile the output tile");
   constexpr int NCOL = (XW - 1) * S + K;
-  constexpr int BSLAB = KSF * PARTS * 64;     // uint4 per slab of packed expand weights
+  constexpr int BSLAB = KSF * NPC * 64;     // uint4 per slab of packed expand weights
   extern __shared__ __attribute__((aligned(16))) float dlds[];
   float* E = dlds;                            // [NPP][ES]
   float* red = E + (size_t)NPP * ES;          // [NG][32]
@@ -1045,8 +1026,8 @@ __global__ __launch_bounds__(512, (KSF <= 8 && PARTS == 2) ? 4 : 2) void mbxd_ke
   // HBM round trip.  The loads are plain and branch-free so that no wait is placed right behind them.
   // ---- slab 0 operands -> LDS buffers 0
   for (int f = tid; f < BSLAB; f += 512) {
-    const int ks = f / (PARTS * 64), rest = f - ks * (PARTS * 64);     // [ks][part][lane]
-    Bs[f] = Wp[(((size_t)ks * NCH + chb) * PARTS + (rest >> 6)) * 64 + (rest & 63)];
+    const int ks = f / (NPC * 64), rest = f - ks * (NPC * 64);     // [ks][part][lane]
+    Bs[f] = Wp[(((size_t)ks * NCH + chb) * NPC + (rest >> 6)) * 64 + (rest & 63)];
   }
   for (int f = tid; f < NPAR; f += 512) par[f] = a.wpar[(size_t)chb * NPAR + f];
   for (int f = tid; f < 2 * 32 * NCH; f += 512) {
@@ -1056,7 +1037,8 @@ __global__ __launch_bounds__(512, (KSF <= 8 && PARTS == 2) ? 4 : 2) void mbxd_ke
   }
 
   // ---- this wave's operand fragments: pixel = wave * 32 + li, channels 16 ks + 8 lh .. + 7
-  bf16x8 ap[KSF][PARTS];
+  bf16x8 ap[KSF][NPC];
+  float amax = 0.f;                           // fp16 pieces: largest operand magnitude this lane has split
   {
     const int p = wave * 32 + li;
     const int iy = iy0 + p / IW, ix = ix0 + p % IW;
@@ -1071,9 +1053,10 @@ __global__ __launch_bounds__(512, (KSF <= 8 && PARTS == 2) ? 4 : 2) void mbxd_ke
         v1 = *(const float4*)(px + k + 4);
       }
       if (k == a.Cin) v0.x = in ? 1.f : 0.f;          // the "inside the image" channel that carries the BN shift
-      split_parts<PARTS>(v0, v1, ap[ks]);
+      split_parts<PARTS>(v0, v1, ap[ks], amax);
     }
   }
+  split_report<PARTS>(amax, a.oor);
   __syncthreads();
 
   const int c = tid & 31, g = tid >> 5;       // depthwise stage: channel within the slab, thread group
@@ -1108,9 +1091,9 @@ __global__ __launch_bounds__(512, (KSF <= 8 && PARTS == 2) ? 4 : 2) void mbxd_ke
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {      // (guarded loads measured 6 % faster than clamped unconditional ones here)
       const int f = tid + 512 * i;
-      const int ks = f / (PARTS * 64), rest = f - ks * (PARTS * 64);
+      const int ks = f / (NPC * 64), rest = f - ks * (NPC * 64);
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (more && f < BSLAB) v = Wp[(((size_t)ks * NCH + (ch + 1)) * PARTS + (rest >> 6)) * 64 + (rest & 63)];
+      if (more && f < BSLAB) v = Wp[(((size_t)ks * NCH + (ch + 1)) * NPC + (rest >> 6)) * 64 + (rest & 63)];
       nb[i] = v;
     }
     constexpr int P_PER = (NPAR + 511) / 512;
@@ -1128,9 +1111,9 @@ __global__ __launch_bounds__(512, (KSF <= 8 && PARTS == 2) ? 4 : 2) void mbxd_ke
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < KSF; ++ks) {
-        bf16x8 bp[PARTS];
+        bf16x8 bp[NPC];
 #pragma unroll
-        for (int p_ = 0; p_ < PARTS; ++p_) bp[p_] = __builtin_bit_cast(bf16x8, bcur[(ks * PARTS + p_) * 64 + lane]);
+        for (int p_ = 0; p_ < NPC; ++p_) bp[p_] = __builtin_bit_cast(bf16x8, bcur[(ks * NPC + p_) * 64 + lane]);
         acc = mfma_terms<PARTS>(ap[ks], bp, acc);
       }
       if constexpr (ET) {
@@ -1239,8 +1222,9 @@ __global__ __launch_bounds__(512, (KSF <= 8 && PARTS == 2) ? 4 : 2) void mbxd_ke
 // region; the matrix core runs asynchronously to the VALU), then activates that accumulator into the other E buffer.
 // E, the packed weights and the SE sums are double-buffered, the per-slab depthwise block triple-buffered, and ONE
 // barrier per slab remains.
-template <int K, int KSF, bool WIDE>
+template <int K, int KSF, bool WIDE, int SCH>    // SCH: UDA_SPLIT_BF16X2 or UDA_SPLIT_F16X2 (two pieces per operand)
 __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
+  static_assert(split_np(SCH) == 2, "the self-overlapping kernel is laid out for two pieces per operand");
   constexpr int NW = 8;
   constexpr int TH = mbxd_cfg(K, 1, WIDE).th, TW = mbxd_cfg(K, 1, WIDE).tw;
   constexpr int IH = TH + K - 1, IW = TW + K - 1;
@@ -1299,6 +1283,7 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
     mks[f] = ((m && col < a.Cmid) ? m[(size_t)b * a.Cmid + col] : 1.f) * UDA_NEG_LN2;
   }
   bf16x8 ah[KSF], al[KSF];
+  float amax = 0.f;                           // fp16 pieces: largest operand magnitude this lane has split
   {
     const int p = wave * 32 + li;
     const int iy = iy0 + p / IW, ix = ix0 + p % IW;
@@ -1313,16 +1298,13 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
         v1 = *(const float4*)(px + k + 4);
       }
       if (k == a.Cin) v0.x = in ? 1.f : 0.f;
-      const unsigned h0 = pack_bf16(v0.x, v0.y), h1 = pack_bf16(v0.z, v0.w);
-      const unsigned h2 = pack_bf16(v1.x, v1.y), h3 = pack_bf16(v1.z, v1.w);
-      const unsigned l0 = pack_bf16(v0.x - bf16_lo_f32(h0), v0.y - bf16_hi_f32(h0));
-      const unsigned l1 = pack_bf16(v0.z - bf16_lo_f32(h1), v0.w - bf16_hi_f32(h1));
-      const unsigned l2 = pack_bf16(v1.x - bf16_lo_f32(h2), v1.y - bf16_hi_f32(h2));
-      const unsigned l3 = pack_bf16(v1.z - bf16_lo_f32(h3), v1.w - bf16_hi_f32(h3));
-      ah[ks] = __builtin_bit_cast(bf16x8, make_uint4(h0, h1, h2, h3));
-      al[ks] = __builtin_bit_cast(bf16x8, make_uint4(l0, l1, l2, l3));
+      bf16x8 pc[2];
+      split_parts<SCH>(v0, v1, pc, amax);
+      ah[ks] = pc[0];
+      al[ks] = pc[1];
     }
   }
+  split_report<SCH>(amax, a.oor);
   __syncthreads();
 
   const int c = tid & 31, g = tid >> 5;
@@ -1362,9 +1344,9 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
     for (int ks = 0; ks < KSF; ++ks) {
       const bf16x8 bh = __builtin_bit_cast(bf16x8, Bs[(ks * 2 + 0) * 64 + lane]);
       const bf16x8 bl = __builtin_bit_cast(bf16x8, Bs[(ks * 2 + 1) * 64 + lane]);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh, acc, 0, 0, 0);
+      acc = mfma16<SCH>(al[ks], bh, acc);
+      acc = mfma16<SCH>(ah[ks], bl, acc);
+      acc = mfma16<SCH>(ah[ks], bh, acc);
     }
     e_store(E, acc);
   }
@@ -1458,10 +1440,10 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
             bh_n = __builtin_bit_cast(bf16x8, bnext[((ks + 1) * 2 + 0) * 64 + lane]);
             bl_n = __builtin_bit_cast(bf16x8, bnext[((ks + 1) * 2 + 1) * 64 + lane]);
           }
-          if (t == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh_c, acc, 0, 0, 0);
-          if (t == 1) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl_c, acc, 0, 0, 0);
+          if (t == 0) acc = mfma16<SCH>(al[ks], bh_c, acc);
+          if (t == 1) acc = mfma16<SCH>(ah[ks], bl_c, acc);
           if (t == 2) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh_c, acc, 0, 0, 0);
+            acc = mfma16<SCH>(ah[ks], bh_c, acc);
             bh_c = bh_n; bl_c = bl_n;
           }
         }
@@ -1568,27 +1550,44 @@ static int mbx_ch_groups(long long blocks, int per_cu, int n_slabs) {
   return g < 1 ? 1 : (int)g;
 }
 
-template <int K, int KSF, bool WIDE>
+template <int K, int KSF, bool WIDE, int SCH>
 static void launch_mbxp_tw(const MbxArgs& a, int rows, hipStream_t s) {
   constexpr int TH = mbxd_cfg(K, 1, WIDE).th, TW = mbxd_cfg(K, 1, WIDE).tw;
   const size_t lds = ((size_t)2 * 256 * 33 + 2 * 16 * 32 + 3 * (K * K + 2) * 32 + 2 * 32 * ((a.Cmid + 31) / 32)) * sizeof(float) +
                      (size_t)2 * KSF * 2 * 64 * sizeof(uint4);
   static size_t attr_lds = 64 * 1024;
   if (lds > attr_lds) {
-    hipFuncSetAttribute((const void*)mbxp_kernel<K, KSF, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)mbxp_kernel<K, KSF, WIDE, SCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_lds = lds;
   }
   dim3 grid((a.Wo + TW - 1) / TW, (a.Ho + TH - 1) / TH, rows);
   MbxArgs b = a;
   b.ch_groups = mbx_ch_groups((long long)grid.x * grid.y * rows, 1, (a.Cmid + 31) / 32);
   grid.z = (unsigned)(rows * b.ch_groups);
-  hipLaunchKernelGGL((mbxp_kernel<K, KSF, WIDE>), grid, dim3(512), lds, s, b);
+  hipLaunchKernelGGL((mbxp_kernel<K, KSF, WIDE, SCH>), grid, dim3(512), lds, s, b);
 }
 
+template <int K, int KSF, int SCH>
+static void launch_mbxp_ts(const MbxArgs& a, int rows, hipStream_t s) {
+  if (mbxd_wide(a.Ho, a.Wo, K, 1)) launch_mbxp_tw<K, KSF, true, SCH>(a, rows, s);
+  else launch_mbxp_tw<K, KSF, false, SCH>(a, rows, s);
+}
+template <int K, int KSF, int PARTS, int S> static void launch_mbxd_t(const MbxArgs& a, int rows, hipStream_t s);
 template <int K, int KSF>
 static void launch_mbxp_t(const MbxArgs& a, int rows, hipStream_t s) {
-  if (mbxd_wide(a.Ho, a.Wo, K, 1)) launch_mbxp_tw<K, KSF, true>(a, rows, s);
-  else launch_mbxp_tw<K, KSF, false>(a, rows, s);
+  if (a.wparts == UDA_SPLIT_F16X2) {
+    if constexpr (K == 3) {
+      // (the fp16 instances of the 3x3 variant on 16-column tiles do not build: hipcc forms the "uniform" store bases of their
+      // stores with vector arithmetic and hands the scalar-base store of store_uniform_base a vector register pair; those maps
+      // - none at 1280 x 768, where blocks 12-15 take 20-column tiles - run the two-phase kernel)
+      if (!mbxd_wide(a.Ho, a.Wo, K, 1)) { launch_mbxd_t<K, KSF, UDA_SPLIT_F16X2, 1>(a, rows, s); return; }
+      launch_mbxp_tw<K, KSF, true, UDA_SPLIT_F16X2>(a, rows, s);
+    } else {
+      launch_mbxp_ts<K, KSF, UDA_SPLIT_F16X2>(a, rows, s);
+    }
+    return;
+  }
+  launch_mbxp_ts<K, KSF, UDA_SPLIT_BF16X2>(a, rows, s);
 }
 
 bool mbxd_supported(int Cin, int Cmid, int k, int stride) {
@@ -1612,7 +1611,7 @@ template <int K, int KSF, int PARTS, int S, bool WIDE>
 static void launch_mbxd_tw(const MbxArgs& a, int rows, hipStream_t s) {
   constexpr int TH = mbxd_cfg(K, S, WIDE).th, TW = mbxd_cfg(K, S, WIDE).tw;
   const size_t lds = ((size_t)256 * 33 + 16 * 32 + 2 * (K * K + 2) * 32 + 2 * 32 * ((a.Cmid + 31) / 32)) * sizeof(float) +
-                     (size_t)KSF * PARTS * 64 * sizeof(uint4);
+                     (size_t)KSF * split_np(PARTS) * 64 * sizeof(uint4);
   static size_t attr_lds = 64 * 1024;      // above the default limit the kernel needs an explicit opt-in
   if (lds > attr_lds) {
     hipFuncSetAttribute((const void*)mbxd_kernel<K, KSF, PARTS, S, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1620,7 +1619,7 @@ static void launch_mbxd_tw(const MbxArgs& a, int rows, hipStream_t s) {
   }
   dim3 grid((a.Wo + TW - 1) / TW, (a.Ho + TH - 1) / TH, rows);
   MbxArgs b = a;
-  b.ch_groups = mbx_ch_groups((long long)grid.x * grid.y * rows, (KSF <= 8 && PARTS == 2) ? 2 : 1, (a.Cmid + 31) / 32);
+  b.ch_groups = mbx_ch_groups((long long)grid.x * grid.y * rows, (KSF <= 8 && PARTS != 3) ? 2 : 1, (a.Cmid + 31) / 32);
   grid.z = (unsigned)(rows * b.ch_groups);
   hipLaunchKernelGGL((mbxd_kernel<K, KSF, PARTS, S, WIDE>), grid, dim3(512), lds, s, b);
 }
@@ -1655,13 +1654,14 @@ static void launch_mbxd_p(const MbxArgs& a, int rows, int k, int ksf, hipStream_
 void launch_mbxd(const MbxArgs& a, int rows, int k, int stride, hipStream_t s) {
   const int ksf = (a.Cin + 1 + 15) / 16;
   if (stride == 2) {                // the first block of a stage: the two-phase kernel on the stride-2 tiles
-    if (a.wparts == 3) launch_mbxd_p<3, 2>(a, rows, k, ksf, s);
+    if (a.wparts == UDA_SPLIT_BF16X3) launch_mbxd_p<3, 2>(a, rows, k, ksf, s);
+    else if (a.wparts == UDA_SPLIT_F16X2) launch_mbxd_p<4, 2>(a, rows, k, ksf, s);
     else launch_mbxd_p<2, 2>(a, rows, k, ksf, s);
     return;
   }
   static int pipe = -1;
   if (pipe < 0) { const char* e = getenv("UDA_MBXP"); pipe = e ? atoi(e) : 1; }
-  if (a.wparts == 3) {              // six cross terms (UDA_PW_TERMS=6): three pieces per operand, the two-phase kernel
+  if (a.wparts == UDA_SPLIT_BF16X3) {     // six cross terms: three pieces per operand, the two-phase kernel
     launch_mbxd_p<3, 1>(a, rows, k, ksf, s);
     return;
   }
@@ -1670,7 +1670,8 @@ void launch_mbxd(const MbxArgs& a, int rows, int k, int stride, hipStream_t s) {
     else { if (ksf == 13) launch_mbxp_t<5, 13>(a, rows, s); else launch_mbxp_t<5, 14>(a, rows, s); }
     return;
   }
-  launch_mbxd_p<2, 1>(a, rows, k, ksf, s);
+  if (a.wparts == UDA_SPLIT_F16X2) launch_mbxd_p<4, 1>(a, rows, k, ksf, s);
+  else launch_mbxd_p<2, 1>(a, rows, k, ksf, s);
 }
 
 // depthwise-side operands of the fused kernels, one contiguous block per 32-channel slab:
@@ -1690,10 +1691,10 @@ void mbx_pack_params(const float* wd, const float* sc1, const float* sh1, int Cm
 }
 
 // expand kernel [Cin][Cmid] times the BN scale, plus the BN shift as row Cin -> packed split-bf16 fragments
-size_t mbxb_packed_elems(int Cin, int Cmid, int parts) { return pwb_packed_elems(Cin + 1, Cmid, parts); }
+size_t mbxb_packed_elems(int Cin, int Cmid, int scheme) { return pwb_packed_elems(Cin + 1, Cmid, scheme); }
 // perm16: rows 0..15 stored in the k order of an accumulator tile used as the A operand (FUSE0): slot 8 h + j holds
 // channel (j & 3) + 8 (j >> 2) + 4 h
-void mbxb_pack_weights(const float* we, const float* sc0, const float* sh0, int Cin, int Cmid, uint16_t* out, bool perm16, int parts) {
+void mbxb_pack_weights(const float* we, const float* sc0, const float* sh0, int Cin, int Cmid, uint16_t* out, bool perm16, int scheme, float* stats) {
   float* w = (float*)malloc((size_t)(Cin + 1) * Cmid * sizeof(float));
   // the GEMM delivers y = -log2(e) * BN(x W): see swish_folded
   const float L = -1.4426950408889634f;
@@ -1708,7 +1709,15 @@ void mbxb_pack_weights(const float* we, const float* sc0, const float* sh0, int 
         memcpy(w + (size_t)(8 * h + j) * Cmid, t + (size_t)((j & 3) + 8 * (j >> 2) + 4 * h) * Cmid, (size_t)Cmid * sizeof(float));
     free(t);
   }
-  pwb_pack_weights(w, Cin + 1, Cmid, parts, out);
+  if (stats) {
+    double mx = 0.0, s2 = 0.0;
+    const size_t n = (size_t)(Cin + 1) * Cmid;
+    for (size_t i = 0; i < n; ++i) { const double v = fabs((double)w[i]); if (v > mx) mx = v; s2 += v * v; }
+    stats[0] = (float)mx;
+    stats[1] = (float)sqrt(s2 / (double)(n ? n : 1));
+  }
+  // (no power-of-two pre-scale here: the expand accumulator feeds the swish directly, there is no free place to undo one)
+  pwb_pack_weights(w, Cin + 1, Cmid, scheme, out);
   free(w);
 }
 
@@ -1733,24 +1742,70 @@ static inline float bf16_to_f32(uint16_t h) {
   return x;
 }
 
-size_t pwb_packed_elems(int K, int N, int parts) {
-  return (size_t)((K + 15) / 16) * ((N + 31) / 32) * parts * 64 * 8;
+// IEEE binary16, round to nearest even, subnormals kept (what v_cvt_pk_f16_f32 does on the device); finite inputs
+static inline uint16_t f32_to_f16_rne(float x) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+  const uint32_t a = u & 0x7FFFFFFFu;
+  if (a >= 0x47800000u) return (uint16_t)(sign | 0x7C00u);               // >= 65536 (or inf / NaN): infinity
+  if (a < 0x38800000u) {                                                  // below 2^-14: subnormal (or zero)
+    if (a < 0x33000000u) return sign;                                     // below 2^-25: rounds to zero
+    const int e = (int)(a >> 23);                                         // biased float exponent, 102 .. 112
+    const uint32_t m = (a & 0x7FFFFFu) | 0x800000u;                       // 24-bit significand
+    const int shift = 126 - e;                                            // value = m * 2^(e - 150); units of 2^-24 -> m >> shift
+    const uint32_t q = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    uint32_t r = q;
+    if (rem > half || (rem == half && (q & 1u))) ++r;
+    return (uint16_t)(sign | r);                                          // (a carry into 0x400 is the smallest normal: correct)
+  }
+  uint32_t r = a + 0xFFFu + ((a >> 13) & 1u);                             // round the 13 dropped bits to nearest even
+  r = ((r >> 13) - (112u << 10));                                         // rebias 127 -> 15
+  if (r >= 0x7C00u) r = 0x7C00u;                                          // 65520 and above round to infinity
+  return (uint16_t)(sign | r);
+}
+static inline float f16_to_f32(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  const uint32_t e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
+  float x;
+  if (e == 0) {
+    x = ldexpf((float)m, -24);
+    uint32_t u; memcpy(&u, &x, 4); u |= sign; memcpy(&x, &u, 4);
+    return x;
+  }
+  const uint32_t u = sign | (e == 31 ? 0x7F800000u | (m << 13) : ((e + 112u) << 23) | (m << 13));
+  memcpy(&x, &u, 4);
+  return x;
+}
+
+size_t pwb_packed_elems(int K, int N, int scheme) {
+  return (size_t)((K + 15) / 16) * ((N + 31) / 32) * uda_split_pieces(scheme) * 64 * 8;
+}
+
+float split_weight_scale(const float* w, size_t n) {
+  float mx = 0.f;
+  for (size_t i = 0; i < n; ++i) { const float v = fabsf(w[i]); if (v > mx) mx = v; }
+  if (!(mx > 0.f) || !(mx < 3.0e38f)) return 1.0f;
+  int e = 0;
+  frexpf(mx, &e);                 // mx = f * 2^e, f in [0.5, 1)  ->  mx * 2^(14 - e) in [2^13, 2^14)
+  return ldexpf(1.0f, 14 - e);
 }
 
 // w [K][N] float32 -> fragments [k-step][32-col tile][part][lane][8] bf16 of v_mfma_f32_32x32x16_bf16's B operand:
 // lane l holds B[16 s + 8 (l >> 5) + e][32 j + (l & 31)], e = 0..7
-void pwb_pack_weights(const float* w, int K, int N, int parts, uint16_t* out) {
-  const int KS = (K + 15) / 16, NTL = (N + 31) / 32;
+void pwb_pack_weights(const float* w, int K, int N, int scheme, uint16_t* out, float scale) {
+  const int KS = (K + 15) / 16, NTL = (N + 31) / 32, parts = uda_split_pieces(scheme);
+  const bool half = scheme == UDA_SPLIT_F16X2;
   for (int s = 0; s < KS; ++s)
     for (int j = 0; j < NTL; ++j)
       for (int l = 0; l < 64; ++l)
         for (int e = 0; e < 8; ++e) {
           const int k = 16 * s + 8 * (l >> 5) + e, n = 32 * j + (l & 31);
-          float r = (k < K && n < N) ? w[(size_t)k * N + n] : 0.f;
+          float r = (k < K && n < N) ? w[(size_t)k * N + n] * scale : 0.f;
           for (int p = 0; p < parts; ++p) {
-            const uint16_t h = f32_to_bf16_rne(r);
+            const uint16_t h = half ? f32_to_f16_rne(r) : f32_to_bf16_rne(r);
             out[((((size_t)s * NTL + j) * parts + p) * 64 + l) * 8 + e] = h;
-            r -= bf16_to_f32(h);
+            r -= half ? f16_to_f32(h) : bf16_to_f32(h);
           }
         }
 }

@@ -33,16 +33,18 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
     const SepLevel& L = m.lv[l];
     a.in = L.in; a.out = L.out; a.wd = L.wd; a.wsplit = L.wsplit;
     a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift; a.mask = L.mask;
-    a.H = L.H; a.W = L.W;
+    a.H = L.H; a.W = L.W; a.wunscale = L.wunscale;
   }
   extern __shared__ __attribute__((aligned(16))) unsigned char slds[];
   const int C = a.C, C4 = C >> 2;
   const int KS = (C + 15) >> 4;            // MFMA k-steps
+  constexpr int NPC = split_np(PARTS);     // pieces per operand (PARTS names the scheme: UDA_SPLIT_*)
   constexpr bool F32A = PARTS == 3;        // A image kept as float32, split at the fragment loads
+  float amax = 0.f;                        // fp16 pieces: largest operand magnitude this lane has split
   // bytes per A image row: KS * 16 bf16 (float32) + 16 pad (conflict-free ds_read_b128: 36- / 68-dword pitch at C = 64)
   const int arow = F32A ? KS * 64 + 16 : KS * 32 + 16;
-  unsigned char* As = slds;                // [PARTS][BM][arow] bf16 pieces, or [BM][arow] float32
-  uint4* Bs = (uint4*)(slds + (size_t)(F32A ? 1 : PARTS) * BM * arow);   // [KS][NT][PARTS][64 lanes] x 16 B
+  unsigned char* As = slds;                // [NPC][BM][arow] pieces, or [BM][arow] float32
+  uint4* Bs = (uint4*)(slds + (size_t)(F32A ? 1 : NPC) * BM * arow);   // [KS][NT][NPC][64 lanes] x 16 B
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, b_in = b / a.in_div;
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
 
   // ---- B: all k-steps of this block's column tiles, requested first (in flight during the depthwise stage)
   const uint4* Wp = (const uint4*)a.wsplit;
-  const int b_total = KS * NT * PARTS * 64;
+  const int b_total = KS * NT * NPC * 64;
   constexpr int B_MAX = 8;                 // uint4 per thread: K <= 128, NT <= 4, PARTS = 2 -> 8 * 4 * 2 * 64 / 256 = 16 (two rounds)
   for (int f0 = tid; f0 < b_total; f0 += 256 * B_MAX) {
     uint4 rb[B_MAX];
@@ -62,10 +64,10 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
     for (int i = 0; i < B_MAX; ++i) {
       const int f = f0 + 256 * i;
       int q = f >> 6;
-      const int part = q % PARTS; q /= PARTS;
+      const int part = q % NPC; q /= NPC;
       const int nt = q % NT, ks = q / NT;
       rb[i] = make_uint4(0u, 0u, 0u, 0u);
-      if (f < b_total && nt0 + nt < NTL) rb[i] = Wp[(((size_t)ks * NTL + (nt0 + nt)) * PARTS + part) * 64 + (f & 63)];
+      if (f < b_total && nt0 + nt < NTL) rb[i] = Wp[(((size_t)ks * NTL + (nt0 + nt)) * NPC + part) * 64 + (f & 63)];
     }
 #pragma unroll
     for (int i = 0; i < B_MAX; ++i) {
@@ -117,13 +119,15 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
         continue;
       }
       float r0 = acc.x, r1 = acc.y, r2 = acc.z, r3 = acc.w;
+      split_track<PARTS>(amax, r0, r1);
+      split_track<PARTS>(amax, r2, r3);
 #pragma unroll
-      for (int p = 0; p < PARTS; ++p) {
-        const unsigned u0 = pack_bf16(r0, r1), u1 = pack_bf16(r2, r3);
+      for (int p = 0; p < NPC; ++p) {
+        const unsigned u0 = pack_piece<PARTS>(r0, r1), u1 = pack_piece<PARTS>(r2, r3);
         *(uint2*)(As + (size_t)(p * BM + m) * arow + q * 8) = make_uint2(u0, u1);
-        if (p + 1 < PARTS) {
-          r0 -= bf16_lo_f32(u0); r1 -= bf16_hi_f32(u0);
-          r2 -= bf16_lo_f32(u1); r3 -= bf16_hi_f32(u1);
+        if (p + 1 < NPC) {
+          r0 -= piece_lo<PARTS>(u0); r1 -= piece_hi<PARTS>(u0);
+          r2 -= piece_lo<PARTS>(u1); r3 -= piece_hi<PARTS>(u1);
         }
       }
     }
@@ -133,9 +137,10 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
     if constexpr (F32A) {
       for (int e = tid; e < 2 * BM; e += 256) *(uint4*)(As + (size_t)(e >> 1) * arow + (C >> 3) * 32 + (e & 1) * 16) = make_uint4(0u, 0u, 0u, 0u);
     } else {
-      for (int e = tid; e < PARTS * BM; e += 256) *(uint4*)(As + (size_t)e * arow + (C >> 3) * 16) = make_uint4(0u, 0u, 0u, 0u);
+      for (int e = tid; e < NPC * BM; e += 256) *(uint4*)(As + (size_t)e * arow + (C >> 3) * 16) = make_uint4(0u, 0u, 0u, 0u);
     }
   }
+  split_report<PARTS>(amax, a.oor);
   __syncthreads();
 
   // ---- 1x1 on the matrix cores: wave w owns pixel rows [32 w, 32 w + 32) and all NT column tiles
@@ -145,38 +150,22 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
   for (int ks = 0; ks < KS; ++ks) {
-    bf16x8 af[PARTS];
+    bf16x8 af[NPC];
     if constexpr (F32A) {
       const unsigned char* ap = As + (size_t)(wave * 32 + li) * arow + ks * 64 + lh * 32;     // 8 channels of pixel row li
       const float4 v0 = *(const float4*)ap, v1 = *(const float4*)(ap + 16);
-      float r0 = v0.x, r1 = v0.y, r2 = v0.z, r3 = v0.w, r4 = v1.x, r5 = v1.y, r6 = v1.z, r7 = v1.w;
-#pragma unroll
-      for (int p = 0; p < PARTS; ++p) {
-        const unsigned u0 = pack_bf16(r0, r1), u1 = pack_bf16(r2, r3), u2 = pack_bf16(r4, r5), u3 = pack_bf16(r6, r7);
-        af[p] = __builtin_bit_cast(bf16x8, make_uint4(u0, u1, u2, u3));
-        if (p + 1 < PARTS) {
-          r0 -= bf16_lo_f32(u0); r1 -= bf16_hi_f32(u0); r2 -= bf16_lo_f32(u1); r3 -= bf16_hi_f32(u1);
-          r4 -= bf16_lo_f32(u2); r5 -= bf16_hi_f32(u2); r6 -= bf16_lo_f32(u3); r7 -= bf16_hi_f32(u3);
-        }
-      }
+      split_parts<PARTS>(v0, v1, af);
     } else {
 #pragma unroll
-      for (int p = 0; p < PARTS; ++p)
+      for (int p = 0; p < NPC; ++p)
         af[p] = *(const bf16x8*)(As + (size_t)(p * BM + wave * 32 + li) * arow + ks * 32 + lh * 16);
     }
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-      bf16x8 bf[PARTS];
+      bf16x8 bf[NPC];
 #pragma unroll
-      for (int p = 0; p < PARTS; ++p) bf[p] = __builtin_bit_cast(bf16x8, Bs[((ks * NT + n) * PARTS + p) * 64 + lane]);
-      if constexpr (PARTS == 3) {
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[n], 0, 0, 0);
-      }
-      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[n], 0, 0, 0);
-      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[n], 0, 0, 0);
-      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[n], 0, 0, 0);
+      for (int p = 0; p < NPC; ++p) bf[p] = __builtin_bit_cast(bf16x8, Bs[((ks * NT + n) * NPC + p) * 64 + lane]);
+      acc[n] = mfma_terms<PARTS>(af, bf, acc[n]);
     }
   }
   __syncthreads();      // the staging tile below aliases the A / B images
@@ -188,6 +177,7 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
     return y < a.H && x < a.W;
   };
   const size_t out_base = (size_t)b * a.H * a.W;
+  const float un = a.wunscale;             // the packed weights carry a power-of-two factor 1 / un (fp16 pieces; else 1)
 
   if ((a.Cout & 3) != 0) {
     // scalar epilogue (class head: 9 * 7 = 63 channels)
@@ -203,7 +193,7 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
       for (int r = 0; r < 16; ++r) {
         size_t pix;
         if (!pixel_of(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, pix)) continue;
-        float v = fmaf(acc[n][r] + bias, sc, sh);
+        float v = fmaf(fmaf(acc[n][r], un, bias), sc, sh);
         if (a.act == UDA_ACT_SWISH) v = swishf_b(v);
         v *= mk;
         a.out[(out_base + pix) * a.Cout + col] = v;
@@ -243,10 +233,10 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
       size_t pix;
       if (colok && pixel_of(wave * 32 + row, pix)) {
         float4 v = *(const float4*)(stg + row * PWB_STG + 4 * c4);
-        v.x = fmaf(v.x + bias.x, sc.x, sh.x);
-        v.y = fmaf(v.y + bias.y, sc.y, sh.y);
-        v.z = fmaf(v.z + bias.z, sc.z, sh.z);
-        v.w = fmaf(v.w + bias.w, sc.w, sh.w);
+        v.x = fmaf(fmaf(v.x, un, bias.x), sc.x, sh.x);
+        v.y = fmaf(fmaf(v.y, un, bias.y), sc.y, sh.y);
+        v.z = fmaf(fmaf(v.z, un, bias.z), sc.z, sh.z);
+        v.w = fmaf(fmaf(v.w, un, bias.w), sc.w, sh.w);
         if (a.act == UDA_ACT_SWISH) {
           v.x = swishf_b(v.x); v.y = swishf_b(v.y); v.z = swishf_b(v.z); v.w = swishf_b(v.w);
         }
@@ -266,8 +256,9 @@ template <int NT>
 static void launch_sep_nt(const SepMulti& m, int rows, int gy, hipStream_t s) {
   const SepArgs& a = m.one;
   const int KS = (a.C + 15) / 16;
-  const size_t a_img = a.wparts == 3 ? (size_t)128 * (KS * 64 + 16) : (size_t)a.wparts * 128 * (KS * 32 + 16);   // float32 image | bf16 pieces
-  size_t lds = a_img + (size_t)KS * NT * a.wparts * 1024;
+  const int npc = uda_split_pieces(a.wparts);
+  const size_t a_img = a.wparts == UDA_SPLIT_BF16X3 ? (size_t)128 * (KS * 64 + 16) : (size_t)npc * 128 * (KS * 32 + 16);   // float32 image | pieces
+  size_t lds = a_img + (size_t)KS * NT * npc * 1024;
   const size_t stg = 4 * 32 * PWB_STG * 4;
   if (lds < stg) lds = stg;
   const dim3 grid(m.n_lv > 0 ? m.tile0[m.n_lv] : sep_tiles(a.H, a.W), gy, rows);
@@ -281,7 +272,8 @@ static void launch_sep_nt(const SepMulti& m, int rows, int gy, hipStream_t s) {
   };
   static int occ = -1;
   if (occ < 0) { const char* e = getenv("UDA_SEP_OCC"); occ = e ? atoi(e) : 3; }   // 3 blocks per CU: measured 14 % faster than 2
-  if (a.wparts == 3) { if (occ >= 3 && NT <= 2) go(sep_kernel<NT, 3, 3>); else go(sep_kernel<NT, 3, 2>); }
+  if (a.wparts == UDA_SPLIT_BF16X3) { if (occ >= 3 && NT <= 2) go(sep_kernel<NT, 3, 3>); else go(sep_kernel<NT, 3, 2>); }
+  else if (a.wparts == UDA_SPLIT_F16X2) { if (occ >= 3 && NT <= 2) go(sep_kernel<NT, 4, 3>); else go(sep_kernel<NT, 4, 2>); }
   else if (occ >= 3 && NT <= 2) go(sep_kernel<NT, 2, 3>);
   else go(sep_kernel<NT, 2, 2>);
 }
@@ -292,8 +284,9 @@ static void launch_sep_any(const SepMulti& m, int rows, hipStream_t s) {
   // fragments of four column tiles (7 x 4 x 3 KB) are 142 KB - two column tiles per block there, more column blocks
   {
     const int KS = (m.one.C + 15) / 16;
-    const size_t a_img = m.one.wparts == 3 ? (size_t)128 * (KS * 64 + 16) : (size_t)m.one.wparts * 128 * (KS * 32 + 16);
-    const size_t need = a_img + (size_t)KS * (ntl < 4 ? ntl : 3) * m.one.wparts * 1024;
+    const int npc = uda_split_pieces(m.one.wparts);
+    const size_t a_img = m.one.wparts == UDA_SPLIT_BF16X3 ? (size_t)128 * (KS * 64 + 16) : (size_t)npc * 128 * (KS * 32 + 16);
+    const size_t need = a_img + (size_t)KS * (ntl < 4 ? ntl : 3) * npc * 1024;
     if (ntl > 2 && need > 120 * 1024) { launch_sep_nt<2>(m, rows, (ntl + 1) / 2, s); return; }
   }
   // all columns in one block when they fit four 32-column tiles, else blocks of three

@@ -39,10 +39,15 @@ struct uda_ctx {
   uint16_t* d_wsplit = nullptr;
   std::vector<int64_t> wsplit_off;
   std::vector<int64_t> wpar_off;   // MBX: offset (uint16 units) of the per-slab depthwise operand block inside d_wsplit
-  int pw_parts = 2;            // UDA_PW_TERMS: 3 -> 2 pieces (default), 6 -> 3 pieces, 0 -> f32 MFMA everywhere
+  int pw_parts = UDA_SPLIT_F16X2;  // requested split scheme of the 1x1 contractions (UDA_PW_SCHEME / UDA_PW_TERMS, parse_pw_scheme)
+  std::vector<int> wscheme;        // per op: the scheme its packed weights use (an op whose weights do not suit fp16 pieces keeps bf16 x3)
+  std::vector<float> wunscale;     // per op: 1 / (power-of-two factor folded into the packed weights); 1 unless fp16 pieces
+  int n_f16_ops = 0, n_f16_demoted = 0;
+  unsigned* d_oor = nullptr;       // fp16 pieces: bit 0 set by any kernel that split an operand above 65504
+  bool oor_armed = false;          // a run with fp16-piece ops has been queued since the flag was last read
   float* d_arena = nullptr;
-  uint4* d_w0frag = nullptr;       // gated, split projection kernel per gate row for the fused block-1 kernel (launch_w0gate)
-  size_t w0frag_cap = 0;
+  uint4* d_w0frag[2] = {nullptr, nullptr};   // gated, split projection kernel per gate row for the fused block-1 kernel (launch_w0gate), per chunk lane
+  size_t w0frag_cap[2] = {0, 0};
   // chunk lanes: consecutive chunks alternate between independent (stream, arena) pairs so that the
   // barrier-heavy kernels of one chunk overlap the streaming kernels of the other
   int n_lanes = 1;
@@ -176,6 +181,27 @@ static hipError_t dalloc(T** p, size_t n) {
   return hipMalloc((void**)p, (n ? n : 1) * sizeof(T));
 }
 
+// UDA_PW_SCHEME = f16x2 | bf16x3 | bf16x2 | f32 (mirror: plan.pw_scheme); the older UDA_PW_TERMS = 6 | 3 | 0 names the last three
+static int parse_pw_scheme(std::string* err) {
+  const char* v = getenv("UDA_PW_SCHEME");
+  if (v && *v) {
+    if (!strcmp(v, "f16x2")) return UDA_SPLIT_F16X2;
+    if (!strcmp(v, "bf16x3")) return UDA_SPLIT_BF16X3;
+    if (!strcmp(v, "bf16x2")) return UDA_SPLIT_BF16X2;
+    if (!strcmp(v, "f32")) return UDA_SPLIT_NONE;
+    if (err) *err = std::string("UDA_PW_SCHEME=") + v + ": expected f16x2, bf16x3, bf16x2 or f32";
+    return -1;
+  }
+  const char* t = getenv("UDA_PW_TERMS");
+  if (!t || !*t) return UDA_SPLIT_F16X2;
+  const int terms = atoi(t);
+  if (terms == 0) return UDA_SPLIT_NONE;
+  if (terms == 6) return UDA_SPLIT_BF16X3;
+  if (terms == 3) return UDA_SPLIT_BF16X2;
+  if (err) *err = std::string("UDA_PW_TERMS=") + t + ": expected 6, 3 or 0";
+  return -1;
+}
+
 static inline int same_pad_before(int in, int out, int k, int s) {
   int total = (out - 1) * s + k - in;
   if (total < 0) total = 0;
@@ -240,7 +266,8 @@ extern "C" void uda_destroy(uda_ctx_t* c) {
   }
   for (auto& e : c->ev_pre_done) if (e) hipEventDestroy(e);
   if (c->copy_stream) hipStreamDestroy(c->copy_stream);
-  if (c->d_w0frag) hipFree(c->d_w0frag);
+  for (auto& p : c->d_w0frag) if (p) hipFree(p);
+  if (c->d_oor) hipFree(c->d_oor);
   void* ptrs[] = {c->d_weights, c->d_wsplit, c->d_arena, c->d_anchors, c->d_images, c->d_scales, c->d_masks,
                   c->d_site_off, c->d_site_ch, c->d_site_rate, c->d_cboxes, c->d_cscores, c->d_clogits,
                   c->d_cclasses, c->d_ucls, c->d_ual, c->d_uep, c->d_clsmean, c->d_cand_flat, c->d_merge_keys,
@@ -454,11 +481,15 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
   CK(hipMemcpy(c->d_weights, weights, (size_t)n_weights * sizeof(float), hipMemcpyHostToDevice));
   {
     // split-precision copies of every 1x1 kernel, packed once (host) in B-fragment order
-    const char* e = getenv("UDA_PW_TERMS");
-    const int terms = e ? atoi(e) : 3;
-    c->pw_parts = terms == 0 ? 0 : (terms == 6 ? 3 : 2);
+    std::string perr;
+    c->pw_parts = parse_pw_scheme(&perr);
+    if (c->pw_parts < 0) { fail(nullptr, "uda_create: %s", perr.c_str()); uda_destroy(c); return 1; }
     c->wsplit_off.assign(n_ops, -1);
     c->wpar_off.assign(n_ops, -1);
+    c->wscheme.assign(n_ops, c->pw_parts);
+    c->wunscale.assign(n_ops, 1.0f);
+    CK(dalloc(&c->d_oor, 1));
+    CK(hipMemset(c->d_oor, 0, sizeof(unsigned)));
     const char* em = getenv("UDA_MBX_BF16");
     const bool mbx_bf16 = em ? atoi(em) != 0 : true;
     if (c->pw_parts) {
@@ -468,20 +499,70 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
         if (o.w_off < 0) continue;
         const int K = bufs[o.in[0]].C, Nn = bufs[o.out].C;
         const size_t at = packed.size();
+        // diagnostic: UDA_F16_KINDS=pw,sep,mbx (any subset) keeps fp16 pieces for those op kinds only, three bf16 pieces elsewhere
+        static const char* f16_kinds = getenv("UDA_F16_KINDS");
+        const bool kind_f16 = !f16_kinds || strstr(f16_kinds, o.kind == UDA_OP_PW ? "pw" : (o.kind == UDA_OP_SEP ? "sep" : "mbx")) != nullptr;
         if (o.kind == UDA_OP_PW || o.kind == UDA_OP_SEP) {
-          packed.resize(at + pwb_packed_elems(K, Nn, c->pw_parts));
-          pwb_pack_weights(weights + o.w_off, K, Nn, c->pw_parts, packed.data() + at);
+          // fp16 pieces: the kernel times a power of two that puts its largest entry in [2^13, 2^14) - every low piece of a
+          // weight that matters is then a normal fp16 number; the epilogue multiplies the accumulator by the inverse (exact)
+          float scale = 1.0f;
+          int sch = c->pw_parts;
+          if (sch == UDA_SPLIT_F16X2 && !kind_f16) sch = UDA_SPLIT_BF16X3;
+          if (sch == UDA_SPLIT_F16X2) {
+            scale = split_weight_scale(weights + o.w_off, (size_t)K * Nn);
+            c->wunscale[i] = 1.0f / scale;
+            ++c->n_f16_ops;
+          }
+          c->wscheme[i] = sch;
+          const size_t w_elems = (pwb_packed_elems(K, Nn, sch) + 7) / 8 * 8;
+          // fp16 pieces, separable conv: the A operand is the depthwise result, whose magnitude nothing bounds from below (a
+          // BiFPN / head feature times nine small taps: rms 0.01-0.1 under the reference initialisers - its low pieces would
+          // all be subnormal, 2^-25 absolute instead of 2^-22 relative: measured 3.2e-6 / 6.2e-6 relative rms on the heads of
+          // D0 / D2, all of it from these ops; with the shift 2.4e-7 / 3.1e-7, the float32 floor of 2.3e-7 / 3.3e-7 that three
+          // bf16 pieces reach).  The depthwise kernel is therefore applied times 2^UDA_F16_SEP_SHIFT (default 6; a host-side copy
+          // of the 9 x C taps behind the packed 1x1 kernel, no device cost) and the epilogue's factor carries the inverse;
+          // the range flag watches the scaled values (65504 / 64 = 1023 for the depthwise result itself).
+          size_t dw_fl = 0;
+          float ascale = 1.0f;
+          if (o.kind == UDA_OP_SEP && sch == UDA_SPLIT_F16X2 && o.w2_off >= 0) {
+            static const int shift = getenv("UDA_F16_SEP_SHIFT") ? atoi(getenv("UDA_F16_SEP_SHIFT")) : 6;
+            ascale = ldexpf(1.0f, shift < 0 ? 0 : (shift > 12 ? 12 : shift));
+            dw_fl = (size_t)9 * K;
+          }
+          packed.resize(at + w_elems + 2 * dw_fl);
+          pwb_pack_weights(weights + o.w_off, K, Nn, sch, packed.data() + at, scale);
+          if (dw_fl) {
+            std::vector<float> wd(dw_fl);
+            for (size_t j = 0; j < dw_fl; ++j) wd[j] = weights[o.w2_off + j] * ascale;
+            memcpy(packed.data() + at + w_elems, wd.data(), dw_fl * sizeof(float));
+            c->wpar_off[i] = (int64_t)(at + w_elems);
+            c->wunscale[i] /= ascale;
+          }
         } else if (o.kind == UDA_OP_MBX && mbx_bf16 && o.bn_scale_off >= 0 && o.bn_shift_off >= 0 &&
                    (mbxb_supported(o.se_scale >= 0 ? o.se_mid : K, Nn, o.k, o.stride) || mbxd_supported(K, Nn, o.k, o.stride))) {
           if (o.w2_off < 0 || o.bn2_scale_off < 0 || o.bn2_shift_off < 0) continue;
           const bool fuse0 = o.se_scale >= 0;      // the previous block's projection is computed in this op's prologue
           const int Ke = fuse0 ? o.se_mid : K;     // input channels of the expand
           // [split expand weights | 16-byte aligned float block of the depthwise-side operands | (fuse0) projection block]
-          const size_t we_elems = (mbxb_packed_elems(Ke, Nn, c->pw_parts) + 7) / 8 * 8;
+          // fp16 pieces in a fused MBConv op: the expand accumulator feeds the swish directly, so the packed kernel (times
+          // the BN scale, with the BN shift row) cannot carry a power-of-two factor.  It keeps fp16 pieces when its entries
+          // sit where two pieces resolve them (largest below 2^15, rms at least 2^-6: a low piece that is subnormal resolves
+          // 2^-25 absolutely); otherwise THIS op keeps three bf16 pieces - decided here, per op, never silently degraded.
+          int sch = c->pw_parts;
+          if (sch == UDA_SPLIT_F16X2) {
+            std::vector<uint16_t> probe(mbxb_packed_elems(Ke, Nn, UDA_SPLIT_F16X2));
+            float st[2] = {0.f, 0.f};
+            mbxb_pack_weights(weights + o.w_off, weights + o.bn_scale_off, weights + o.bn_shift_off, Ke, Nn, probe.data(), fuse0, UDA_SPLIT_F16X2, st);
+            static const float min_rms = getenv("UDA_F16_MIN_RMS") ? (float)atof(getenv("UDA_F16_MIN_RMS")) : 0.015625f;
+            if (!(st[0] < 32768.0f) || !(st[1] >= min_rms) || !kind_f16) { sch = UDA_SPLIT_BF16X3; ++c->n_f16_demoted; }
+            else ++c->n_f16_ops;
+          }
+          c->wscheme[i] = sch;
+          const size_t we_elems = (mbxb_packed_elems(Ke, Nn, sch) + 7) / 8 * 8;
           const size_t par_fl = mbx_par_floats(Nn, o.k);
           const size_t proj_fl = fuse0 ? 32 * 32 + 32 : 0;
           packed.resize(at + we_elems + 2 * (par_fl + proj_fl));
-          mbxb_pack_weights(weights + o.w_off, weights + o.bn_scale_off, weights + o.bn_shift_off, Ke, Nn, packed.data() + at, fuse0, c->pw_parts);
+          mbxb_pack_weights(weights + o.w_off, weights + o.bn_scale_off, weights + o.bn_shift_off, Ke, Nn, packed.data() + at, fuse0, sch);
           std::vector<float> par(par_fl + proj_fl);
           mbx_pack_params(weights + o.w2_off, weights + o.bn2_scale_off, weights + o.bn2_shift_off, Nn, o.k, par.data());
           if (fuse0) mbxb_pack_proj(weights + o.se_w1_off, weights + o.se_b1_off, weights + o.se_w2_off, K, Ke, par.data() + par_fl);
@@ -825,7 +906,6 @@ struct ChunkView {
   uda_ctx* c;
   int i0, nc;
   int lane = 0;
-  int sub0 = 0;      // first image of a sub-chunk inside the chunk (experiment UDA_MALL_IMAGES: a block's ops on a few images at a time)
   hipStream_t stream() const { return c->lane_stream[lane]; }
   int rows(const uda_buf_desc_t& b) const { return nc * (b.per_sample ? c->model.mc_samples : 1); }
   float* ptr(int id) const {
@@ -833,16 +913,16 @@ struct ChunkView {
     const size_t per = (size_t)b.H * b.W * b.C;
     const int T = c->model.mc_samples;
     switch (b.kind) {
-      case 1: return c->d_images + (size_t)(i0 + sub0) * per;
-      case 2: return c->d_cls[b.level] + (size_t)(i0 + sub0) * (b.per_sample ? T : 1) * per;
-      case 3: return c->d_box[b.level] + (size_t)(i0 + sub0) * (b.per_sample ? T : 1) * per;
-      default: return c->lane_arena[lane] + b.offset + (size_t)sub0 * (b.per_sample ? T : 1) * per;
+      case 1: return c->d_images + (size_t)i0 * per;
+      case 2: return c->d_cls[b.level] + (size_t)i0 * (b.per_sample ? T : 1) * per;
+      case 3: return c->d_box[b.level] + (size_t)i0 * (b.per_sample ? T : 1) * per;
+      default: return c->lane_arena[lane] + b.offset;
     }
   }
   const float* wt(int64_t off) const { return off < 0 ? nullptr : c->d_weights + off; }
   const float* mask(int site) const {
     if (site < 0) return nullptr;
-    return c->d_masks + c->site_off[site] + (size_t)(i0 + sub0) * c->model.mc_samples * c->sites[site].channels;
+    return c->d_masks + c->site_off[site] + (size_t)i0 * c->model.mc_samples * c->sites[site].channels;
   }
   int div(const uda_buf_desc_t& in, const uda_buf_desc_t& out) const {
     return (out.per_sample && !in.per_sample) ? c->model.mc_samples : 1;
@@ -898,7 +978,10 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       a.act = o.act;
       if (c->wsplit_off[oi] >= 0) {
         a.wsplit = c->d_wsplit + c->wsplit_off[oi];
-        a.wparts = c->pw_parts;
+        a.wparts = c->wscheme[oi];
+        a.wunscale = c->wunscale[oi];
+        a.oor = c->d_oor;
+        if (a.wparts == UDA_SPLIT_F16X2) c->oor_armed = true;
         launch_pwb(a, rows, v.stream());
       } else {
         launch_pw(a, rows, v.stream());
@@ -964,7 +1047,9 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       }
       if (c->wsplit_off[oi] >= 0) {
         a.wsplit = c->d_wsplit + c->wsplit_off[oi];
-        a.wparts = c->pw_parts;
+        a.wparts = c->wscheme[oi];
+        a.oor = c->d_oor;
+        if (a.wparts == UDA_SPLIT_F16X2) c->oor_armed = true;
         a.wpar = (const float*)(c->d_wsplit + c->wpar_off[oi]);
         if (fuse0) {
           const uda_buf_desc_t& gb = c->bufs[o.se_scale];
@@ -976,17 +1061,20 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
           a.sh0f = a.w0t + 32 * 32;
           static const bool pre = !(getenv("UDA_W0GATE") && atoi(getenv("UDA_W0GATE")) == 0);   // 0: every block redoes the prep
           if (pre && ib.C == 32) {
+            // one buffer per chunk lane: with UDA_LANES=2 consecutive chunks run concurrently on two streams, each with its
+            // own gates - lane 1's prep must not overwrite the fragments lane 0's block-1 kernel is still reading
             const int gate_rows = v.rows(gb);
-            const size_t need = mbxb_w0frag_elems(gate_rows, c->pw_parts);
-            if (need > c->w0frag_cap) {
-              HIPC(c, hipStreamSynchronize(v.stream()));
-              if (c->d_w0frag) HIPC(c, hipFree(c->d_w0frag));
-              c->d_w0frag = nullptr; c->w0frag_cap = 0;
-              HIPC(c, hipMalloc((void**)&c->d_w0frag, need * sizeof(uint4)));
-              c->w0frag_cap = need;
+            const int ln = v.lane & 1;
+            const size_t need = mbxb_w0frag_elems(gate_rows, a.wparts);
+            if (need > c->w0frag_cap[ln]) {
+              HIPC(c, hipStreamSynchronize(v.stream()));     // this lane's stream is the only user of this lane's buffer
+              if (c->d_w0frag[ln]) HIPC(c, hipFree(c->d_w0frag[ln]));
+              c->d_w0frag[ln] = nullptr; c->w0frag_cap[ln] = 0;
+              HIPC(c, hipMalloc((void**)&c->d_w0frag[ln], need * sizeof(uint4)));
+              c->w0frag_cap[ln] = need;
             }
-            launch_w0gate(a.gate, a.w0t, a.c0, gate_rows, c->pw_parts, c->d_w0frag, v.stream());
-            a.w0frag = c->d_w0frag;
+            launch_w0gate(a.gate, a.w0t, a.c0, gate_rows, a.wparts, c->d_w0frag[ln], c->d_oor, v.stream());
+            a.w0frag = c->d_w0frag[ln];
           }
         }
         if (deep) launch_mbxd(a, rows, o.k, o.stride, v.stream());
@@ -1002,9 +1090,12 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       SepArgs a{};
       a.in = v.ptr(o.in[0]);
       a.out = v.ptr(o.out);
-      a.wd = v.wt(o.w2_off);
+      a.wd = c->wpar_off[oi] >= 0 ? (const float*)(c->d_wsplit + c->wpar_off[oi]) : v.wt(o.w2_off);    // (fp16 pieces: pre-scaled taps)
       a.wsplit = c->d_wsplit + c->wsplit_off[oi];
-      a.wparts = c->pw_parts;
+      a.wparts = c->wscheme[oi];
+      a.wunscale = c->wunscale[oi];
+      a.oor = c->d_oor;
+      if (a.wparts == UDA_SPLIT_F16X2) c->oor_armed = true;
       a.bias = v.wt(o.bias_off);
       a.bn_scale = v.wt(o.bn_scale_off);
       a.bn_shift = v.wt(o.bn_shift_off);
@@ -1100,13 +1191,15 @@ static int run_sep_group(uda_ctx* c, const ChunkView& v, int oi, int n) {
       if (k != j && (c->ops[oi + k].out == o.in[0] || c->ops[oi + k].out == o.out)) return -1;    // not independent
     lv[j].in = v.ptr(o.in[0]);
     lv[j].out = v.ptr(o.out);
-    lv[j].wd = v.wt(o.w2_off);
+    lv[j].wd = c->wpar_off[oi + j] >= 0 ? (const float*)(c->d_wsplit + c->wpar_off[oi + j]) : v.wt(o.w2_off);
     lv[j].wsplit = c->d_wsplit + c->wsplit_off[oi + j];
     lv[j].bias = v.wt(o.bias_off);
     lv[j].bn_scale = v.wt(o.bn_scale_off);
     lv[j].bn_shift = v.wt(o.bn_shift_off);
     lv[j].mask = v.mask(o.drop_site);
     lv[j].H = ob.H; lv[j].W = ob.W;
+    lv[j].wunscale = c->wunscale[oi + j];
+    if (c->wscheme[oi + j] != c->wscheme[oi]) return -1;
   }
   // The grouped ops run concurrently inside one grid: no op's OUTPUT byte range may touch another op's input or output
   // (the planner keeps every buffer of such a run alive to its end; this is the executor's own check of that promise).
@@ -1131,7 +1224,10 @@ static int run_sep_group(uda_ctx* c, const ChunkView& v, int oi, int n) {
   a.C = ib0.C; a.Cout = ob0.C;
   a.in_div = v.div(ib0, ob0);
   a.act = o0.act;
-  a.wparts = c->pw_parts;
+  a.wparts = c->wscheme[oi];
+  a.wunscale = c->wunscale[oi];
+  a.oor = c->d_oor;
+  if (a.wparts == UDA_SPLIT_F16X2) c->oor_armed = true;
   launch_sep_multi(a, lv, n, v.rows(ob0), v.stream());
   return 0;
 }
@@ -1177,40 +1273,36 @@ static int run_network(uda_ctx* c, int post_mode = 0, bool chunk_post = false) {
     ChunkView v{c, i0, (n - i0 < m.chunk_images) ? n - i0 : m.chunk_images};
     v.lane = ci % lanes;
     for (int oi = 0; oi < (int)c->ops.size(); ++oi) {
-      // experiment (UDA_MALL_BLOCKS in the planner + UDA_MALL_IMAGES here): the ops of one backbone block on a few images
-      // at a time, so that the projection reads the expanded depthwise output back out of the Infinity Cache
-      static const int mall_images = getenv("UDA_MALL_IMAGES") ? atoi(getenv("UDA_MALL_IMAGES")) : 0;
-      if (mall_images > 0 && c->ops[oi].reserved0 != 0) {
-        int oe = oi;
-        while (oe < (int)c->ops.size() && c->ops[oe].reserved0 == c->ops[oi].reserved0) ++oe;
-        for (int j = 0; j < v.nc; j += mall_images) {
-          ChunkView sv = v;
-          sv.sub0 = j;
-          sv.nc = v.nc - j < mall_images ? v.nc - j : mall_images;
-          for (int ok = oi; ok < oe; ++ok) {
-            const int rc = run_op(c, sv, ok);
-            if (rc) return rc;
-          }
-        }
-        oi = oe - 1;
-        continue;
-      }
       const int grp = c->ops[oi].launch_group;
       if (grp > 1) {
         const int rg = run_sep_group(c, v, oi, grp);
         if (rg > 0) return rg;
-        if (rg == 0) { oi += grp - 1; continue; }
+        if (rg == 0) {
+          const hipError_t le = hipGetLastError();
+          if (le != hipSuccess)
+            return fail(c, "ops %d..%d (head layer, one launch for %d pyramid levels): launch failed: %s", oi, oi + grp - 1, grp, hipGetErrorString(le));
+          oi += grp - 1;
+          continue;
+        }
       }
       const int rc = run_op(c, v, oi);
       if (rc) return rc;
-      static const bool check_each = getenv("UDA_CHECK_LAUNCH") != nullptr;      // debug: name the op whose launch was refused
-      if (check_each) {
-        const hipError_t le = hipGetLastError();
-        if (le != hipSuccess) {
-          const uda_op_t& o = c->ops[oi];
-          return fail(c, "op %d (kind %d, k %d, stride %d, in C %d, out C %d): launch failed: %s", oi, o.kind, o.k, o.stride,
-                      c->bufs[o.in[0]].C, c->bufs[o.out].C, hipGetErrorString(le));
-        }
+      // debugging aid (UDA_SYNC_EACH=1): wait for every op and name it on stderr before the next one is queued, so that a
+      // device fault is attributed to the op that raised it
+      static const bool sync_each = getenv("UDA_SYNC_EACH") != nullptr;
+      if (sync_each) {
+        const uda_op_t& o = c->ops[oi];
+        fprintf(stderr, "[uda] op %d kind %d k %d s %d C %d -> %d ... ", oi, o.kind, o.k, o.stride, c->bufs[o.in[0]].C, c->bufs[o.out].C);
+        fflush(stderr);
+        const hipError_t se = hipStreamSynchronize(v.stream());
+        fprintf(stderr, "%s\n", hipGetErrorString(se));
+      }
+      // a refused launch (LDS over budget, bad grid) is named with its op: the query is host-only and costs nothing
+      const hipError_t le = hipGetLastError();
+      if (le != hipSuccess) {
+        const uda_op_t& o = c->ops[oi];
+        return fail(c, "op %d (kind %d, k %d, stride %d, in C %d, out C %d): launch failed: %s", oi, o.kind, o.k, o.stride,
+                    c->bufs[o.in[0]].C, c->bufs[o.out].C, hipGetErrorString(le));
       }
     }
     c->last_chunk_i0 = i0;
@@ -1463,9 +1555,28 @@ static int run_post(uda_ctx* c, int n, int post_mode) {
   return 0;
 }
 
+// fp16-piece contractions (UDA_SPLIT_F16X2): an activation above 65504 cannot be split and its products are infinite.
+// Every kernel that splits operands reports that through one flag word; every reader of a run's results comes through
+// here first and fails loudly instead of returning them.
+static int check_split_range(uda_ctx* c) {
+  if (!c->oor_armed) return 0;
+  c->oor_armed = false;
+  HIPC(c, hipStreamSynchronize(c->stream));
+  unsigned f = 0;
+  HIPC(c, hipMemcpy(&f, c->d_oor, sizeof(unsigned), hipMemcpyDeviceToHost));
+  if (f) {
+    hipMemset(c->d_oor, 0, sizeof(unsigned));
+    return fail(c, "an activation above 65504 reached a 1x1 contraction that splits its operands into fp16 pieces "
+                   "(UDA_PW_SCHEME=f16x2): the results of this run are invalid.  Re-create the handle with "
+                   "UDA_PW_SCHEME=bf16x3 (three bf16 pieces: float32 exponent range)");
+  }
+  return 0;
+}
+
 // Every reader of the post-process outputs comes through here: images whose score prefix turned out not to be
 // sufficient (flag written by prefix_check_kernel) are redone on the full candidate set before anything is read.
 static int finish_post(uda_ctx* c) {
+  if (int rc = check_split_range(c)) return rc;
   if (c->coop_used) {        // a barrier of the cooperative NMS that timed out leaves garbage: fail loudly
     c->coop_used = false;
     HIPC(c, hipStreamSynchronize(c->stream));
@@ -1703,18 +1814,20 @@ extern "C" int uda_calibrate_class(uda_ctx_t* c, int32_t mode, int32_t n_tables,
 // CRC-32C (Castagnoli, reflected polynomial 0x82F63B78), slicing-by-8 on the host: the per-tensor checksum of TensorFlow
 // checkpoint bundles (ckpt_reader.py verifies every tensor it restores; a pure-Python table CRC manages ~1 MB/s).
 extern "C" uint32_t uda_crc32c(const void* data, uint64_t n, uint32_t crc) {
-  static uint32_t T[8][256];
-  static bool ready = false;
-  if (!ready) {
-    for (uint32_t i = 0; i < 256; ++i) {
-      uint32_t c = i;
-      for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
-      T[0][i] = c;
+  struct Tables {
+    uint32_t t[8][256];
+    Tables() {
+      for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+        t[0][i] = c;
+      }
+      for (uint32_t i = 0; i < 256; ++i)
+        for (int k = 1; k < 8; ++k) t[k][i] = (t[k - 1][i] >> 8) ^ t[0][t[k - 1][i] & 0xFFu];
     }
-    for (uint32_t i = 0; i < 256; ++i)
-      for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xFFu];
-    ready = true;
-  }
+  };
+  static const Tables tables;          // function-local static: initialised once, thread-safe (C++11) - ctypes releases the GIL
+  const uint32_t (*T)[256] = tables.t;
   const uint8_t* p = (const uint8_t*)data;
   crc = ~crc;
   while (n >= 8) {
@@ -1745,6 +1858,7 @@ extern "C" int uda_get_head_outputs(uda_ctx_t* c, int32_t level, float* cls, flo
   if (level < 0 || level >= c->model.num_levels) return fail(c, "get_head_outputs: bad level %d", level);
   HIPC(c, hipSetDevice(c->device));
   HIPC(c, hipStreamSynchronize(c->stream));
+  if (int rc = check_split_range(c)) return rc;
   const uda_model_t& m = c->model;
   const size_t hw = (size_t)m.level_h[level] * m.level_w[level];
   const int n = c->n_images;
@@ -2007,7 +2121,8 @@ extern "C" int uda_debug_pw(int32_t device, const float* in, const float* w, con
                             int32_t terms, int32_t reps, float* out, float* avg_ms) {
   if (!in || !w || !out || rows < 1 || in_div < 1 || rows % in_div || hw < 1 || cin < 4 || cin % 4 || cout < 1)
     return fail(nullptr, "uda_debug_pw: bad argument");
-  if (terms != 0 && terms != 3 && terms != 6) return fail(nullptr, "uda_debug_pw: terms must be 0 (f32 MFMA), 3 or 6");
+  if (terms != 0 && terms != 3 && terms != 6 && terms != 16)
+    return fail(nullptr, "uda_debug_pw: terms must be 0 (f32 MFMA), 3 (bf16 x2), 6 (bf16 x3) or 16 (fp16 x2)");
   HIPC(nullptr, hipSetDevice(device));
   const size_t rows_in = rows / in_div;
   std::vector<void*> owned;
@@ -2034,15 +2149,22 @@ extern "C" int uda_debug_pw(int32_t device, const float* in, const float* w, con
   a.out = d_out;
   a.HW = hw; a.Cin = cin; a.Cout = cout; a.in_div = in_div; a.res_div = 1; a.se_div = in_div; a.act = act;
   uint16_t* d_ws = nullptr;
+  unsigned* d_oor = nullptr;
   if (terms) {
-    const int parts = terms == 6 ? 3 : 2;
-    std::vector<uint16_t> packed(pwb_packed_elems(cin, cout, parts));
-    pwb_pack_weights(w, cin, cout, parts, packed.data());
+    const int scheme = terms == 6 ? UDA_SPLIT_BF16X3 : (terms == 16 ? UDA_SPLIT_F16X2 : UDA_SPLIT_BF16X2);
+    const float scale = scheme == UDA_SPLIT_F16X2 ? split_weight_scale(w, (size_t)cin * cout) : 1.0f;
+    std::vector<uint16_t> packed(pwb_packed_elems(cin, cout, scheme));
+    pwb_pack_weights(w, cin, cout, scheme, packed.data(), scale);
     HIPC(nullptr, hipMalloc((void**)&d_ws, packed.size() * sizeof(uint16_t)));
     owned.push_back(d_ws);
     HIPC(nullptr, hipMemcpy(d_ws, packed.data(), packed.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIPC(nullptr, hipMalloc((void**)&d_oor, sizeof(unsigned)));
+    owned.push_back(d_oor);
+    HIPC(nullptr, hipMemset(d_oor, 0, sizeof(unsigned)));
     a.wsplit = d_ws;
-    a.wparts = parts;
+    a.wparts = scheme;
+    a.wunscale = 1.0f / scale;
+    a.oor = d_oor;
   }
   hipStream_t st;
   HIPC(nullptr, hipStreamCreate(&st));
@@ -2060,11 +2182,14 @@ extern "C" int uda_debug_pw(int32_t device, const float* in, const float* w, con
   hipEventElapsedTime(&ms, e0, e1);
   if (avg_ms) *avg_ms = reps > 0 ? ms / reps : 0.f;
   if (err == hipSuccess) err = hipMemcpy(out, d_out, (size_t)rows * hw * cout * sizeof(float), hipMemcpyDeviceToHost);
+  unsigned oor = 0;
+  if (err == hipSuccess && d_oor) err = hipMemcpy(&oor, d_oor, sizeof(unsigned), hipMemcpyDeviceToHost);
   hipEventDestroy(e0);
   hipEventDestroy(e1);
   hipStreamDestroy(st);
   for (void* p : owned) hipFree(p);
   if (err != hipSuccess) return fail(nullptr, "uda_debug_pw: %s", hipGetErrorString(err));
+  if (oor) return fail(nullptr, "uda_debug_pw: an input above 65504 cannot be split into fp16 pieces (terms = 16)");
   return 0;
 }
 

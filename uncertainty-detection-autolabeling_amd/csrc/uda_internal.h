@@ -49,6 +49,16 @@ __device__ __forceinline__ void philox_normal2(uint64_t seed, uint32_t i0, uint3
 }
 #endif
 
+// ---------------------------------------------------------------- split-precision schemes of the 1x1 contractions
+// (`wparts` of the argument blocks below = PARTS of the kernels; see mfma_common.h)
+enum {
+  UDA_SPLIT_NONE = 0,     // exact f32-input MFMA kernels (kernels_conv.hip)
+  UDA_SPLIT_BF16X2 = 2,   // two bf16 pieces per operand, three cross terms (~2^-17 per product)
+  UDA_SPLIT_BF16X3 = 3,   // three bf16 pieces, six cross terms (~2^-24)
+  UDA_SPLIT_F16X2 = 4,    // two fp16 pieces, three cross terms (~2^-22; operands must stay below 65504)
+};
+inline int uda_split_pieces(int scheme) { return scheme == UDA_SPLIT_BF16X3 ? 3 : 2; }
+
 // ---------------------------------------------------------------- kernel argument blocks
 struct StemArgs {
   const float* in;    // [rows, H, W, 3]
@@ -76,12 +86,17 @@ struct PwArgs {
   int res_div;
   int se_div;            // 1: one gate per output row (per sample); in_div: one per input row
   int act;
-  const void* wsplit;    // split-bf16 weights in MFMA fragment order (kernels_pwb.hip) or null
-  int wparts;            // bf16 pieces per value: 2 (three cross terms) or 3 (six: float32-equivalent)
+  const void* wsplit;    // split weights in MFMA fragment order (kernels_pwb.hip) or null
+  int wparts;            // split scheme of wsplit (UDA_SPLIT_*)
+  float wunscale;        // the packed weights are the kernel times 1 / wunscale (a power of two; 1 unless fp16 pieces)
+  unsigned* oor;         // fp16 pieces: word that receives bit 0 when an operand above 65504 was split (or null)
 };
 void launch_pwb(const PwArgs& a, int rows, hipStream_t s);
-size_t pwb_packed_elems(int K, int N, int parts);
-void pwb_pack_weights(const float* w, int K, int N, int parts, uint16_t* out);
+size_t pwb_packed_elems(int K, int N, int scheme);
+// scale: every weight is multiplied by it before the split (a power of two; fp16 pieces only)
+void pwb_pack_weights(const float* w, int K, int N, int scheme, uint16_t* out, float scale = 1.0f);
+// power of two that brings the largest magnitude of w[0 .. n) into [2^13, 2^14) (1 for an all-zero tensor)
+float split_weight_scale(const float* w, size_t n);
 
 struct SepArgs {          // fused depthwise 3x3 (stride 1, SAME) + 1x1 (kernels_pwb.hip)
   const float* in;        // [rows / in_div, H, W, C]
@@ -95,7 +110,9 @@ struct SepArgs {          // fused depthwise 3x3 (stride 1, SAME) + 1x1 (kernels
   int H, W, C, Cout;
   int in_div;
   int act;
-  int wparts;
+  int wparts;             // split scheme (UDA_SPLIT_*)
+  float wunscale;         // see PwArgs
+  unsigned* oor;
 };
 void launch_sep(const SepArgs& a, int rows, hipStream_t s);
 // Several independent separable convs of ONE shape class (same C, Cout, activation, sample-axis relation, row count) in one
@@ -106,6 +123,7 @@ struct SepLevel {
   const float* in; float* out; const float* wd; const void* wsplit;
   const float* bias; const float* bn_scale; const float* bn_shift; const float* mask;
   int H, W;
+  float wunscale;
 };
 struct SepMulti {
   SepArgs one;                         // the single problem (n_lv == 0) / the fields shared by all problems
@@ -151,8 +169,9 @@ struct MbxArgs {
   int in_div;
   int n_tiles;
   unsigned long long* stamps;  // diagnostic phase stamps (UDA_MBX_STAMPS); null in production
-  const void* wsplit;     // expand kernel * BN scale (+ BN shift row) as split-bf16 fragments (kernels_pwb.hip) or null
-  int wparts;             // bf16 pieces per operand in wsplit: 2 (three cross terms) or 3 (six: UDA_PW_TERMS=6)
+  const void* wsplit;     // expand kernel * BN scale (+ BN shift row) as split fragments (kernels_pwb.hip) or null
+  int wparts;             // split scheme of wsplit (UDA_SPLIT_*)
+  unsigned* oor;          // fp16 pieces: out-of-range flag word (see PwArgs) or null
   const float* wpar;      // per-slab depthwise taps + BN scale / shift block (mbx_pack_params) or null
   // fused projection of the previous block (mbxb_kernel FUSE0): in = D [rows / in_div, H, W, c0]
   const float* gate;      // [rows / g_div, c0] per-sample gate on D (SE gate x deferred dropout), null = not fused
@@ -178,10 +197,12 @@ int mbxd_tiles(int Ho, int Wo, int k, int stride = 1);
 bool mbxd_wide(int Ho, int Wo, int k, int stride);     // 20-column tiles for this map (mirror: plan.mbx_tile)
 bool mbxb_supported(int Cin, int Cmid, int k, int stride);
 int mbxb_tiles(int Ho, int Wo, int k, int stride);
-size_t mbxb_packed_elems(int Cin, int Cmid, int parts = 2);
-size_t mbxb_w0frag_elems(int gate_rows, int parts);
-void launch_w0gate(const float* gate, const float* w0t, int c0, int gate_rows, int parts, uint4* out, hipStream_t s);
-void mbxb_pack_weights(const float* we, const float* sc0, const float* sh0, int Cin, int Cmid, uint16_t* out, bool perm16 = false, int parts = 2);
+size_t mbxb_packed_elems(int Cin, int Cmid, int scheme = UDA_SPLIT_BF16X2);
+size_t mbxb_w0frag_elems(int gate_rows, int scheme);
+void launch_w0gate(const float* gate, const float* w0t, int c0, int gate_rows, int scheme, uint4* out, unsigned* oor, hipStream_t s);
+// stats (optional, 2 floats): largest magnitude and rms of the matrix that was packed (expand kernel x BN scale, shift row)
+void mbxb_pack_weights(const float* we, const float* sc0, const float* sh0, int Cin, int Cmid, uint16_t* out, bool perm16 = false,
+                       int scheme = UDA_SPLIT_BF16X2, float* stats = nullptr);
 void launch_mbx(const MbxArgs& a, int rows, int k, int stride, hipStream_t s);
 int mbx_tiles(int Ho, int Wo, int k, int stride);
 bool mbx_supported(int Cin, int Cmid, int k, int stride);

@@ -49,6 +49,30 @@ def dw_tiles(C, Ho, Wo, k, stride):
     return -(-Ho // dw_rows(k, stride)) * dw_tiles_x(C, Wo, k, stride)
 
 
+PW_SCHEMES = ("f16x2", "bf16x3", "bf16x2", "f32")
+PW_SCHEME_DEFAULT = "f16x2"
+
+
+def pw_scheme():
+    """Split scheme of the 1x1 contractions (mirror of parse_pw_scheme in csrc/uda_api.hip): UDA_PW_SCHEME =
+    f16x2 (two fp16 pieces, three cross terms, ~2^-22 per product: the default) | bf16x3 (three bf16 pieces, six terms,
+    ~2^-24) | bf16x2 (two bf16 pieces, three terms, ~2^-17) | f32 (exact f32-input MFMA kernels, unfused);
+    the older UDA_PW_TERMS = 6 | 3 | 0 selects the last three when UDA_PW_SCHEME is not set."""
+    import os
+    v = os.environ.get("UDA_PW_SCHEME")
+    if v:
+        if v not in PW_SCHEMES:
+            raise ValueError("UDA_PW_SCHEME=%r: expected one of %s" % (v, ", ".join(PW_SCHEMES)))
+        return v
+    t = os.environ.get("UDA_PW_TERMS")
+    if t is None or t == "":
+        return PW_SCHEME_DEFAULT
+    t = int(t)
+    if t not in (0, 3, 6):
+        raise ValueError("UDA_PW_TERMS=%r: expected 6, 3 or 0" % (t,))
+    return {0: "f32", 3: "bf16x2", 6: "bf16x3"}[t]
+
+
 def mbx_deep(cin):
     """Cin > 48: the deep variant of the fused kernel (mbxd_kernel in csrc/kernels_pwb.hip)."""
     return cin > 48
@@ -67,7 +91,7 @@ def mbx_tile(k, stride, cin=16, Ho=None, Wo=None):
             return normal
         return (7, 8) if k == 3 else (4, 10)
     import os
-    if int(os.environ.get("UDA_PW_TERMS", "3")) == 0 or not int(os.environ.get("UDA_MBX_BF16", "1")):
+    if pw_scheme() == "f32" or not int(os.environ.get("UDA_MBX_BF16", "1")):
         return (8, 16) if stride == 1 else ((4, 16) if k == 3 else (4, 8))      # f32-MFMA fallback kernel (mbx_cfg)
     s2_k3 = (7, 8) if os.environ.get("UDA_MBXB_S2_TILE", "78") == "78" else (4, 12)     # (A/B builds: -DUDA_MBXB_S2_TILE=412)
     return ((12, 16) if k == 3 else (8, 16)) if stride == 1 else (s2_k3 if k == 3 else (4, 10))
@@ -82,13 +106,13 @@ def mbx_supported(cin, cmid, k, stride):
     import os
     if not (int(os.environ.get("UDA_FUSE_MBX", "1")) and cin % 8 == 0 and cmid % 4 == 0 and k in (3, 5)):
         return False
-    if int(os.environ.get("UDA_PW_TERMS", "3")) == 6 and not int(os.environ.get("UDA_FUSE_MBX6", "1")):
+    if pw_scheme() == "bf16x3" and not int(os.environ.get("UDA_FUSE_MBX6", "1")):
         # six cross terms = float32-equivalent products EVERYWHERE.  The fused MBConv kernels have three-piece variants
         # (mbxb_kernel / mbxd_kernel<..., PARTS = 3>, csrc/kernels_pwb.hip) and stay fused; UDA_FUSE_MBX6=0 restores the
         # round-2 behaviour (stand-alone six-term 1x1 convs + depthwise) for A/B runs
         return False
     if mbx_deep(cin):       # mirror of mbxd_supported: 16-deep k-steps of Cin + 1 in {6, 8, 13, 14}, split-bf16 path on
-        return (int(os.environ.get("UDA_FUSE_MBXD", "1")) and int(os.environ.get("UDA_PW_TERMS", "3")) != 0
+        return (int(os.environ.get("UDA_FUSE_MBXD", "1")) and pw_scheme() != "f32"
                 and int(os.environ.get("UDA_MBX_BF16", "1"))
                 and (stride == 1 or (stride == 2 and int(os.environ.get("UDA_FUSE_MBXD_S2", "1"))))
                 and (cin + 1 + 15) // 16 in (6, 8, 13, 14)
@@ -126,8 +150,8 @@ class Plan:
         self.buffer_names = {}
         import os
         self.defer_dropout = bool(int(os.environ.get("UDA_DEFER_DROPOUT", "1")))
-        self.fuse_sep = bool(int(os.environ.get("UDA_FUSE_SEP", "1"))) and int(os.environ.get("UDA_PW_TERMS", "3")) != 0
-        self.fuse_proj = (bool(int(os.environ.get("UDA_FUSE_PROJ", "1"))) and int(os.environ.get("UDA_PW_TERMS", "3")) != 0
+        self.fuse_sep = bool(int(os.environ.get("UDA_FUSE_SEP", "1"))) and pw_scheme() != "f32"
+        self.fuse_proj = (bool(int(os.environ.get("UDA_FUSE_PROJ", "1"))) and pw_scheme() != "f32"
                           and bool(int(os.environ.get("UDA_MBX_BF16", "1"))) and bool(int(os.environ.get("UDA_FUSE_MBX", "1"))))
         if self.post_only:
             self._post_only_layout()
@@ -310,14 +334,7 @@ class Plan:
         reductions = []
         red_ids = set(arch.reduction_block_ids(blocks))
         pending_proj = None      # (gate buffer, projection kernel, BN name) of a block whose 1x1 projection the next block absorbs
-        # experiment (UDA_MALL_BLOCKS="first-last", executor: UDA_MALL_IMAGES): the ops of these blocks carry a sub-chunk group
-        # id; the executor runs each such block (fused front half -> SE -> projection) on a few images at a time, so that the
-        # 6x-expanded depthwise output is read back by the projection while the Infinity Cache still holds it
-        import os
-        mall = os.environ.get("UDA_MALL_BLOCKS", "")
-        mall_lo, mall_hi = ([int(v) for v in mall.split("-")] if mall else (1, 0))
         for i, b in enumerate(blocks):
-            first_op = len(self.ops)
             p = "%s/blocks_%d/" % (bb, i)
             bn_names = [p + "tpu_batch_normalization" + ("" if j == 0 else "_%d" % j) for j in range(3)]
             inp, nb = x, 0
@@ -390,9 +407,6 @@ class Plan:
                 continue
             x = self._pw(x, b["cout"], proj, "blocks_%d/out" % i, bn=bn_names[nb], se=gate,
                          residual=inp if b["skip"] else -1)
-            if mall_lo <= i <= mall_hi:
-                for o in self.ops[first_op:]:
-                    o["sub_group"] = i + 1
             if i in red_ids:
                 reductions.append(x)
         lo, hi = cfg["min_level"], cfg["max_level"]
@@ -645,7 +659,7 @@ class Plan:
                       "bn_scale_off", "bn_shift_off", "se_w1_off", "se_b1_off", "se_w2_off", "se_b2_off",
                       "se_mid", "drop_site", "drop_site2", "w2_off", "bn2_scale_off", "bn2_shift_off", "launch_group"):
                 setattr(c, k, int(o[k]))
-            c.reserved0 = int(o.get("sub_group", 0))
+            c.reserved0 = 0
         sites = (capi.DropSite * max(1, len(self.sites)))()
         for i, (_, ch, r) in enumerate(self.sites):
             sites[i].channels, sites[i].rate = ch, np.float32(r)
