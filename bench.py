@@ -240,12 +240,14 @@ def main():
     def step(upload=False):
         if upload:
             drv.stage_images(images)
-        drv.run_resident(sync=True)
-        det = drv._collect(a.batch)
         if dist is not None:
-            from uda_amd.dist import all_gather_detections
-            det = all_gather_detections(det, device=tdev, counts=[a.batch] * world)
-        return det
+            # the detections stay in the handle's device buffer until RCCL has gathered them; ONE download of the gathered
+            # records (dist.all_gather_detections_device)
+            from uda_amd.dist import all_gather_detections_device
+            drv.run_resident(sync=False)
+            return all_gather_detections_device(drv, a.batch, [a.batch] * world, tdev)
+        drv.run_resident(sync=True)
+        return drv._collect(a.batch)
 
     # warm-up; the last warm-up step also ranks the kernel kinds by device time.  The very first call of a handle is
     # set-up (lazy allocations, and the global NMS probes whether a score prefix suffices for this score distribution,

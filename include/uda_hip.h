@@ -212,6 +212,15 @@ int64_t uda_nms_coop_not_launched(const uda_ctx_t* ctx);
 int uda_get_detections(uda_ctx_t* ctx, float* boxes, float* scores, float* classes,
                        int32_t* valid, float* logits);
 int uda_detection_cols(const uda_ctx_t* ctx, int32_t post_mode, int32_t* box_cols, int32_t* cls_cols);
+/* The detections of the last post-process as ONE device-resident float32 buffer [rows, max_output_size, cols], a row per
+ * (image, detection): boxes (box_cols) | score | classes (cls_cols) | logits (num_classes, when with_logits and the global
+ * post-process ran) | valid_len - the record of dist.pack_detections.  rows >= the images of the last post-process; the
+ * rows beyond them are zero (padding of a ragged shard to the collective's common size).  The multi-GPU layer all-gathers
+ * straight out of this buffer (RCCL): the detections do not cross PCIe before they have been collected (the
+ * reference has no inference collective - infer_lib.py:337-343 returns host arrays of one process).  The buffer belongs to
+ * the handle and is valid until its next call; the handle's stream has been synchronised when the call returns. */
+int uda_detections_device(uda_ctx_t* ctx, int32_t rows, int32_t with_logits, void** dev_ptr, int32_t* cols);
+
 /* What every caller of serve() computes next from `logits` (validate_model.py:159-166,
  * infer_model.py:585-600, utils_class.py:36-41), on the device: probs [n, M, num_classes] = stable softmax of the
  * selected rows' mean logits, entropy [n, M] = -sum p * log2(max(p, 1e-7)).  Global post-process only. */

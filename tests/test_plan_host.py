@@ -276,3 +276,29 @@ def test_reference_block_kats_structure():
     # a plan over a custom table lowers (a stride-1 stage and four stride-2 stages: the three FPN inputs are blocks 2..4)
     pl = plan_mod.Plan(cfg, W.init_weights(cfg, 0))
     assert pl.level_hw[0] == (16, 16) and len(pl.level_hw) == 5
+
+
+def test_pw_scheme_switches(monkeypatch):
+    """UDA_PW_SCHEME names the split scheme of the 1x1 contractions (default: two fp16 pieces); the older UDA_PW_TERMS is
+    honoured when the newer switch is silent; anything else is refused (mirror of parse_pw_scheme in csrc/uda_api.hip)."""
+    from uda_amd import plan
+    monkeypatch.delenv("UDA_PW_SCHEME", raising=False)
+    monkeypatch.delenv("UDA_PW_TERMS", raising=False)
+    assert plan.pw_scheme() == "f16x2" == plan.PW_SCHEME_DEFAULT
+    for terms, want in (("6", "bf16x3"), ("3", "bf16x2"), ("0", "f32")):
+        monkeypatch.setenv("UDA_PW_TERMS", terms)
+        assert plan.pw_scheme() == want
+    monkeypatch.setenv("UDA_PW_SCHEME", "bf16x3")          # the newer switch wins
+    assert plan.pw_scheme() == "bf16x3"
+    monkeypatch.setenv("UDA_PW_SCHEME", "fp8")
+    with pytest.raises(ValueError):
+        plan.pw_scheme()
+    monkeypatch.delenv("UDA_PW_SCHEME")
+    monkeypatch.setenv("UDA_PW_TERMS", "4")
+    with pytest.raises(ValueError):
+        plan.pw_scheme()
+    # the exact-f32 scheme switches the fusions off in the planner, the split schemes keep them
+    monkeypatch.setenv("UDA_PW_TERMS", "0")
+    assert not plan.mbx_supported(192, 1152, 5, 1)
+    monkeypatch.delenv("UDA_PW_TERMS")
+    assert plan.mbx_supported(192, 1152, 5, 1)

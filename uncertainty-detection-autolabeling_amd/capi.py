@@ -90,6 +90,7 @@ _SIGNATURES = {
     "uda_nms_coop_not_launched": (C.c_int64, [_P]),
     "uda_get_detections": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "uda_detection_cols": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "uda_detections_device": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int32)]),
     "uda_get_class_probs": (C.c_int, [_P, _P, _P]),
     "uda_calibrate_box": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "uda_calibrate_class": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_uint64, _P, _P, _P]),

@@ -2537,6 +2537,37 @@ void launch_probs(const float* logits, float* probs, float* entropy, int rows, i
   hipLaunchKernelGGL(probs_kernel, dim3((rows + 127) / 128), dim3(128), 0, s, logits, probs, entropy, rows, C);
 }
 
+// ------------------------------------------------------------------------------------ packed detection records
+// One float32 row per (image, detection): [boxes (bc) | score | classes (cc) | logits (C, optional) | valid_len] - the record
+// the multi-GPU layer gathers (dist.pack_detections builds the same row on the host).  Rows of images >= n are zero: padding
+// of a ragged shard up to the collective's common size.  The gather then reads this buffer in place: the detections never
+// cross PCIe before they have been collected.
+__global__ __launch_bounds__(256) void pack_det_kernel(PackDetArgs a) {
+  const int64_t total = (int64_t)a.rows_out * a.M * a.cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % a.cols);
+    const int64_t r = i / a.cols;               // image * M + detection
+    const int img = (int)(r / a.M);
+    float v = 0.f;
+    if (img < a.n) {
+      if (col < a.bc) v = a.boxes[r * a.bc + col];
+      else if (col == a.bc) v = a.scores[r];
+      else if (col < a.bc + 1 + a.cc) v = a.classes[r * a.cc + (col - a.bc - 1)];
+      else if (col < a.bc + 1 + a.cc + a.C) v = a.logits[r * a.C + (col - a.bc - 1 - a.cc)];
+      else v = (float)a.valid[img];
+    }
+    a.out[i] = v;
+  }
+}
+
+void launch_pack_det(const PackDetArgs& a, hipStream_t s) {
+  const int64_t total = (int64_t)a.rows_out * a.M * a.cols;
+  if (total <= 0) return;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_det_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+}
+
 // ------------------------------------------------------------------------------------ box-uncertainty calibration
 // CalibrateBoxUncert.calibrate_boxuncert (utils_box.py:404-524) on the selected rows: temperature scaling
 // (uncert / T) or isotonic regression tables (sklearn IsotonicRegression(out_of_bounds="clip").predict = linear

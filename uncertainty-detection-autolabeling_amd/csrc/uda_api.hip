@@ -148,6 +148,7 @@ struct uda_ctx {
   // outputs
   float *d_oboxes = nullptr, *d_oscores = nullptr, *d_oclasses = nullptr, *d_ologits = nullptr;
   float *d_oprobs = nullptr, *d_oentropy = nullptr;   // stable softmax / entropy of the selected rows (lazy)
+  float* d_opacked = nullptr;                        // packed detection records for the multi-GPU gather (lazy, uda_detections_device)
   int32_t* d_ovalid = nullptr;
   int last_post_mode = 0;
   int last_n = 0;
@@ -271,7 +272,8 @@ extern "C" void uda_destroy(uda_ctx_t* c) {
   void* ptrs[] = {c->d_weights, c->d_wsplit, c->d_arena, c->d_anchors, c->d_images, c->d_scales, c->d_masks,
                   c->d_site_off, c->d_site_ch, c->d_site_rate, c->d_cboxes, c->d_cscores, c->d_clogits,
                   c->d_cclasses, c->d_ucls, c->d_ual, c->d_uep, c->d_clsmean, c->d_cand_flat, c->d_merge_keys,
-                  c->d_oboxes, c->d_oscores, c->d_oclasses, c->d_ologits, c->d_ovalid, c->d_oprobs, c->d_oentropy};
+                  c->d_oboxes, c->d_oscores, c->d_oclasses, c->d_ologits, c->d_ovalid, c->d_oprobs, c->d_oentropy,
+                  c->d_opacked};
   for (void* p : ptrs)
     if (p) hipFree(p);
   free_prefix_ws(c->pfx);
@@ -1680,6 +1682,32 @@ extern "C" int uda_get_detections(uda_ctx_t* c, float* boxes, float* scores, flo
   if (valid) HIPC(c, hipMemcpy(valid, c->d_ovalid, n * sizeof(int32_t), hipMemcpyDeviceToHost));
   if (logits && c->last_post_mode == UDA_POST_GLOBAL)
     HIPC(c, hipMemcpy(logits, c->d_ologits, n * M * C * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int uda_detections_device(uda_ctx_t* c, int32_t rows, int32_t with_logits, void** dev_ptr, int32_t* cols) {
+  if (!c || !dev_ptr) return c ? fail(c, "detections_device: NULL argument") : 1;
+  const size_t n = c->last_n, M = c->model.max_output_size;
+  if (rows < (int32_t)n || rows > c->model.max_images)
+    return fail(c, "detections_device: rows %d outside [%d images of the last post-process, max_images %d]", rows, (int)n, c->model.max_images);
+  HIPC(c, hipSetDevice(c->device));
+  if (int rc = finish_post(c)) return rc;
+  const int bc = box_cols_of(c->model, c->last_post_mode), cc = cls_cols_of(c->model, c->last_post_mode);
+  const int C = (with_logits && c->last_post_mode == UDA_POST_GLOBAL) ? c->model.num_classes : 0;
+  const int nc = bc + 1 + cc + C + 1;
+  if (!c->d_opacked) {      // sized once for the widest record of this handle
+    const int widest = box_cols_of(c->model, UDA_POST_GLOBAL) + 1 + cls_cols_of(c->model, UDA_POST_GLOBAL) + c->model.num_classes + 1;
+    HIPC(c, dalloc(&c->d_opacked, (size_t)c->model.max_images * M * widest));
+  }
+  PackDetArgs a{};
+  a.boxes = c->d_oboxes; a.scores = c->d_oscores; a.classes = c->d_oclasses; a.logits = c->d_ologits; a.valid = c->d_ovalid;
+  a.out = c->d_opacked;
+  a.n = (int)n; a.rows_out = rows; a.M = (int)M; a.bc = bc; a.cc = cc; a.C = C; a.cols = nc;
+  launch_pack_det(a, c->stream);
+  HIPC(c, hipGetLastError());
+  HIPC(c, hipStreamSynchronize(c->stream));      // another stream (the process group's) reads the buffer next
+  *dev_ptr = c->d_opacked;
+  if (cols) *cols = nc;
   return 0;
 }
 

@@ -428,6 +428,13 @@ struct CalibArgs {
 };
 void launch_calib(const CalibArgs& a, hipStream_t s);
 void launch_probs(const float* logits, float* probs, float* entropy, int rows, int C, hipStream_t s);
+struct PackDetArgs {
+  const float *boxes, *scores, *classes, *logits;   // post-process outputs [n, M, bc] / [n, M] / [n, M, cc] / [n, M, C] (C = 0: no logits)
+  const int32_t* valid;                             // [n]
+  float* out;                                       // [rows_out, M, cols], cols = bc + 1 + cc + C + 1
+  int n, rows_out, M, bc, cc, C, cols;
+};
+void launch_pack_det(const PackDetArgs& a, hipStream_t s);
 
 struct ClsCalibArgs {
   const float* logits;    // [rows, C] mean logits of the selected rows

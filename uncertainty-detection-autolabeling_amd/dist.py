@@ -86,16 +86,74 @@ def all_gather_detections(det, device=None, group=None, counts=None):
     return unpack_detections(full, layout)
 
 
+_GATHER_BUF = {}     # (device, world, n_max, M, cols) -> the receive tensor of the device-resident gather, reused across steps
+
+
+def all_gather_detections_device(driver, n_local, counts, device, group=None, to_host=True):
+    """The same gather WITHOUT a host hop: the handle packs its detections into one device-resident record
+    buffer (`uda_detections_device`, padded with zero rows to the largest shard), RCCL all-gathers straight out of it into
+    a reusable tensor, and ONE device-to-host copy of the gathered records follows on the ranks that want them
+    (`to_host=False` returns the device tensor [world * n_max, M, cols] and the layout instead).  Before: download of the
+    local detections, re-upload of the packed copy, gather, download - three PCIe crossings and two synchronisations per
+    step for an 11 KB / image record that already sat in a device buffer."""
+    import torch
+    import torch.distributed as dist
+    dev = torch.device(device)
+    world = dist.get_world_size(group)
+    counts = [int(c) for c in counts]
+    if len(counts) != world or counts[dist.get_rank(group)] != int(n_local):
+        raise ValueError("counts %s do not describe this rank's %d images" % (counts, n_local))
+    n_max = max(counts)
+    if n_local > 0:
+        ptr, rows, layout = driver.detections_device(rows=n_max)
+        cols = layout["box"] + 1 + layout["cls"] + layout["logits"] + 1
+        t = torch.as_tensor(DevArray(ptr, (rows, driver.M, cols)), device=dev)
+    else:       # an empty shard (more ranks than images): zero records of the right shape
+        det = driver.empty_detections()
+        layout = dict(box=det[0].shape[-1], cls=1 if det[2].ndim == 2 else det[2].shape[-1], logits=det[4].shape[-1] if len(det) > 4 else 0)
+        cols = layout["box"] + 1 + layout["cls"] + layout["logits"] + 1
+        t = torch.zeros((n_max, driver.M, cols), dtype=torch.float32, device=dev)
+    key = (str(dev), world, n_max, driver.M, cols)
+    out = _GATHER_BUF.get(key)
+    if out is None:
+        out = _GATHER_BUF[key] = torch.empty((world, n_max, driver.M, cols), dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(out, t, group=group)
+    if not to_host:
+        return out.reshape(world * n_max, driver.M, cols), layout
+    host = out.cpu().numpy()             # the one download (synchronises the collective's stream)
+    full = host.reshape((world * n_max, driver.M, cols)) if all(c == n_max for c in counts) else \
+        np.concatenate([host[r, :c] for r, c in enumerate(counts)], axis=0)
+    return unpack_detections(full, layout)
+
+
+def gather_detections(driver, det_or_none, n_local, counts, device=None, group=None):
+    """One entry point for both process-group kinds: RCCL (`nccl`) gathers the handle's device-resident records
+    (`all_gather_detections_device`), a CPU group (`gloo`, tests) goes through host arrays (`all_gather_detections`).
+    det_or_none: the local detections already on the host, or None (they are then collected only on the host path)."""
+    import torch.distributed as dist
+    if dist.get_backend(group) == "nccl" and device is not None:
+        return all_gather_detections_device(driver, n_local, counts, device, group=group)
+    det = det_or_none
+    if det is None:
+        det = driver._collect(n_local) if n_local > 0 else driver.empty_detections()
+    return all_gather_detections(det, device=device, group=group, counts=counts)
+
+
 def serve_sharded(driver, images, rank, world, device=None, group=None):
     """Image-sharded serve: each rank runs the path on its contiguous shard, then one
     all-gather returns the full batch's detections on every rank."""
+    import torch.distributed as dist
     start, stop = shard_range(len(images), rank, world)
     driver.set_image_offset(start)      # same dropout masks as the unsharded batch
+    counts = [shard_range(len(images), r, world)[1] - shard_range(len(images), r, world)[0] for r in range(world)]
+    if dist.get_backend(group) == "nccl" and device is not None:      # detections stay on the device until they are gathered
+        if stop > start:
+            driver.serve_resident(images[start:stop])
+        return all_gather_detections_device(driver, stop - start, counts, device, group=group)
     if stop > start:
         det = driver.serve(images[start:stop])
     else:  # more ranks than images: this rank contributes an empty shard
         det = driver.empty_detections()
-    counts = [shard_range(len(images), r, world)[1] - shard_range(len(images), r, world)[0] for r in range(world)]
     return all_gather_detections(det, device=device, group=group, counts=counts)
 
 
@@ -203,7 +261,8 @@ def reshard_member_heads_device(member_drivers, post_driver, n_members, n_total,
         drv.synchronize()                       # the members' heads are complete before torch's stream reads them
     post_driver.synchronize()
     levels = len(post_driver.plan.level_hw)
-    ops, pending, keep = [], [], []
+    ops, pending, keep, recv_from = [], [], [], []
+    stage_off = 0
     for lvl in range(levels):
         for which in (0, 1):
             dst = _head_tensor(torch, post_driver, lvl, which, dev, rows_expected=n_members)   # [cap, M, per]
@@ -224,16 +283,37 @@ def reshard_member_heads_device(member_drivers, post_driver, n_members, n_total,
                     if r == rank:
                         continue
                     for m in (mm for mm in range(n_members) if member_owner(mm, world) == r):
-                        t = torch.empty((b - a, dst.shape[2]), dtype=torch.float32, device=dev)
-                        ops.append(dist.P2POp(dist.irecv, t, r, group=group))
-                        pending.append((dst, m, t))
+                        # (a sample slot of the aggregating buffer is a strided view - row pitch n_members x per - and RCCL
+                        # receives into contiguous memory: the receives land in ONE reusable staging tensor, carved in
+                        # posting order, and are scattered into their slots afterwards)
+                        k = (b - a) * dst.shape[2]
+                        pending.append((dst, m, stage_off, k))
+                        stage_off += k
+                        recv_from.append(r)
+                        ops.append("recv")
             keep.append((dst, srcs))
-    # every rank posts its operations in the same global order (level, head, peer, member): matching sends and receives
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
+    # every rank posts its operations in the same global order (level, head, peer, member): matching sends and receives.
+    # The sends of all (level, head) pairs were appended first per pair, the receives right behind them - keep that order.
+    stage = None
+    if pending:
+        key = (str(dev), "ensemble-stage")
+        stage = _GATHER_BUF.get(key)
+        if stage is None or stage.numel() < stage_off:
+            stage = _GATHER_BUF[key] = torch.empty((stage_off,), dtype=torch.float32, device=dev)
+    ordered = []
+    ri = 0
+    for op in ops:
+        if op == "recv":
+            dst, m, off, k = pending[ri]
+            ordered.append(dist.P2POp(dist.irecv, stage[off:off + k].view(b - a, dst.shape[2]), recv_from[ri], group=group))
+            ri += 1
+        else:
+            ordered.append(op)
+    if ordered:
+        for w in dist.batch_isend_irecv(ordered):
             w.wait()
-    for dst, m, t in pending:
-        dst[:b - a, m, :].copy_(t)
+    for dst, m, off, k in pending:
+        dst[:b - a, m, :].copy_(stage[off:off + k].view(b - a, dst.shape[2]))
     torch.cuda.synchronize(dev)                 # the aggregating handle's stream may read its buffers now
     post_driver.heads_written_externally(b - a)
     return b - a
@@ -277,8 +357,10 @@ def serve_ensemble_striped(member_drivers, post_driver, images, n_members, rank,
         sc = np.asarray(scales, np.float32)[a:b]
         if on_device:
             cls_lv, box_lv = post_driver.device_heads(b - a)      # resident: post-processed where the exchange left them
-        det = post_driver.postprocess(cls_lv, box_lv, sc, post_mode=post_mode)
+        det = post_driver.postprocess(cls_lv, box_lv, sc, post_mode=post_mode, collect=not on_device)
     else:
         det = post_driver.empty_detections()
     counts = [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
+    if on_device:       # the records are gathered where the post-process left them
+        return all_gather_detections_device(post_driver, b - a, counts, device, group=group)
     return all_gather_detections(det, device=device, group=group, counts=counts)

@@ -210,6 +210,22 @@ class ServingDriver:
             out.append(logits)
         return tuple(out)
 
+    def detections_device(self, rows=None, mode=None):
+        """The detections of the last run as ONE device-resident record buffer: (device address, rows, layout) with the
+        float32 buffer [rows, M, cols] laid out as `dist.pack_detections` does on the host.  rows >= the images of the last
+        run pads the tail with zeros (ragged shards); `dist.all_gather_detections_device` gathers straight out of it."""
+        mode = self._post_mode if mode is None else mode
+        n = self._n_last()
+        rows = n if rows is None else int(rows)
+        bc, cc = C.c_int32(), C.c_int32()
+        self._ck(self._lib.uda_detection_cols(self._h, mode, C.byref(bc), C.byref(cc)), "uda_detection_cols")
+        with_logits = bool(self.params["enable_softmax"] and mode == capi.POST_GLOBAL)
+        ptr, cols = C.c_void_p(), C.c_int32()
+        self._ck(self._lib.uda_detections_device(self._h, rows, int(with_logits), C.byref(ptr), C.byref(cols)), "uda_detections_device")
+        layout = dict(box=bc.value, cls=cc.value, logits=self.num_classes if with_logits else 0)
+        assert cols.value == layout["box"] + 1 + layout["cls"] + layout["logits"] + 1
+        return ptr.value, rows, layout
+
     def empty_detections(self):
         """A zero-image output tuple with the right trailing shapes (ragged multi-GPU shards)."""
         bc, cc = C.c_int32(), C.c_int32()
@@ -240,6 +256,17 @@ class ServingDriver:
         self._ck(self._lib.uda_run(self._h, mode, 1), "uda_run")
         self._last_n = n
         return self._collect(n, mode)
+
+    def serve_resident(self, image_arrays, post_mode=None):
+        """serve() without the download: the detections stay in the handle (`detections_device`, calibrators,
+        `class_probs`) - what the multi-GPU layer runs before its device-resident gather.  Returns the image count."""
+        mode = self._mode(post_mode)
+        n = self._feed(image_arrays)
+        self._next_seed()
+        self._run_id += 1
+        self._ck(self._lib.uda_run(self._h, mode, 1), "uda_run")
+        self._last_n = n
+        return n
 
     def serve_files(self, paths, post_mode=None):
         """Decode image files and serve them as ONE batch (the reference reads and serves file by file,
@@ -362,7 +389,7 @@ class ServingDriver:
                                  % (what, lvl, a.shape[0], t_dev))
         return np.ascontiguousarray(a)
 
-    def postprocess(self, cls_outputs, box_outputs, image_scales=None, post_mode=None):
+    def postprocess(self, cls_outputs, box_outputs, image_scales=None, post_mode=None, collect=True):
         """`ServingDriver._postprocess` = postprocess_global on given head outputs (infer_lib.py:263-267);
         post_mode="per_class" = postprocess_per_class (eval.py:117-123 via generate_detections).  Head outputs that
         are still resident in this handle (`DeviceHeads` of its last run) are not uploaded again."""
@@ -392,7 +419,7 @@ class ServingDriver:
             raise ValueError("image_scales must have shape (%d,), got %s" % (n, s.shape))
         self._ck(self._lib.uda_postprocess_heads(self._h, n, _ptr(s), mode), "uda_postprocess_heads")
         self._last_n = n
-        return self._collect(n, mode)
+        return self._collect(n, mode) if collect else None      # (collect=False: the detections stay resident, see detections_device)
 
     def device_heads(self, n):
         """(cls_outputs, box_outputs) of the last run as lazy sequences that stay on the device until indexed."""
