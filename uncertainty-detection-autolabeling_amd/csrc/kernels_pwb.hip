@@ -1590,6 +1590,26 @@ static void launch_mbxp_t(const MbxArgs& a, int rows, hipStream_t s) {
   launch_mbxp_ts<K, KSF, UDA_SPLIT_BF16X2>(a, rows, s);
 }
 
+// Dynamic LDS of the fused MBConv launch the executor will make for this op (the formulas of launch_mbxb_t / launch_mbxd_tw /
+// launch_mbxp_tw): uda_create checks it against the 160 KB of a gfx950 CU and names the op, instead of a refused launch
+// surfacing in the middle of a run.
+size_t mbx_lds_bytes(int Cin, int Cmid, int k, int stride, int scheme, int Ho, int Wo) {
+  const int npc = uda_split_pieces(scheme), ksf = (Cin + 1 + 15) / 16, nch = (Cmid + 31) / 32;
+  const size_t par = (size_t)(k * k + 2) * 32;
+  if (Cin <= 48) {        // mbxb_kernel
+    const MbxCfgB c = mbxb_cfg(k, stride);
+    const int ih = (c.th - 1) * stride + k, iw = (c.tw - 1) * stride + k, npp = (ih * iw + 31) / 32 * 32;
+    const int etw = mbx_et_w(k, stride);
+    return ((etw ? (size_t)32 * mbx_et_pitch(etw) : (size_t)npp * 32) + 8 * 32 + 2 * par) * sizeof(float) + (size_t)ksf * npc * 64 * sizeof(uint4);
+  }
+  static int pipe = -1;
+  if (pipe < 0) { const char* e = getenv("UDA_MBXP"); pipe = e ? atoi(e) : 1; }
+  const bool wide = mbxd_wide(Ho, Wo, k, stride);
+  const bool p2 = pipe && stride == 1 && ksf >= 13 && npc == 2 && !(scheme == UDA_SPLIT_F16X2 && k == 3 && !wide);      // mbxp_kernel
+  if (p2) return ((size_t)2 * 256 * 33 + 2 * 16 * 32 + 3 * par + 2 * 32 * nch) * sizeof(float) + (size_t)2 * ksf * 2 * 64 * sizeof(uint4);
+  return ((size_t)256 * 33 + 16 * 32 + 2 * par + 2 * 32 * nch) * sizeof(float) + (size_t)ksf * npc * 64 * sizeof(uint4);
+}
+
 bool mbxd_supported(int Cin, int Cmid, int k, int stride) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("UDA_FUSE_MBXD"); on = e ? atoi(e) : 1; }

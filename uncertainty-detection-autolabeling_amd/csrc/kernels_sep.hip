@@ -278,6 +278,16 @@ static void launch_sep_nt(const SepMulti& m, int rows, int gy, hipStream_t s) {
   else go(sep_kernel<NT, 2, 2>);
 }
 
+// Dynamic LDS of the launch launch_sep_any will make for a C -> Cout separable conv (see launch_sep_nt): checked by uda_create
+size_t sep_lds_bytes(int C, int Cout, int scheme) {
+  const int KS = (C + 15) / 16, ntl = (Cout + 31) / 32, npc = uda_split_pieces(scheme);
+  const size_t a_img = scheme == UDA_SPLIT_BF16X3 ? (size_t)128 * (KS * 64 + 16) : (size_t)npc * 128 * (KS * 32 + 16);
+  int nt = ntl <= 4 ? ntl : 3;
+  if (ntl > 2 && a_img + (size_t)KS * (ntl < 4 ? ntl : 3) * npc * 1024 > 120 * 1024) nt = 2;
+  const size_t lds = a_img + (size_t)KS * nt * npc * 1024, stg = 4 * 32 * PWB_STG * 4;
+  return lds < stg ? stg : lds;
+}
+
 static void launch_sep_any(const SepMulti& m, int rows, hipStream_t s) {
   const int ntl = (m.one.Cout + 31) / 32;
   // three pieces per operand (UDA_PW_TERMS=6) at 112 channels (D2's BiFPN): the A image (128 x 464 B) plus the weight

@@ -575,6 +575,23 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
         }
         c->wsplit_off[i] = (int64_t)at;
       }
+      // LDS budget of every fused launch, checked now and by name (a template / shape pair that asks for more than a CU has
+      // would otherwise surface as a refused launch in the middle of the first run: round 3, D2 under six-term products)
+      for (int i = 0; i < n_ops; ++i) {
+        if (c->wsplit_off[i] < 0) continue;
+        const uda_op_t& o = ops[i];
+        const int K = bufs[o.in[0]].C, Nn = bufs[o.out].C;
+        size_t lds = 0;
+        if (o.kind == UDA_OP_MBX) lds = mbx_lds_bytes(o.se_scale >= 0 ? o.se_mid : K, Nn, o.k, o.stride, c->wscheme[i], bufs[o.out].H, bufs[o.out].W);
+        else if (o.kind == UDA_OP_SEP) lds = sep_lds_bytes(K, Nn, c->wscheme[i]);
+        if (lds > (size_t)160 * 1024) {
+          fail(nullptr, "op %d (%s, %d -> %d channels, k %d, stride %d, split scheme %d): its launch needs %zu bytes of LDS, a gfx950 "
+                        "CU has 163840", i, o.kind == UDA_OP_MBX ? "fused MBConv front half" : "fused separable conv", K, Nn, o.k, o.stride,
+               c->wscheme[i], lds);
+          uda_destroy(c);
+          return 1;
+        }
+      }
       CK(dalloc(&c->d_wsplit, packed.size()));
       if (!packed.empty())
         CK(hipMemcpy(c->d_wsplit, packed.data(), packed.size() * sizeof(uint16_t), hipMemcpyHostToDevice));

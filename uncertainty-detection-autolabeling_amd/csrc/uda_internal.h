@@ -133,6 +133,7 @@ struct SepMulti {
 };
 void launch_sep_multi(const SepArgs& common, const SepLevel* lv, int n_lv, int rows, hipStream_t s);
 bool sep_supported(int C, int Cout);
+size_t sep_lds_bytes(int C, int Cout, int scheme);      // dynamic LDS of the launch an op of this shape gets
 
 struct DwArgs {
   const float* in;       // [rows_in, H, W, C]
@@ -193,6 +194,7 @@ void mbx_pack_params(const float* wd, const float* sc1, const float* sh1, int Cm
 void launch_mbxb(const MbxArgs& a, int rows, int k, int stride, hipStream_t s);
 void launch_mbxd(const MbxArgs& a, int rows, int k, int stride, hipStream_t s);     // deep blocks (Cin > 48), stride 1 or 2
 bool mbxd_supported(int Cin, int Cmid, int k, int stride);
+size_t mbx_lds_bytes(int Cin, int Cmid, int k, int stride, int scheme, int Ho, int Wo);   // dynamic LDS of the fused launch of this op
 int mbxd_tiles(int Ho, int Wo, int k, int stride = 1);
 bool mbxd_wide(int Ho, int Wo, int k, int stride);     // 20-column tiles for this map (mirror: plan.mbx_tile)
 bool mbxb_supported(int Cin, int Cmid, int k, int stride);
