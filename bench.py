@@ -365,9 +365,9 @@ def main():
                     "share_of_step": round(dom_ms / a.steps / (elapsed / a.steps * 1e3), 3)}
             if KIND_NAMES.get(dominant, "") == "mbx":
                 roof["note"] = ("fused MBConv front halves: bound by vector issue, not by HBM - SQ counters of the committed profile "
-                                "(profiles/r03_sq.txt): VALU 74-89 % busy in blocks 1-10 at the 1.8-2.0 GHz the chip holds under them, two "
-                                "transcendentals per swish = 60 % of block 1's vector time, instruction counts at the floor of the algorithm "
-                                "(DESIGN.md 4.5); plain streaming kernels reach 4.5-5.7 TB/s on this box (tools/micro/hbm_rates.hip)")
+                                "(profiles/r04_sq.txt, this scheme): VALU 75-88 % busy in blocks 1-10 at the 1.8-2.0 GHz the chip holds under them, "
+                                "two transcendentals per swish = 60 % of block 1's vector time, instruction counts at the floor of the algorithm "
+                                "(DESIGN.md 4.5, 4.6); plain streaming kernels reach 4.5-5.7 TB/s on this box (tools/micro/hbm_rates.hip)")
             # `traffic` (HBM bytes per launch from the PMC counters) cannot be collected inside this process: it comes from
             # separate rocprofv3 --pmc passes.  The figure of the last committed profile of this command is quoted beside it.
             tf = os.path.join(ROOT, "profiles", "traffic.json")

@@ -23,6 +23,7 @@
 //   epilogue        : accumulators through a wave-private LDS tile so that every lane stores 16 contiguous
 //                     bytes, with bias / BN / swish / dropout keep-scale / residual applied on the float4.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1222,6 +1223,31 @@ __global__ __launch_bounds__(512, (KSF <= 8 && PARTS != 3) ? 4 : 2) void mbxd_ke
 // region; the matrix core runs asynchronously to the VALU), then activates that accumulator into the other E buffer.
 // E, the packed weights and the SE sums are double-buffered, the per-slab depthwise block triple-buffered, and ONE
 // barrier per slab remains.
+#ifdef UDA_MBXP_STAMPS
+// diagnostic build (-DUDA_MBXP_STAMPS, A/B libraries only): shader-clock cycles every wave spends in the phases of a slab
+// iteration, summed over all waves of all launches and printed by the launcher every few launches.  [0] barrier wait,
+// [1] operand requests + taps + first window row, [2] interleaved MFMA / depthwise region, [3] output epilogue + stores,
+// [4] activation of the next slab -> E, [5] operand writes to LDS, [6] wave-iterations.  Round 4 (blocks 12-14, 5x5, 13 k-steps,
+// 20-column tiles): 6970 cycles per wave and slab = barrier 1046 + requests 1197 + MFMA region 2628 (two waves x 39 MFMAs x 32
+// cycles = 2496 on the SIMD's matrix pipe) + epilogue 831 + activation 552 + operand writes 723 (the wait for the slab-ahead
+// weight loads, which retire in order behind the previous slab's output stores: moving the writes ahead of the stores moved
+// the wait into the MFMA region, 6970 either way; without any output stores 6402).  DESIGN.md 4.6.
+__device__ unsigned long long g_mbxp_stamps[8];
+static void mbxp_stamp_dump() {       // (the runtime is gone by the time static destructors run)
+  unsigned long long h[8] = {};
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mbxp_stamps), sizeof(h)) != hipSuccess || !h[6]) return;
+  const char* nm[6] = {"barrier wait", "requests + first row", "MFMA / depthwise region", "epilogue + stores", "activation -> E", "operand writes"};
+  unsigned long long tot = 0;
+  for (int i = 0; i < 6; ++i) tot += h[i];
+  fprintf(stderr, "[mbxp stamps] %llu wave-iterations, %.0f cycles each:", h[6], (double)tot / (double)h[6]);
+  for (int i = 0; i < 6; ++i) fprintf(stderr, "  %s %.0f (%.0f %%)", nm[i], (double)h[i] / (double)h[6], 100.0 * (double)h[i] / (double)tot);
+  fprintf(stderr, "\n");
+}
+#define MBXP_STAMP(i) do { const unsigned long long t_ = clock64(); st_acc[i] += t_ - st_t; st_t = t_; } while (0)
+#else
+#define MBXP_STAMP(i) do { } while (0)
+#endif
+
 template <int K, int KSF, bool WIDE, int SCH>    // SCH: UDA_SPLIT_BF16X2 or UDA_SPLIT_F16X2 (two pieces per operand)
 __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
   static_assert(split_np(SCH) == 2, "the self-overlapping kernel is laid out for two pieces per operand");
@@ -1351,8 +1377,12 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
     e_store(E, acc);
   }
 
+#ifdef UDA_MBXP_STAMPS
+  unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = clock64();
+#endif
   for (int ch = chb; ch < che; ++ch) {
     __syncthreads();      // E[r & 1], Bs[(r + 1) & 1], par[(r + 1) % 3], red[(r - 1) & 1] are complete
+    MBXP_STAMP(0);
     const int r = ch - chb;
     const int col = ch * 32 + c;
     const bool dcol = col < a.Cmid;
@@ -1428,6 +1458,7 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
     bf16x8 bh_c = __builtin_bit_cast(bf16x8, bnext[lane]), bl_c = __builtin_bit_cast(bf16x8, bnext[64 + lane]);
     bf16x8 bh_n = bh_c, bl_n = bl_c;
     __builtin_amdgcn_sched_barrier(0);
+    MBXP_STAMP(1);
 #pragma unroll
     for (int st = 0; st < ROWS; ++st) {
       const int ui = st / K, ky = st % K;
@@ -1472,6 +1503,7 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
     for (int ui = 0; ui < UPT; ++ui)
 #pragma unroll
       for (int o = 0; o < XW; ++o) asm volatile("" : "+v"(dacc[ui][o]));
+    MBXP_STAMP(2);
     // ---- outputs of slab ch
     float ssum = 0.f;
     float* const ob = obase + ch * 32;            // uniform
@@ -1500,8 +1532,10 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
     if (full) store_units(std::false_type());
     else if (dcol) store_units(std::true_type());
     if (a.se_partial) red[((r & 1) * NG + g) * 32 + c] = ssum;
+    MBXP_STAMP(3);
     // ---- slab ch + 1: activate -> the other E buffer (its readers, depthwise ch - 1, finished before the barrier above)
     if (more) e_store(En, acc);
+    MBXP_STAMP(4);
     // ---- slab ch + 2 operands -> LDS: Bs[r & 1] (its MFMAs were issued one iteration ago), par[(r + 2) % 3]
     {
       uint4* bw = Bs + (size_t)(r & 1) * BSLAB;
@@ -1517,7 +1551,14 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
         if (more2 && f < NPAR) pw[f] = np_[i];
       }
     }
+    MBXP_STAMP(5);
   }
+#ifdef UDA_MBXP_STAMPS
+  if (lane == 0) {
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_mbxp_stamps[i], st_acc[i]);
+    atomicAdd(&g_mbxp_stamps[6], (unsigned long long)(che - chb));
+  }
+#endif
   if (a.se_partial) {
     __syncthreads();
     const int lc = (che - 1) * 32 + c;
@@ -1565,6 +1606,10 @@ static void launch_mbxp_tw(const MbxArgs& a, int rows, hipStream_t s) {
   b.ch_groups = mbx_ch_groups((long long)grid.x * grid.y * rows, 1, (a.Cmid + 31) / 32);
   grid.z = (unsigned)(rows * b.ch_groups);
   hipLaunchKernelGGL((mbxp_kernel<K, KSF, WIDE, SCH>), grid, dim3(512), lds, s, b);
+#ifdef UDA_MBXP_STAMPS
+  static int n_launch = 0;
+  if (K == 5 && ++n_launch % 9 == 0) mbxp_stamp_dump();
+#endif
 }
 
 template <int K, int KSF, int SCH>
