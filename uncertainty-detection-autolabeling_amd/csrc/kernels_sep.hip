@@ -180,7 +180,14 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
   const float un = a.wunscale;             // the packed weights carry a power-of-two factor 1 / un (fp16 pieces; else 1)
 
   if ((a.Cout & 3) != 0) {
-    // scalar epilogue (class head: 9 * 7 = 63 channels)
+    // Output rows that are not a multiple of 16 bytes (class head: 9 * 7 = 63 channels = 252 bytes per pixel): no aligned
+    // float4 stores.  Writing the accumulator layout directly (a lane holds one column of 16 rows: 128-byte pieces at 252-byte
+    // pitch) leaves every cache line partially written per store - the counters showed 1.41x the algorithmic traffic for
+    // class-predict, an extra read of the output's own size.  The finished values (bias / BN / activation / dropout applied
+    // in the accumulator layout, where the column is the lane) are staged per wave as packed rows [32][Cout] and leave in
+    // memory order: the 16 pixels of a tile row are one contiguous run of 16 * Cout floats, written 64 lanes x 4 bytes at a time.
+    float* st = (float*)slds + wave * 32 * (NT * 32);      // [32 rows][<= NT * 32 columns] packed (the A / B images are dead)
+    const int cw = a.Cout - n0 < NT * 32 ? a.Cout - n0 : NT * 32;      // columns of this block
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       const int col = n0 + n * 32 + li;
@@ -191,12 +198,29 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
       const float mk = a.mask ? a.mask[(size_t)b * a.Cout + col] : 1.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        size_t pix;
-        if (!pixel_of(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, pix)) continue;
         float v = fmaf(fmaf(acc[n][r], un, bias), sc, sh);
         if (a.act == UDA_ACT_SWISH) v = swishf_b(v);
         v *= mk;
-        a.out[(out_base + pix) * a.Cout + col] = v;
+        st[((r & 3) + 8 * (r >> 2) + 4 * lh) * cw + n * 32 + li] = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (cw == a.Cout) {
+      // this wave's rows: tile rows 2 wave and 2 wave + 1 (16 pixels each), each a contiguous run of 16 * Cout floats
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int y = oy0 + 2 * wave + half;
+        if (y >= a.H) continue;
+        const int npx = a.W - ox0 < 16 ? a.W - ox0 : 16;
+        float* dst = a.out + (out_base + (size_t)y * a.W + ox0) * a.Cout;
+        const float* src = st + half * 16 * cw;
+        for (int i = lane; i < npx * cw; i += 64) dst[i] = src[i];
+      }
+    } else {                                                 // several column blocks: rows are not contiguous per block
+      for (int i = lane; i < 32 * cw; i += 64) {
+        const int row = i / cw, cc = i - row * cw;
+        size_t pix;
+        if (pixel_of(wave * 32 + row, pix)) a.out[(out_base + pix) * a.Cout + n0 + cc] = st[i];
       }
     }
     return;
@@ -259,7 +283,7 @@ static void launch_sep_nt(const SepMulti& m, int rows, int gy, hipStream_t s) {
   const int npc = uda_split_pieces(a.wparts);
   const size_t a_img = a.wparts == UDA_SPLIT_BF16X3 ? (size_t)128 * (KS * 64 + 16) : (size_t)npc * 128 * (KS * 32 + 16);   // float32 image | pieces
   size_t lds = a_img + (size_t)KS * NT * npc * 1024;
-  const size_t stg = 4 * 32 * PWB_STG * 4;
+  const size_t stg = (a.Cout & 3) ? (size_t)4 * 32 * NT * 32 * 4 : (size_t)4 * 32 * PWB_STG * 4;     // epilogue staging (packed rows | float4 tiles)
   if (lds < stg) lds = stg;
   const dim3 grid(m.n_lv > 0 ? m.tile0[m.n_lv] : sep_tiles(a.H, a.W), gy, rows);
   auto go = [&](auto kern) {
@@ -284,7 +308,8 @@ size_t sep_lds_bytes(int C, int Cout, int scheme) {
   const size_t a_img = scheme == UDA_SPLIT_BF16X3 ? (size_t)128 * (KS * 64 + 16) : (size_t)npc * 128 * (KS * 32 + 16);
   int nt = ntl <= 4 ? ntl : 3;
   if (ntl > 2 && a_img + (size_t)KS * (ntl < 4 ? ntl : 3) * npc * 1024 > 120 * 1024) nt = 2;
-  const size_t lds = a_img + (size_t)KS * nt * npc * 1024, stg = 4 * 32 * PWB_STG * 4;
+  const size_t lds = a_img + (size_t)KS * nt * npc * 1024;
+  const size_t stg = (Cout & 3) ? (size_t)4 * 32 * nt * 32 * 4 : (size_t)4 * 32 * PWB_STG * 4;
   return lds < stg ? stg : lds;
 }
 
