@@ -24,14 +24,23 @@ def test_crc32c_known_answers():
     assert CR._masked(0) == 0xA282EAD8                               # LevelDB: rotate right by 15, add the constant
 
 
+def _with_shadows(w, **changed):
+    """The bundle a training run with moving_average_decay > 0 leaves: every variable (the trainable ones and the BN moving
+    statistics, utils_keras.py:85-97) has its `/ExponentialMovingAverage` shadow; `changed` overrides single shadows."""
+    b = dict(w)
+    for k, v in w.items():
+        b[k + "/ExponentialMovingAverage"] = changed.get(k, v)
+    return b
+
+
 def test_name_based_checkpoint_round_trip(tmp_path):
     p = make_params(loss_attenuation=True)
     w = W.init_weights(p, seed=3)
-    prefix = CR.save_checkpoint(str(tmp_path / "model"), w, checksum=True)     # every restored tensor is CRC-checked
+    prefix = CR.save_checkpoint(str(tmp_path / "model"), _with_shadows(w), checksum=True)     # every restored tensor is CRC-checked
     raw = open(prefix + ".index", "rb").read()
-    assert struct.unpack("<Q", raw[-8:])[0] == 0xDB4775248B80FB57 and os.path.getsize(prefix + ".data-00000-of-00001") == sum(v.nbytes for v in w.values())
+    assert struct.unpack("<Q", raw[-8:])[0] == 0xDB4775248B80FB57 and os.path.getsize(prefix + ".data-00000-of-00001") == 2 * sum(v.nbytes for v in w.values())
     r = CR.BundleReader(prefix)
-    assert set(r.entries) == set(w) and r.variable_to_shape_map()["efficientnet-b0/stem/conv2d/kernel"] == (3, 3, 3, 32)
+    assert set(r.entries) == set(_with_shadows(w)) and r.variable_to_shape_map()["efficientnet-b0/stem/conv2d/kernel"] == (3, 3, 3, 32)
     got = CR.load_checkpoint(prefix, p, use_ema=True, skip_mismatch=False)
     assert set(got) == set(w)
     for k in w:
@@ -69,6 +78,27 @@ def test_restore_rules_ema_missing_and_mismatch(tmp_path):
     np.testing.assert_array_equal(got["box_net/box-predict/bias"], ref["box_net/box-predict/bias"])
     with pytest.raises((KeyError, ValueError)):
         CR.load_checkpoint(prefix, p, use_ema=True, skip_mismatch=False)
+
+
+def test_checkpoint_without_shadows_is_refused_when_ema_is_on(tmp_path, caplog):
+    """With moving_average_decay > 0 the reference's restore map holds the plain AND the shadow name of every variable and
+    raises `Not found ...` for a missing shadow (utils_keras.py:176-235): a checkpoint saved without EMA must not load as if it
+    had one.  skip_mismatch=True restores the plain variables and says so; use_ema=False never looks for shadows."""
+    p = make_params()
+    w = W.init_weights(p, seed=12)
+    prefix = CR.save_checkpoint(str(tmp_path / "ckpt-9"), w, checksum=False)
+    with pytest.raises(KeyError, match="ExponentialMovingAverage"):
+        CR.load_checkpoint(prefix, p, use_ema=True, skip_mismatch=False)
+    with pytest.raises(KeyError, match="ExponentialMovingAverage"):
+        W.resolve_weights(prefix, dict(p, moving_average_decay=0.9998))          # the drivers restore strictly (infer_lib.py:435)
+    import logging
+    with caplog.at_level(logging.WARNING):
+        got = CR.load_checkpoint(prefix, p, use_ema=True, skip_mismatch=True)
+    assert "no ExponentialMovingAverage shadow" in caplog.text
+    k = "efficientnet-b0/blocks_1/conv2d/kernel"
+    np.testing.assert_array_equal(got[k], w[k])
+    np.testing.assert_array_equal(CR.load_checkpoint(prefix, p, use_ema=False, skip_mismatch=False)[k], w[k])
+    np.testing.assert_array_equal(W.resolve_weights(prefix, dict(p, moving_average_decay=0))[k], w[k])
 
 
 def test_tf2_object_graph_checkpoint_names(tmp_path):
@@ -133,7 +163,7 @@ def test_ema_shadow_wins_for_bn_statistics_too(tmp_path):
     plain name (:183-196): a bundle holding both keys for a BN statistic restores the shadow."""
     p = make_params()
     w = W.init_weights(p, seed=6)
-    bundle = dict(w)
+    bundle = _with_shadows(w)
     for f in ("moving_mean", "moving_variance", "gamma"):
         k = "efficientnet-b0/stem/tpu_batch_normalization/" + f
         bundle[k + "/ExponentialMovingAverage"] = w[k] + 3
@@ -152,7 +182,7 @@ def test_driver_restore_is_strict_and_follows_moving_average_decay(tmp_path, cap
     p = make_params()
     w = W.init_weights(p, seed=8)
     k = "efficientnet-b0/blocks_2/conv2d/kernel"
-    bundle = dict(w)
+    bundle = _with_shadows(w)
     bundle[k + "/ExponentialMovingAverage"] = w[k] * 3
     prefix = CR.save_checkpoint(str(tmp_path / "ckpt-1"), bundle, checksum=False)
     np.testing.assert_array_equal(W.resolve_weights(prefix, dict(p, moving_average_decay=0.9998))[k], w[k] * 3)

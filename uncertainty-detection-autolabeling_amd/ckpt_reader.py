@@ -268,13 +268,34 @@ def load_checkpoint(path, config, use_ema=True, skip_mismatch=False, verify_crc=
         fields = [(name + "/" + f, shape) for f in weights_mod.BN_FIELDS] if kind == "bn" else [(name, shape)]
         for var, shp in fields:
             key = None
-            if use_ema:
-                key = names.get(var + "/ExponentialMovingAverage")
-            key = key or names.get(var)
             problem = None
+            if use_ema:
+                # the reference puts BOTH names into its restore map when moving_average_decay > 0 (utils_keras.py:200-235) and
+                # raises when the shadow is missing: a checkpoint saved without EMA does not load silently as if it had one
+                key = names.get(var + "/ExponentialMovingAverage")
+                if key is None and names.get(var) is not None:
+                    if not skip_mismatch:
+                        raise KeyError("Not found %s/ExponentialMovingAverage in %s (the checkpoint holds %s without its moving "
+                                       "average; restore with moving_average_decay = 0 or skip_mismatch=True)" % (var, path, var))
+                    logging.getLogger(__name__).warning("skip_mismatch: %s has no ExponentialMovingAverage shadow in %s: the plain "
+                                                        "variable is restored", var, path)
+            if use_ema and key is not None:
+                # ... and the plain name is in that map too: it must exist with the right shape although the shadow is what is kept
+                plain = names.get(var)
+                if plain is None:
+                    problem = KeyError("Not found %s in %s" % (var, path))
+                else:
+                    gotp = tuple(reader.entries[plain]["shape"])
+                    wantp = tuple(shp) if kind != "wsm" else ()
+                    if gotp != wantp and not (kind == "wsm" and gotp in ((), (1,))):
+                        problem = ValueError("Shape mismatch: %s, expected %s, but got %s" % (var, wantp, gotp))
+                if problem is not None and skip_mismatch:
+                    logging.getLogger(__name__).warning("skip_mismatch: %s (the ExponentialMovingAverage shadow is restored)", problem)
+                    problem = None
+            key = key or names.get(var)
             if key is None:
                 problem = KeyError("Not found %s in %s" % (var, path))
-            else:
+            elif problem is None:
                 got = tuple(reader.entries[key]["shape"])
                 want = tuple(shp) if kind != "wsm" else ()
                 if got != want and not (kind == "wsm" and got in ((), (1,))):
