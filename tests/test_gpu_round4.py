@@ -202,3 +202,49 @@ def test_fp16_pieces_fail_loudly_on_an_activation_above_65504(tmp_path):
         res[scheme] = [l for l in r.stdout.splitlines() if l.startswith(("served", "raised"))][-1]
     assert res["f16x2"].startswith("raised") and "65504" in res["f16x2"] and "bf16x3" in res["f16x2"], res
     assert res["bf16x3"] == "served True", res
+
+
+STEM_WORKER = r"""
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import numpy as np
+from common import FULL_MC, make_images, make_params, make_weights
+from uda_amd.infer_lib import KerasDriver
+p = make_params(**FULL_MC)
+w = make_weights(p, seed=91, cls_spread=20.0)
+d = KerasDriver("_", False, p["name"], 3, False, p, weights=w, chunk_images=2)
+d.set_dropout_seed(19)
+out = {}
+for tag, hw in (("full", (128, 192)), ("small", (100, 180)), ("tiny", (3, 5))):        # raw size = / < the 192x128 network input: scale 1
+    imgs = make_images(3, hw[0], hw[1], seed=92)
+    det = d.serve(imgs)
+    cls, box = d.head_outputs(3)
+    pre, scales = d.preprocessed()
+    for i, a in enumerate(list(det) + [cls[0], box[0], cls[4], box[4], pre, scales]):
+        out["%%s_%%d" %% (tag, i)] = a
+det = d.serve(make_images(2, 90, 200, seed=93))      # wider than the network input: resampled, the separate preprocess pass runs
+for i, a in enumerate(det):
+    out["resampled_%%d" %% i] = a
+np.savez(sys.argv[1], **out)
+d.close()
+print("saved")
+"""
+
+
+def test_uint8_stem_is_bit_identical_to_the_preprocess_pass(tmp_path):
+    """When no image of a uint8 batch is resampled (scale 1) the stem reads the raw images itself - normalisation through a
+    768-entry table of the preprocess kernel's own expression - and the separate preprocess pass is skipped.  Same values, same
+    accumulation order: heads and detections equal the two-pass path (UDA_STEM_U8=0) bit for bit, for raw sizes
+    equal to and smaller than the network input (zero padding) down to 3 x 5 pixels; the float image is still available on
+    demand (`preprocessed()`), and a batch that IS resampled takes the separate pass either way."""
+    outs = {}
+    for sw in ("1", "0"):
+        e = dict(os.environ, UDA_STEM_U8=sw)
+        out = str(tmp_path / ("stem%s.npz" % sw))
+        r = subprocess.run([sys.executable, "-c", STEM_WORKER % {"root": ROOT}, out], cwd=ROOT, env=e, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0 and "saved" in r.stdout, (sw, r.stdout[-1500:], r.stderr[-1500:])
+        outs[sw] = dict(np.load(out))
+    assert outs["1"].keys() == outs["0"].keys() and len(outs["1"]) >= 3 * 11
+    for k in outs["1"]:
+        np.testing.assert_array_equal(outs["1"][k], outs["0"][k], err_msg=k)

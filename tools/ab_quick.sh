@@ -8,7 +8,7 @@ for ROUND in 1 2; do
     python - <<PY
 import json
 d=json.load(open("/tmp/ab_out.json")); k=d["kernel_ms_per_step"]
-print("%-28s %6.2f ms/step  mbx %.2f pw %.2f sep %.2f fuse %.2f nms %.2f" % ("$LIB", d["ms_per_step"], k["mbx"], k["pw"], k["sep"], k["fuse"], k["nms"]))
+print("%-28s %6.2f ms/step  mbx %.2f pw %.2f sep %.2f fuse %.2f nms %.2f stem %.2f pre %.2f" % ("$LIB", d["ms_per_step"], k["mbx"], k["pw"], k["sep"], k["fuse"], k["nms"], k["stem"], k["preprocess"]))
 PY
     grep "stamps" /tmp/ab_err.txt | tail -1
   done

@@ -134,7 +134,110 @@ __global__ __launch_bounds__(256) void stem16_kernel(StemArgs a) {
   }
 }
 
+// The same convolution straight from the raw uint8 images (StemArgs::u8): a thread loads the three 9-byte window rows of its
+// output pixel (one unaligned 12-byte load each; the byte behind the last image is slack the host allocates), turns every byte
+// into its normalised value through the table in LDS (one SDWA shift + one LDS read per value) and runs the float kernel's
+// accumulation - same values, same order, bit-identical outputs.  Pixels beyond the raw image (zero padding of the network
+// input, dataloader.py:123-152) and beyond the map (SAME padding) contribute 0.  CG output channels per thread (32: the window
+// is decoded once per pixel).
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+// SW: Co == CG, every thread computes ALL output channels: the weight addresses are wave-uniform, so the 27 x Co weights come
+// through the scalar cache into scalar registers (s_load) and enter the FMAs as scalar operands - no LDS traffic for them (the
+// LDS-broadcast version was bound by those 216 ds_read_b128 per thread: 0.83 ms; the float kernel above has the same bound)
+template <int CG, bool SW>
+__global__ __launch_bounds__(256) void stem_u8_kernel(StemArgs a) {
+  extern __shared__ float wl[];  // [27][Co] | table [3][256]
+  float* lut = wl + (SW ? 0 : 27 * a.Co);
+  if constexpr (!SW)
+    for (int i = threadIdx.x; i < 27 * a.Co; i += blockDim.x) wl[i] = a.w[i];
+  for (int i = threadIdx.x; i < 768; i += blockDim.x) {
+    const int c = i >> 8;
+    lut[i] = ((float)(i & 255) - a.mean[c]) / a.stdv[c];
+  }
+  __syncthreads();
+  const int cgn = SW ? 1 : a.Co / CG;
+  const int64_t total = (int64_t)a.rows * a.Ho * a.Wo * cgn;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  const int cg = SW ? 0 : (int)(gid % cgn);
+  int64_t p = gid / cgn;
+  const int x = (int)(p % a.Wo);
+  p /= a.Wo;
+  const int y = (int)(p % a.Ho);
+  const int b = (int)(p / a.Ho);
+  const PreGeo g = a.geo[a.img0 + b];
+  const uint8_t* img = a.u8 + g.off;
+  float v[27];
+  const int ix0 = x * 2 - a.pad_l;
+  const bool colsok = ix0 >= 0 && ix0 + 2 < g.w;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = y * 2 - a.pad_t + ky;
+    const bool rowok = iy >= 0 && iy < g.h;
+    if (rowok && colsok) {
+      const uint8_t* q = img + ((size_t)iy * g.w + ix0) * 3;
+      const uint32_t u0 = *(const u32_unaligned*)q, u1 = *(const u32_unaligned*)(q + 4), u2 = *(const u32_unaligned*)(q + 8);
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        const uint32_t u = j < 4 ? u0 : (j < 8 ? u1 : u2);
+        v[ky * 9 + j] = lut[(j % 3) * 256 + ((u >> (8 * (j & 3))) & 255u)];
+      }
+    } else {
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ix0 + kx;
+        const bool in = rowok && ix >= 0 && ix < g.w;
+        const uint8_t* q = img + ((size_t)(in ? iy : 0) * g.w + (in ? ix : 0)) * 3;
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) v[(ky * 3 + kx) * 3 + ci] = in ? lut[ci * 256 + q[ci]] : 0.f;
+      }
+    }
+  }
+  float4 acc[CG / 4];
+#pragma unroll
+  for (int q = 0; q < CG / 4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int t = 0; t < 27; ++t) {
+#pragma unroll
+    for (int q = 0; q < CG / 4; ++q) {
+      const float4 w = SW ? *(const float4*)(a.w + t * CG + q * 4) : *(const float4*)(wl + t * a.Co + cg * CG + q * 4);
+      acc[q].x = fmaf(v[t], w.x, acc[q].x);
+      acc[q].y = fmaf(v[t], w.y, acc[q].y);
+      acc[q].z = fmaf(v[t], w.z, acc[q].z);
+      acc[q].w = fmaf(v[t], w.w, acc[q].w);
+    }
+  }
+  float* op = a.out + (size_t)gid * CG;
+#pragma unroll
+  for (int q = 0; q < CG / 4; ++q) {
+    const float4 s = *(const float4*)(a.bn_scale + cg * CG + q * 4);
+    const float4 t = *(const float4*)(a.bn_shift + cg * CG + q * 4);
+    float4 o;
+    o.x = swishf(fmaf(acc[q].x, s.x, t.x));
+    o.y = swishf(fmaf(acc[q].y, s.y, t.y));
+    o.z = swishf(fmaf(acc[q].z, s.z, t.z));
+    o.w = swishf(fmaf(acc[q].w, s.w, t.w));
+    *(float4*)(op + q * 4) = o;
+  }
+}
+
+bool stem_u8_supported(int Co) { return (Co & 15) == 0 && Co <= 64; }
+
 void launch_stem(const StemArgs& a, hipStream_t s) {
+  if (a.u8) {
+    const size_t lds = (27 * (size_t)a.Co + 768) * sizeof(float);
+    if (a.Co == 32) {              // (EfficientNet-B0 ... B2)
+      const int64_t total = (int64_t)a.rows * a.Ho * a.Wo;
+      hipLaunchKernelGGL((stem_u8_kernel<32, true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 768 * sizeof(float), s, a);
+    } else if ((a.Co & 31) == 0) {
+      const int64_t total = (int64_t)a.rows * a.Ho * a.Wo * (a.Co >> 5);
+      hipLaunchKernelGGL((stem_u8_kernel<32, false>), dim3((unsigned)((total + 255) / 256)), dim3(256), lds, s, a);
+    } else {
+      const int64_t total = (int64_t)a.rows * a.Ho * a.Wo * (a.Co >> 4);
+      hipLaunchKernelGGL((stem_u8_kernel<16, false>), dim3((unsigned)((total + 255) / 256)), dim3(256), lds, s, a);
+    }
+    return;
+  }
   static int wide = -1;
   if (wide < 0) { const char* e = getenv("UDA_STEM16"); wide = e ? atoi(e) : 1; }
   if (wide && (a.Co & 15) == 0) {

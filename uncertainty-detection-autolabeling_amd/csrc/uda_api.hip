@@ -85,6 +85,9 @@ struct uda_ctx {
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_pre_done[2] = {nullptr, nullptr};   // the preprocess kernel has consumed slot i (its buffer may be refilled)
   bool have_u8 = false;
+  bool stem_from_u8 = false;   // this run's stem ops read the uint8 slot (set by run_network)
+  bool pre_valid = false;      // d_images holds the preprocessed current batch (false: the stem read the uint8 images itself)
+  int stem_co = 0;             // output channels of the stem op (0: no stem op in the plan)
   float* d_images = nullptr;   // [max_images, H, W, 3]
   float* d_scales = nullptr;   // [max_images]
   std::vector<float> h_scales;
@@ -405,6 +408,8 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
   c->model = *model;
   c->bufs.assign(bufs, bufs + n_bufs);
   c->ops.assign(ops, ops + n_ops);
+  for (int i = 0; i < n_ops; ++i)
+    if (ops[i].kind == UDA_OP_STEM && ops[i].out >= 0 && ops[i].out < n_bufs) c->stem_co = bufs[ops[i].out].C;
   if (model->n_drop_sites > 0 && sites) c->sites.assign(sites, sites + model->n_drop_sites);
   c->device = device;
   c->n_weights = n_weights;
@@ -766,7 +771,7 @@ static int fill_slot(uda_ctx* c, int si, const void* images, const uint8_t* cons
   if (hdr + total > sl.cap) {
     if (sl.d) HIPC(c, hipFree(sl.d));
     sl.d = nullptr; sl.cap = 0;
-    HIPC(c, hipMalloc((void**)&sl.d, hdr + total));
+    HIPC(c, hipMalloc((void**)&sl.d, hdr + total + 16));      // (+16: the uint8 stem reads 12-byte window rows, 3 bytes past the last pixel)
     sl.cap = hdr + total;
   }
   sl.d_geo = (PreGeo*)sl.d;
@@ -882,6 +887,7 @@ extern "C" int uda_set_images_f32(uda_ctx_t* c, const float* images, int32_t n, 
   HIPC(c, hipMemcpyAsync(c->d_scales, c->h_scales.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream));
   c->n_images = n;
   c->have_u8 = false;
+  c->stem_from_u8 = false;
   return 0;
 }
 
@@ -968,6 +974,12 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       a.pad_t = same_pad_before(ib.H, ob.H, 3, 2);
       a.pad_l = same_pad_before(ib.W, ob.W, 3, 2);
       a.rows = rows;
+      if (c->stem_from_u8) {
+        if (ib.kind != 1 || ib.per_sample) return fail(c, "op %d: the uint8 stem reads the image buffer", oi);
+        const uda_ctx::U8Slot& sl = c->u8[c->cur];
+        a.u8 = sl.d_img; a.geo = sl.d_geo; a.img0 = v.i0;
+        for (int k = 0; k < 3; ++k) { a.mean[k] = c->model.mean_rgb[k]; a.stdv[k] = c->model.stddev_rgb[k]; }
+      }
       launch_stem(a, v.stream());
       break;
     }
@@ -1253,19 +1265,39 @@ static int run_sep_group(uda_ctx* c, const ChunkView& v, int oi, int n) {
 
 static int run_post_range(uda_ctx* c, int i0, int n, int post_mode, hipStream_t st);
 
+static int run_preprocess(uda_ctx* c) {
+  const uda_model_t& m = c->model;
+  ProfScope ps(c, 18);
+  PreprocArgs a{};
+  const uda_ctx::U8Slot& sl = c->u8[c->cur];
+  a.in = sl.d_img; a.out = c->d_images; a.geo = sl.d_geo;
+  a.n = c->n_images; a.H = m.image_h; a.W = m.image_w;
+  for (int k = 0; k < 3; ++k) { a.mean[k] = m.mean_rgb[k]; a.stdv[k] = m.stddev_rgb[k]; }
+  launch_preprocess(a, c->stream);
+  HIPC(c, hipGetLastError());
+  c->pre_valid = true;
+  return 0;
+}
+
 static int run_network(uda_ctx* c, int post_mode = 0, bool chunk_post = false) {
   const uda_model_t& m = c->model;
   const int n = c->n_images, T = m.mc_samples;
+  // uint8 batch in which no image is resampled (scale 1: raw size within the network size - BASELINE configs[1]-[3]): the stem
+  // reads the raw images itself (StemArgs::u8), the preprocess pass and its float32 image (378 MB written and read back per
+  // 32-image batch) are skipped; UDA_STEM_U8=0 restores the separate pass
+  bool stem_u8 = false;
   if (c->have_u8) {
-    ProfScope ps(c, 18);
-    PreprocArgs a{};
+    static const bool on = !(getenv("UDA_STEM_U8") && atoi(getenv("UDA_STEM_U8")) == 0);
     const uda_ctx::U8Slot& sl = c->u8[c->cur];
-    a.in = sl.d_img; a.out = c->d_images; a.geo = sl.d_geo;
-    a.n = n; a.H = m.image_h; a.W = m.image_w;
-    for (int k = 0; k < 3; ++k) { a.mean[k] = m.mean_rgb[k]; a.stdv[k] = m.stddev_rgb[k]; }
-    launch_preprocess(a, c->stream);
-    HIPC(c, hipEventRecord(c->ev_pre_done[c->cur], c->stream));
+    stem_u8 = on && c->stem_co > 0 && stem_u8_supported(c->stem_co);
+    for (int i = 0; i < n && stem_u8; ++i) stem_u8 = sl.geo[i].sh == sl.geo[i].h && sl.geo[i].sw == sl.geo[i].w;
+    c->pre_valid = false;
+    if (!stem_u8) {
+      if (int rc = run_preprocess(c)) return rc;
+      HIPC(c, hipEventRecord(c->ev_pre_done[c->cur], c->stream));
+    }
   }
+  c->stem_from_u8 = stem_u8;
   if (!c->sites.empty()) {
     const int rows = n * T;
     if (c->masks_injected && c->masks_rows != rows)
@@ -1344,6 +1376,7 @@ static int run_network(uda_ctx* c, int post_mode = 0, bool chunk_post = false) {
     HIPC(c, hipEventRecord(c->ev_done[l], c->lane_stream[l]));
     HIPC(c, hipStreamWaitEvent(c->stream, c->ev_done[l], 0));
   }
+  if (stem_u8) HIPC(c, hipEventRecord(c->ev_pre_done[c->cur], c->stream));      // the stem ops have consumed the uint8 slot
   HIPC(c, hipGetLastError());
   return 0;
 }
@@ -2045,6 +2078,10 @@ extern "C" int uda_read_buffer(uda_ctx_t* c, int32_t buf, float* host, int64_t n
   ChunkView v{c, c->last_chunk_i0, c->last_chunk_n};
   v.lane = c->last_lane;
   const uda_buf_desc_t& b = c->bufs[buf];
+  if (b.kind == 1 && c->have_u8 && !c->pre_valid) {
+    if (int rc = run_preprocess(c)) return rc;
+    HIPC(c, hipStreamSynchronize(c->stream));
+  }
   const int64_t have = (int64_t)v.rows(b) * b.H * b.W * b.C;
   if (n_floats > have) return fail(c, "read_buffer: asked %lld floats, buffer holds %lld", (long long)n_floats, (long long)have);
   HIPC(c, hipMemcpy(host, v.ptr(buf), n_floats * sizeof(float), hipMemcpyDeviceToHost));
@@ -2054,6 +2091,8 @@ extern "C" int uda_read_buffer(uda_ctx_t* c, int32_t buf, float* host, int64_t n
 extern "C" int uda_get_preprocessed(uda_ctx_t* c, float* images, float* scales) {
   if (!c) return 1;
   HIPC(c, hipSetDevice(c->device));
+  if (images && c->have_u8 && !c->pre_valid)      // the stem read the uint8 batch itself: produce the float image on demand
+    if (int rc = run_preprocess(c)) return rc;
   HIPC(c, hipStreamSynchronize(c->stream));
   const size_t n = c->n_images;
   if (images)

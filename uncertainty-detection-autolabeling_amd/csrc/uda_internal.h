@@ -60,6 +60,7 @@ enum {
 inline int uda_split_pieces(int scheme) { return scheme == UDA_SPLIT_BF16X3 ? 3 : 2; }
 
 // ---------------------------------------------------------------- kernel argument blocks
+struct PreGeo;
 struct StemArgs {
   const float* in;    // [rows, H, W, 3]
   float* out;         // [rows, Ho, Wo, Co]
@@ -69,6 +70,13 @@ struct StemArgs {
   int H, W, Ho, Wo, Co;
   int pad_t, pad_l;
   int rows;
+  // uint8 input (every image of the batch at scale 1: nothing to resample): the stem normalises on the fly through a 768-entry
+  // table of ((float)v - mean[c]) / std[c] - the preprocess kernel's own expression, so the convolution sees the same values bit
+  // for bit - and reads a quarter of the bytes; the separate preprocess pass and its float32 image are skipped
+  const uint8_t* u8;  // packed raw images (image i at u8 + geo[i].off, [geo[i].h, geo[i].w, 3]) or null
+  const PreGeo* geo;  // [images] (device)
+  int img0;           // first image of this launch in geo
+  float mean[3], stdv[3];
 };
 
 struct PwArgs {
@@ -240,6 +248,7 @@ struct FuseArgs {
 
 // ---------------------------------------------------------------- launchers (kernels_conv.hip)
 void launch_stem(const StemArgs& a, hipStream_t s);
+bool stem_u8_supported(int Co);      // the uint8-input variant of the stem exists for this width
 void launch_pw(const PwArgs& a, int rows, hipStream_t s);
 void launch_dw(DwArgs a, int rows, int k, int stride, hipStream_t s);
 void dw_geometry(int C, int Wo, int k, int stride, int* tc, int* pxb, int* n_cchunk, int* grid_x, int* xb);
