@@ -93,7 +93,8 @@ typedef struct uda_op {
                                       (same channels, activation, sample axes) that may share ONE launch - the pyramid levels
                                       of a head layer; the planner keeps every buffer they touch alive to the end of the run.
                                       0 / 1 elsewhere. */
-  int32_t reserved0;
+  int32_t fuse_in;                 /* SEP: 1 = the conv input is the BiFPN fusion swish(sum_i fuse_w[i] * resample[i](in[i])) of in[0 .. n_in),
+                                      computed on the fly for the tile (no fused tensor in memory); 0 elsewhere */
 } uda_op_t;
 
 /* ---- MC dropout sites -------------------------------------------------------------------- */

@@ -248,3 +248,52 @@ def test_uint8_stem_is_bit_identical_to_the_preprocess_pass(tmp_path):
     assert outs["1"].keys() == outs["0"].keys() and len(outs["1"]) >= 3 * 11
     for k in outs["1"]:
         np.testing.assert_array_equal(outs["1"][k], outs["0"][k], err_msg=k)
+
+
+FUSEIN_WORKER = r"""
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import numpy as np
+from common import FULL_MC, HEAD_MC, make_images, make_params, make_weights
+from uda_amd import capi
+from uda_amd.infer_lib import KerasDriver
+out = {}
+for tag, model, size, mc in (("d0", "efficientdet-d0", "192x128", FULL_MC), ("d0odd", "efficientdet-d0", "448x320", HEAD_MC),
+                             ("d2", "efficientdet-d2", "256x128", FULL_MC)):
+    p = make_params(image_size=size, model=model, **mc)
+    w = make_weights(p, seed=41, cls_spread=20.0)
+    d = KerasDriver("_", False, p["name"], 2, False, p, weights=w, chunk_images=2)
+    d.set_dropout_seed(23)
+    kinds = [o["kind"] for o in d.plan.ops]
+    out[tag + "_nfuse"] = np.array([kinds.count(capi.OP_FUSE), sum(1 for o in d.plan.ops if o.get("fuse_in"))])
+    W, H = [int(v) for v in size.split("x")]
+    det = d.serve(make_images(2, H, W, seed=42))
+    cls, box = d.head_outputs(2)
+    for i, a in enumerate(list(det) + list(cls) + list(box)):
+        out["%%s_%%d" %% (tag, i)] = a
+    d.close()
+np.savez(sys.argv[1], **out)
+print("saved")
+"""
+
+
+def test_bifpn_fusion_inside_the_separable_conv_is_bit_identical(tmp_path):
+    """UDA_FUSE_IN=1 (default): a BiFPN node's weighted fusion (identity / nearest-up / max-pooled inputs, swish) is computed
+    by the node's separable conv for its own 18 x 18 input tile (sepf_kernel) - the fused tensor is never written, the 24
+    (D0) / 40 (D2) fuse launches disappear.  Same expressions, same accumulation order: every head output and every detection
+    equals the two-launch path (UDA_FUSE_IN=0) bit for bit - 64-, and 112-channel pyramids, maps that are and are not
+    multiples of the 16 x 16 tile (40 x 56 ... 3 x 4), per-sample and shared inputs."""
+    outs = {}
+    for sw in ("1", "0"):
+        e = dict(os.environ, UDA_FUSE_IN=sw)
+        out = str(tmp_path / ("fin%s.npz" % sw))
+        r = subprocess.run([sys.executable, "-c", FUSEIN_WORKER % {"root": ROOT}, out], cwd=ROOT, env=e, capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0 and "saved" in r.stdout, (sw, r.stdout[-1500:], r.stderr[-1500:])
+        outs[sw] = dict(np.load(out))
+    assert outs["1"].keys() == outs["0"].keys()
+    for tag, n in (("d0", 24), ("d0odd", 24), ("d2", 40)):
+        assert list(outs["1"][tag + "_nfuse"]) == [0, n] and list(outs["0"][tag + "_nfuse"]) == [n, 0], (tag, outs["1"][tag + "_nfuse"])
+    for k in outs["1"]:
+        if not k.endswith("_nfuse"):
+            np.testing.assert_array_equal(outs["1"][k], outs["0"][k], err_msg=k)

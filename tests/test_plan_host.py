@@ -108,8 +108,11 @@ def test_op_list_shape_d0():
     assert sep == (64 if pl.fuse_sep else 0)
     proj = sum(1 for o in pl.ops if o["kind"] == capi.OP_MBX and o["se_scale"] >= 0)   # block 0's projection inside block 1's op
     assert proj == (1 if pl.fuse_proj and shallow else 0)
-    assert len(pl.ops) == 224 - fused - sep - proj
-    assert kinds.count(capi.OP_STEM) == 1 and kinds.count(capi.OP_SE) == 16 and kinds.count(capi.OP_FUSE) == 24
+    fin = sum(1 for o in pl.ops if o.get("fuse_in"))      # BiFPN fusions computed inside the node's separable conv (round 4)
+    assert fin == (24 if pl.fuse_sep and plan_mod.sepf_supported(64, 64) else 0)
+    assert all(o["kind"] == capi.OP_SEP and len(o["ins"]) in (2, 3) for o in pl.ops if o.get("fuse_in"))
+    assert len(pl.ops) == 224 - fused - sep - proj - fin
+    assert kinds.count(capi.OP_STEM) == 1 and kinds.count(capi.OP_SE) == 16 and kinds.count(capi.OP_FUSE) == 24 - fin
     assert kinds.count(capi.OP_POOL) == 2 and kinds.count(capi.OP_DW) == 16 + 24 + 40 - fused - sep
     assert kinds.count(capi.OP_PW) == 31 + 1 + 5 + 24 + 40 - fused - sep - proj
     assert len(pl.sites) == 61 and pl.T == 3
@@ -302,3 +305,27 @@ def test_pw_scheme_switches(monkeypatch):
     assert not plan.mbx_supported(192, 1152, 5, 1)
     monkeypatch.delenv("UDA_PW_TERMS")
     assert plan.mbx_supported(192, 1152, 5, 1)
+
+
+def test_bifpn_fusion_folds_into_the_separable_conv(monkeypatch):
+    """UDA_FUSE_IN (default 1): a BiFPN node is ONE op - a separable conv whose inputs are the node's fusion inputs with their
+    resample modes and normalised weights (efficientdet_keras.py:90-136 + 207-227); no `fused` buffer is planned, and the
+    arena shrinks by what it held.  UDA_FUSE_IN=0 and the f32 scheme (no fused separable convs at all) keep the FUSE ops."""
+    pl, _ = _plan(FULL_MC, chunk_images=2, max_images=4)
+    monkeypatch.setenv("UDA_FUSE_IN", "0")
+    old, _ = _plan(FULL_MC, chunk_images=2, max_images=4)
+    assert not any("/fused" in n for n in pl.buffer_names) and sum("/fused" in n for n in old.buffer_names) == 24
+    fin = [o for o in pl.ops if o.get("fuse_in")]
+    fuse = [o for o in old.ops if o["kind"] == capi.OP_FUSE]
+    assert len(fin) == len(fuse) == 24
+    for a, b in zip(fin, fuse):             # same inputs, modes and weights, in node order
+        assert [old.bufs[i].name for i in b["ins"]] == [pl.bufs[i].name for i in a["ins"]]
+        assert a["resample"] == b["resample"] and a["fuse_w"] == b["fuse_w"] and a["w2_off"] >= 0 and a["w_off"] >= 0
+    modes = {tuple(o["resample"][:len(o["ins"])]) for o in fin}
+    assert modes == {(capi.RS_NONE, capi.RS_NEAREST_UP), (capi.RS_NONE, capi.RS_NONE, capi.RS_MAXPOOL), (capi.RS_NONE, capi.RS_MAXPOOL)}
+    assert pl.arena_floats <= old.arena_floats
+    assert plan_mod.op_costs(pl, 4)[capi.OP_SEP]["bytes"] < plan_mod.op_costs(old, 4)[capi.OP_SEP]["bytes"] + plan_mod.op_costs(old, 4)[capi.OP_FUSE]["bytes"]
+    monkeypatch.delenv("UDA_FUSE_IN")
+    monkeypatch.setenv("UDA_PW_SCHEME", "f32")
+    f32, _ = _plan(FULL_MC, chunk_images=2, max_images=4)
+    assert not any(o.get("fuse_in") for o in f32.ops) and sum(o["kind"] == capi.OP_FUSE for o in f32.ops) == 24

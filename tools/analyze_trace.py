@@ -32,15 +32,16 @@ def pmc_per_op(path, counter, scale):
     """bytes per op of the first chunk of the last step, in op order (same selection as the trace)."""
     rr = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
     rr.sort(key=lambda r: int(r["Dispatch_Id"]))
-    ix = [i for i, r in enumerate(rr) if "preprocess" in r["Kernel_Name"]]
+    ix = [i for i, r in enumerate(rr) if "::stem" in r["Kernel_Name"]]      # the stem opens a chunk's op list
     rr = rr[ix[-1]:]
     cv = [r for r in rr if any(n in r["Kernel_Name"] for n in names)]
     return [float(r["Counter_Value"]) * 1024 * scale for r in cv[:len(units)]]
 
 
 rows = list(csv.DictReader(open(a.trace)))
-names = ("stem_kernel", "stem16_kernel", "pw_kernel", "pwb_kernel", "pwb_shared_kernel", "dw_kernel", "se_kernel", "fuse_kernel", "mbx_kernel", "mbxb_kernel", "mbxd_kernel", "mbxp_kernel", "sep_kernel")
-idx = [i for i, r in enumerate(rows) if "preprocess" in r["Kernel_Name"]]
+names = ("stem_kernel", "stem16_kernel", "stem_u8_kernel", "sepf_kernel", "pw_kernel", "pwb_kernel", "pwb_shared_kernel", "dw_kernel", "se_kernel", "fuse_kernel", "mbx_kernel", "mbxb_kernel", "mbxd_kernel", "mbxp_kernel", "sep_kernel")
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if "::stem" in r["Kernel_Name"]]      # the stem opens a chunk's op list (last chunk of the last step)
 rows = rows[idx[-1]:]
 conv = [r for r in rows if any(n in r["Kernel_Name"] for n in names)]
 # launch units: one op, or the ops of a head layer that share a launch (launch_group, plan.py)
@@ -87,7 +88,7 @@ for unit, r in zip(units, first):
     elif o["kind"] == capi.OP_SEP:
         ib = pl.bufs[o["ins"][0]]
         fl = 2 * rows_ * ob.H * ob.W * (9 * ib.C + ib.C * ob.C)
-        desc = "sep %d->%d @%dx%d" % (ib.C, ob.C, ob.H, ob.W)
+        desc = "sep %d->%d @%dx%d" % (ib.C, ob.C, ob.H, ob.W) + (" fin%d" % len(o["ins"]) if o.get("fuse_in") else "")
     else:
         desc = {1: "stem", 4: "se", 5: "fuse", 6: "pool"}[o["kind"]] + " C=%d @%dx%d" % (ob.C, ob.H, ob.W)
     res.append((dur, desc, ob.name, by * 4, fl, r["Kernel_Name"].split("(")[0][-16:], r["VGPR_Count"]))

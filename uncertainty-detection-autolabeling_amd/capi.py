@@ -43,7 +43,7 @@ class Op(C.Structure):
                 ("drop_site", C.c_int32), ("resample", C.c_int32 * MAX_FUSE),
                 ("fuse_w", C.c_float * MAX_FUSE), ("n_in", C.c_int32), ("drop_site2", C.c_int32),
                 ("w2_off", C.c_int64), ("bn2_scale_off", C.c_int64), ("bn2_shift_off", C.c_int64),
-                ("launch_group", C.c_int32), ("reserved0", C.c_int32)]
+                ("launch_group", C.c_int32), ("fuse_in", C.c_int32)]
 
 
 class DropSite(C.Structure):

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "uda_internal.h"
+#include "fuse_sample.h"
 
 namespace uda {
 
@@ -748,35 +749,6 @@ void launch_se(const SeArgs& a, int rows, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------ fusion / pooling
-__device__ __forceinline__ float4 fuse_sample(const FuseArgs& a, int i, int b, int y, int x, int c4) {
-  const int bi = b / a.in_div[i];
-  const float* base = a.in[i] + (size_t)bi * a.Hi[i] * a.Wi[i] * a.C + c4 * 4;
-  if (a.mode[i] == UDA_RS_NONE) {
-    return *(const float4*)(base + ((size_t)y * a.Wi[i] + x) * a.C);
-  }
-  if (a.mode[i] == UDA_RS_NEAREST_UP) {
-    int sy = (int)floorf((float)y * a.sy[i]);
-    int sx = (int)floorf((float)x * a.sx[i]);
-    sy = min(sy, a.Hi[i] - 1);
-    sx = min(sx, a.Wi[i] - 1);
-    return *(const float4*)(base + ((size_t)sy * a.Wi[i] + sx) * a.C);
-  }
-  // max pool, TF SAME: padded taps never win
-  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-  const int y0 = y * a.ps[i] - a.ppt[i], x0 = x * a.ps[i] - a.ppl[i];
-  for (int ky = 0; ky < a.pk[i]; ++ky) {
-    const int iy = y0 + ky;
-    if (iy < 0 || iy >= a.Hi[i]) continue;
-    for (int kx = 0; kx < a.pk[i]; ++kx) {
-      const int ix = x0 + kx;
-      if (ix < 0 || ix >= a.Wi[i]) continue;
-      const float4 v = *(const float4*)(base + ((size_t)iy * a.Wi[i] + ix) * a.C);
-      m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
-    }
-  }
-  return m;
-}
-
 __global__ __launch_bounds__(256) void fuse_kernel(FuseArgs a) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= a.total) return;
@@ -787,19 +759,7 @@ __global__ __launch_bounds__(256) void fuse_kernel(FuseArgs a) {
   p /= a.W;
   const int y = (int)(p % a.H);
   const int b = (int)(p / a.H);
-  float4 s = fuse_sample(a, 0, b, y, x, c4);
-  s.x *= a.wgt[0]; s.y *= a.wgt[0]; s.z *= a.wgt[0]; s.w *= a.wgt[0];
-  for (int i = 1; i < a.n_in; ++i) {
-    const float4 v = fuse_sample(a, i, b, y, x, c4);
-    s.x = fmaf(v.x, a.wgt[i], s.x);
-    s.y = fmaf(v.y, a.wgt[i], s.y);
-    s.z = fmaf(v.z, a.wgt[i], s.z);
-    s.w = fmaf(v.w, a.wgt[i], s.w);
-  }
-  if (a.act == UDA_ACT_SWISH) {
-    s.x = swishf(s.x); s.y = swishf(s.y); s.z = swishf(s.z); s.w = swishf(s.w);
-  }
-  *(float4*)(a.out + (size_t)gid * 4) = s;
+  *(float4*)(a.out + (size_t)gid * 4) = fuse_value(a, b, y, x, c4);     // fuse_sample.h
 }
 
 void launch_fuse(const FuseArgs& a, hipStream_t s) {

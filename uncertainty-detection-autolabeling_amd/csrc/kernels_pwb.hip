@@ -204,36 +204,49 @@ __global__ __launch_bounds__(256, OCC) void pwb_kernel(PwArgs a) {
       const int lcol = (wc * NT + 2 * p) * 32 + 4 * c4;     // column inside the block tile
       const int col = n0 + lcol;
       const bool colok = (col < a.Cout) && (2 * p * 32 + 4 * c4 < NT * 32);
+      // Loads first, all of them and unconditionally (dead lanes read a clamped, valid address), then the arithmetic, then
+      // the eight stores back to back.  Written the obvious way - per row group: staged values, residual load, store, all
+      // under the lane's bounds condition - every row group began with s_waitcnt vmcnt(0): the residual load is younger
+      // than the previous group's store and memory operations retire in order, and even without a residual the compiler
+      // re-waits for the epilogue parameters at each conditional use.  Either way a wave had ONE store in flight.
+      const int colc = colok ? col : 0;
       float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f);
       float4 sh = make_float4(0.f, 0.f, 0.f, 0.f), mk = make_float4(1.f, 1.f, 1.f, 1.f);
-      if (colok) {
-        if (a.bias) bias = *(const float4*)(a.bias + col);
-        if (a.bn_scale) {
-          sc = *(const float4*)(a.bn_scale + col);
-          sh = *(const float4*)(a.bn_shift + col);
+      if (a.bias) bias = *(const float4*)(a.bias + colc);
+      if (a.bn_scale) {
+        sc = *(const float4*)(a.bn_scale + colc);
+        sh = *(const float4*)(a.bn_shift + colc);
+      }
+      if (a.mask) mk = *(const float4*)(a.mask + (size_t)b * a.Cout + colc);
+      const int mrow0 = m0 + (wr * MT + m_) * 32 + rrow;
+      float4 rr[8], v[8];
+      if (a.res) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int mc = mrow0 + it * 4 < a.HW ? mrow0 + it * 4 : a.HW - 1;
+          rr[it] = *(const float4*)(a.res + (res_base + mc) * a.Cout + colc);
         }
-        if (a.mask) mk = *(const float4*)(a.mask + (size_t)b * a.Cout + col);
+      }
+#pragma unroll
+      for (int it = 0; it < 8; ++it) v[it] = *(const float4*)(stg + (it * 4 + rrow) * PWB_STG + 4 * c4);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        float4 t = v[it];
+        t.x = fmaf(fmaf(t.x, un, bias.x), sc.x, sh.x);
+        t.y = fmaf(fmaf(t.y, un, bias.y), sc.y, sh.y);
+        t.z = fmaf(fmaf(t.z, un, bias.z), sc.z, sh.z);
+        t.w = fmaf(fmaf(t.w, un, bias.w), sc.w, sh.w);
+        if (a.act == UDA_ACT_SWISH) {
+          t.x = swishf_b(t.x); t.y = swishf_b(t.y); t.z = swishf_b(t.z); t.w = swishf_b(t.w);
+        }
+        t.x *= mk.x; t.y *= mk.y; t.z *= mk.z; t.w *= mk.w;
+        if (a.res) { t.x += rr[it].x; t.y += rr[it].y; t.z += rr[it].z; t.w += rr[it].w; }
+        v[it] = t;
       }
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
-        const int row = it * 4 + rrow;
-        const int m = m0 + (wr * MT + m_) * 32 + row;
-        if (colok && m < a.HW) {
-          float4 v = *(const float4*)(stg + row * PWB_STG + 4 * c4);
-          v.x = fmaf(fmaf(v.x, un, bias.x), sc.x, sh.x);
-          v.y = fmaf(fmaf(v.y, un, bias.y), sc.y, sh.y);
-          v.z = fmaf(fmaf(v.z, un, bias.z), sc.z, sh.z);
-          v.w = fmaf(fmaf(v.w, un, bias.w), sc.w, sh.w);
-          if (a.act == UDA_ACT_SWISH) {
-            v.x = swishf_b(v.x); v.y = swishf_b(v.y); v.z = swishf_b(v.z); v.w = swishf_b(v.w);
-          }
-          v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
-          if (a.res) {
-            const float4 rr = *(const float4*)(a.res + (res_base + m) * a.Cout + col);
-            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-          }
-          *(float4*)(a.out + (out_base + m) * a.Cout + col) = v;
-        }
+        const int m = mrow0 + it * 4;
+        if (colok && m < a.HW) *(float4*)(a.out + (out_base + m) * a.Cout + col) = v[it];
       }
       __syncthreads();
     }

@@ -1,10 +1,12 @@
 // Fused separable convolution on the bf16 matrix cores (split-precision products as in kernels_pwb.hip).
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <type_traits>
 
 #include "mfma_common.h"
+#include "fuse_sample.h"
 
 namespace uda {
 
@@ -25,7 +27,21 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
   constexpr int BM = SEP_TH * SEP_TW;      // 128 pixels = 4 MFMA row tiles, one per wave
   // the problem of this block (uniform): one conv, or one of the pyramid levels of a head layer launched together
   SepArgs a = m.one;
-  int bx = blockIdx.x;
+  // block -> (sample row b, tile bx): consecutive block ids go round the 8 XCDs, so sample row b's tiles (of all levels) are
+  // given to XCD b mod 8 in order - a tile's halo is then fetched into ONE L2 (rows beyond the last multiple of 8: plain order)
+  int bx, b;
+  {
+    const int L = blockIdx.x, rows8 = m.rows & ~7;
+    if (L < m.tiles * rows8) {
+      const int j = L >> 3;
+      b = (j / m.tiles) * 8 + (L & 7);
+      bx = j % m.tiles;
+    } else {
+      const int l2 = L - m.tiles * rows8;
+      b = rows8 + l2 / m.tiles;
+      bx = l2 % m.tiles;
+    }
+  }
   if (m.n_lv > 0) {
     int l = 0;
     while (l + 1 < m.n_lv && bx >= m.tile0[l + 1]) ++l;
@@ -47,7 +63,7 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
   uint4* Bs = (uint4*)(slds + (size_t)(F32A ? 1 : NPC) * BM * arow);   // [KS][NT][NPC][64 lanes] x 16 B
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, b_in = b / a.in_div;
+  const int b_in = b / a.in_div;
   const int tiles_x = (a.W + SEP_TW - 1) / SEP_TW;
   const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
   const int oy0 = ty * SEP_TH, ox0 = tx * SEP_TW;
@@ -241,35 +257,529 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
     __syncthreads();
     const int col = n0 + 2 * p * 32 + 4 * c4;
     const bool colok = (col < a.Cout) && (2 * p * 32 + 4 * c4 < NT * 32);
+    // parameters and staged values first (unconditional: dead lanes read a clamped, valid column), the arithmetic, then the
+    // eight stores back to back - see pwb_kernel's epilogue: with the loads under the lane's bounds condition every store
+    // was preceded by s_waitcnt vmcnt(0), one store in flight per wave
+    const int colc = colok ? col : 0;
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f);
     float4 sh = make_float4(0.f, 0.f, 0.f, 0.f), mk = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (colok) {
-      if (a.bias) bias = *(const float4*)(a.bias + col);
-      if (a.bn_scale) {
-        sc = *(const float4*)(a.bn_scale + col);
-        sh = *(const float4*)(a.bn_shift + col);
+    if (a.bias) bias = *(const float4*)(a.bias + colc);
+    if (a.bn_scale) {
+      sc = *(const float4*)(a.bn_scale + colc);
+      sh = *(const float4*)(a.bn_shift + colc);
+    }
+    if (a.mask) mk = *(const float4*)(a.mask + (size_t)b * a.Cout + colc);
+    float4 v[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) v[it] = *(const float4*)(stg + (it * 4 + rrow) * PWB_STG + 4 * c4);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      float4 t = v[it];
+      t.x = fmaf(fmaf(t.x, un, bias.x), sc.x, sh.x);
+      t.y = fmaf(fmaf(t.y, un, bias.y), sc.y, sh.y);
+      t.z = fmaf(fmaf(t.z, un, bias.z), sc.z, sh.z);
+      t.w = fmaf(fmaf(t.w, un, bias.w), sc.w, sh.w);
+      if (a.act == UDA_ACT_SWISH) {
+        t.x = swishf_b(t.x); t.y = swishf_b(t.y); t.z = swishf_b(t.z); t.w = swishf_b(t.w);
       }
-      if (a.mask) mk = *(const float4*)(a.mask + (size_t)b * a.Cout + col);
+      t.x *= mk.x; t.y *= mk.y; t.z *= mk.z; t.w *= mk.w;
+      v[it] = t;
     }
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const int row = it * 4 + rrow;
       size_t pix;
-      if (colok && pixel_of(wave * 32 + row, pix)) {
-        float4 v = *(const float4*)(stg + row * PWB_STG + 4 * c4);
-        v.x = fmaf(fmaf(v.x, un, bias.x), sc.x, sh.x);
-        v.y = fmaf(fmaf(v.y, un, bias.y), sc.y, sh.y);
-        v.z = fmaf(fmaf(v.z, un, bias.z), sc.z, sh.z);
-        v.w = fmaf(fmaf(v.w, un, bias.w), sc.w, sh.w);
-        if (a.act == UDA_ACT_SWISH) {
-          v.x = swishf_b(v.x); v.y = swishf_b(v.y); v.z = swishf_b(v.z); v.w = swishf_b(v.w);
-        }
-        v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
-        *(float4*)(a.out + (out_base + pix) * a.Cout + col) = v;
-      }
+      if (pixel_of(wave * 32 + it * 4 + rrow, pix) && colok) *(float4*)(a.out + (out_base + pix) * a.Cout + col) = v[it];
     }
     __syncthreads();
   }
+}
+
+// ---------------------------------------------------------------- separable convolution on an LDS-staged input tile
+// sepf_kernel: the same arithmetic as sep_kernel (same depthwise FMA order, same split, same MFMA order: bit-identical
+// outputs), organised around an input tile in LDS instead of a depthwise image in LDS, so that the INPUT can be something
+// that is computed rather than read - the BiFPN fusion act(sum_i w_i resample_i(in_i)) of the node the separable conv
+// belongs to (FIN; efficientdet_keras.py:90-136 + 207-227): the fused tensor never goes to HBM, fuse_kernel's launch, its
+// write and this kernel's read of it disappear.
+//   tile      16 x 16 outputs per block of four waves (halo 18 x 18: 1.27x instead of 1.41x for 8 x 16), staged 32 channels
+//             at a time as [324 pixels][32 + 4] float32 (46.6 KB; the k-steps of a pass accumulate into the same accumulators)
+//   depthwise a wave owns four tile rows = two MFMA row tiles; lane (li, lh) computes pixel li of row tile lh, EIGHT channels
+//             at a time - the same eight channels on every lane, so the 72 taps of a channel group are wave-uniform (scalar
+//             loads, scalar operands of the FMAs: no LDS or vector-memory traffic for the taps); its window arrives in 18
+//             ds_read_b128 (pitch 36 dwords: the 16 pixels of a tile row cover the 64 banks exactly once)
+//   fragments two channel groups make one k-step: lane halves trade them with v_permlane32_swap (upper half of group 0 <->
+//             lower half of group 1) and each operand register is then the A fragment of row tile 0 / row tile 1 - no LDS
+//             round trip of the depthwise result, no second barrier
+constexpr int SF_T = 16, SF_TP = SF_T + 2, SF_NPX = SF_TP * SF_TP;      // (channels per pass PC, tile pitch PC + 4: template)
+
+__device__ __forceinline__ void swap_halves(bf16x8& a, bf16x8& b) {      // a[32..63] <-> b[0..31], per 32-bit register
+  uint4 ua = __builtin_bit_cast(uint4, a), ub = __builtin_bit_cast(uint4, b);
+  auto r0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
+  auto r1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
+  auto r2 = __builtin_amdgcn_permlane32_swap(ua.z, ub.z, false, false);
+  auto r3 = __builtin_amdgcn_permlane32_swap(ua.w, ub.w, false, false);
+  a = __builtin_bit_cast(bf16x8, make_uint4(r0[0], r1[0], r2[0], r3[0]));
+  b = __builtin_bit_cast(bf16x8, make_uint4(r0[1], r1[1], r2[1], r3[1]));
+}
+
+// One resampled input of the fusion at the (clamped, in-map) output position (y, x), mode known at compile time, loads
+// unconditional: out-of-range pool taps are read at a clamped position and replaced by -inf, which is what skipping them
+// does to a running maximum (fuse_sample) - same taps in the same order, same bits.
+template <int MODE>
+__device__ __forceinline__ float4 fuse_sample_t(const FuseArgs& a, int i, int b, int y, int x, int c4) {
+  const int bi = b / a.in_div[i];
+  const float* base = a.in[i] + (size_t)bi * a.Hi[i] * a.Wi[i] * a.C + c4 * 4;
+  if constexpr (MODE == UDA_RS_NONE) {
+    return *(const float4*)(base + ((size_t)y * a.Wi[i] + x) * a.C);
+  } else if constexpr (MODE == UDA_RS_NEAREST_UP) {
+    int sy = (int)floorf((float)y * a.sy[i]);
+    int sx = (int)floorf((float)x * a.sx[i]);
+    sy = min(sy, a.Hi[i] - 1);
+    sx = min(sx, a.Wi[i] - 1);
+    return *(const float4*)(base + ((size_t)sy * a.Wi[i] + sx) * a.C);
+  } else {                                   // 3 x 3 / stride 2 max pool (the launcher checked pk == 3, ps == 2)
+    const int y0 = y * 2 - a.ppt[i], x0 = x * 2 - a.ppl[i];
+    float4 t[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = min(max(y0 + ky, 0), a.Hi[i] - 1), ix = min(max(x0 + kx, 0), a.Wi[i] - 1);
+        t[ky * 3 + kx] = *(const float4*)(base + ((size_t)iy * a.Wi[i] + ix) * a.C);
+      }
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const bool ok = y0 + ky >= 0 && y0 + ky < a.Hi[i] && x0 + kx >= 0 && x0 + kx < a.Wi[i];
+        const float4 v = t[ky * 3 + kx];
+        m.x = fmaxf(m.x, ok ? v.x : -INFINITY); m.y = fmaxf(m.y, ok ? v.y : -INFINITY);
+        m.z = fmaxf(m.z, ok ? v.z : -INFINITY); m.w = fmaxf(m.w, ok ? v.w : -INFINITY);
+      }
+    return m;
+  }
+}
+
+// fuse_value (fuse_sample.h) for a compile-time list of modes (M2 < 0: two inputs), swish on
+template <int M0, int M1, int M2>
+__device__ __forceinline__ float4 fuse_value_t(const FuseArgs& a, int b, int y, int x, int c4) {
+  float4 s = fuse_sample_t<M0>(a, 0, b, y, x, c4);
+  s.x *= a.wgt[0]; s.y *= a.wgt[0]; s.z *= a.wgt[0]; s.w *= a.wgt[0];
+  {
+    const float4 v = fuse_sample_t<M1>(a, 1, b, y, x, c4);
+    s.x = fmaf(v.x, a.wgt[1], s.x); s.y = fmaf(v.y, a.wgt[1], s.y);
+    s.z = fmaf(v.z, a.wgt[1], s.z); s.w = fmaf(v.w, a.wgt[1], s.w);
+  }
+  if constexpr (M2 >= 0) {
+    const float4 v = fuse_sample_t<M2>(a, 2, b, y, x, c4);
+    s.x = fmaf(v.x, a.wgt[2], s.x); s.y = fmaf(v.y, a.wgt[2], s.y);
+    s.z = fmaf(v.z, a.wgt[2], s.z); s.w = fmaf(v.w, a.wgt[2], s.w);
+  }
+  s.x = fuse_swish(s.x); s.y = fuse_swish(s.y); s.z = fuse_swish(s.z); s.w = fuse_swish(s.w);
+  return s;
+}
+
+// mode signatures with a batched staging path (everything else: the generic, one-element-at-a-time loop)
+enum { SF_SIG_GENERIC = 0, SF_SIG_PLAIN = 1, SF_SIG_NU = 2, SF_SIG_NNP = 3, SF_SIG_NP = 4 };
+
+// Stage one 32-channel pass of the 18 x 18 input tile: U elements (pixel, channel quad) per thread and round with ALL their
+// loads in flight before the first use - the block has one memory latency per round, not one per element.
+template <int SIG, int U, int PC>
+__device__ __forceinline__ void sepf_stage(const SepArgs& a, const FuseArgs& f, float* T, const float* inb, int b, int oy0, int ox0,
+                                           int c0, int pc4, int tid) {
+  constexpr int SF_PITCH = PC + 4, FULL4 = PC / 4;
+  const int H = a.H, W = a.W, C = a.C;
+  const int ne = SF_NPX * pc4;
+  for (int e0 = tid; e0 < ne; e0 += 256 * U) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + 256 * u < ne ? e0 + 256 * u : tid;       // (a dead slot repeats a live element: valid addresses)
+      const int px = pc4 == FULL4 ? e / FULL4 : e / pc4, q = e - px * pc4;
+      const int sy = px / SF_TP, sx = px - sy * SF_TP;
+      const int y = oy0 - 1 + sy, x = ox0 - 1 + sx;
+      const bool inside = y >= 0 && y < H && x >= 0 && x < W;
+      const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
+      const int c4 = (c0 >> 2) + q;
+      float4 t;
+      if constexpr (SIG == SF_SIG_PLAIN) t = *(const float4*)(inb + ((size_t)yc * W + xc) * C + 4 * c4);
+      else if constexpr (SIG == SF_SIG_NU) t = fuse_value_t<UDA_RS_NONE, UDA_RS_NEAREST_UP, -1>(f, b, yc, xc, c4);
+      else if constexpr (SIG == SF_SIG_NNP) t = fuse_value_t<UDA_RS_NONE, UDA_RS_NONE, UDA_RS_MAXPOOL>(f, b, yc, xc, c4);
+      else t = fuse_value_t<UDA_RS_NONE, UDA_RS_MAXPOOL, -1>(f, b, yc, xc, c4);
+      v[u] = inside ? t : make_float4(0.f, 0.f, 0.f, 0.f);     // SAME padding of the depthwise conv: zeros outside the map
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + 256 * u;
+      if (e < ne) {
+        const int px = pc4 == FULL4 ? e / FULL4 : e / pc4, q = e - px * pc4;
+        *(float4*)(T + px * SF_PITCH + 4 * q) = v[u];
+      }
+    }
+  }
+}
+
+#ifdef UDA_SEPF_STAMPS
+// diagnostic build (-DUDA_SEPF_STAMPS, A/B libraries only): shader-clock cycles every wave of the LARGE launches (maps of at
+// least 96 x 160) spends in the phases of a block: [0] weight fragments + staging of a pass (requests, wait, fusion, LDS
+// writes), [1] barrier behind it, [2] depthwise + matrix stage, [3] barrier in front of the next pass, [4] epilogue + stores,
+// [5] everything up to the first pass, [6] blocks
+__device__ unsigned long long g_sepf_stamps[64 * 8];      // 64 copies (block id mod 64): the atomics of a launch do not queue on one line
+static void sepf_stamp_dump() {
+  unsigned long long h[8] = {}, all[64 * 8] = {};
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(all, HIP_SYMBOL(g_sepf_stamps), sizeof(all)) != hipSuccess) return;
+  for (int i = 0; i < 64 * 8; ++i) h[i & 7] += all[i];
+  if (!h[6]) return;
+  const char* nm[6] = {"staging", "barrier after staging", "depthwise + matrix", "barrier before staging", "epilogue", "prologue"};
+  unsigned long long tot = 0;
+  for (int i = 0; i < 6; ++i) tot += h[i];
+  fprintf(stderr, "[sepf stamps] %llu waves, %.0f cycles = %.2f us (100 MHz wall clock) each:", h[6], (double)tot / (double)h[6], (double)h[7] / (double)h[6] / 100.0);
+  for (int i = 0; i < 6; ++i) fprintf(stderr, "  %s %.0f (%.0f %%)", nm[i], (double)h[i] / (double)h[6], 100.0 * (double)h[i] / (double)tot);
+  fprintf(stderr, "\n");
+}
+#define SEPF_STAMP(i) do { const unsigned long long t_ = clock64(); st_acc[i] += t_ - st_t; st_t = t_; } while (0)
+#else
+#define SEPF_STAMP(i) do { } while (0)
+#endif
+
+// The same in two halves for the pipelined kernel: sepf_issue requests the raw values of a whole pass (U elements per
+// thread, NR = 1 plain | 2 identity + nearest-up), sepf_finish combines them (fuse_value_t's expression) and writes the tile.
+// Between the two the kernel computes the previous pass: the memory latency of passes 1.. hides behind the matrix stage.
+template <bool FIN, int U, int PC>
+__device__ __forceinline__ void sepf_issue(const SepArgs& a, const FuseArgs& f, float4 (&raw)[U][FIN ? 2 : 1], const float* inb, int b,
+                                           int oy0, int ox0, int c0, int pc4, int tid) {
+  constexpr int FULL4 = PC / 4;
+  const int H = a.H, W = a.W, C = a.C;
+  const int ne = SF_NPX * pc4;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int e = tid + 256 * u < ne ? tid + 256 * u : tid;
+    const int px = pc4 == FULL4 ? e / FULL4 : e / pc4, q = e - px * pc4;
+    const int sy = px / SF_TP, sx = px - sy * SF_TP;
+    const int yc = min(max(oy0 - 1 + sy, 0), H - 1), xc = min(max(ox0 - 1 + sx, 0), W - 1);
+    const int c4 = (c0 >> 2) + q;
+    if constexpr (FIN) {
+      raw[u][0] = fuse_sample_t<UDA_RS_NONE>(f, 0, b, yc, xc, c4);
+      raw[u][1] = fuse_sample_t<UDA_RS_NEAREST_UP>(f, 1, b, yc, xc, c4);
+    } else {
+      raw[u][0] = *(const float4*)(inb + ((size_t)yc * W + xc) * C + 4 * c4);
+    }
+  }
+}
+template <bool FIN, int U, int PC>
+__device__ __forceinline__ void sepf_finish(const SepArgs& a, const FuseArgs& f, const float4 (&raw)[U][FIN ? 2 : 1], float* T,
+                                            int oy0, int ox0, int pc4, int tid) {
+  constexpr int SF_PITCH = PC + 4, FULL4 = PC / 4;
+  const int ne = SF_NPX * pc4;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int e = tid + 256 * u;
+    if (e < ne) {
+      const int px = pc4 == FULL4 ? e / FULL4 : e / pc4, q = e - px * pc4;
+      const int sy = px / SF_TP, sx = px - sy * SF_TP;
+      const int y = oy0 - 1 + sy, x = ox0 - 1 + sx;
+      float4 s = raw[u][0];
+      if constexpr (FIN) {
+        const float4 v = raw[u][1];
+        s.x *= f.wgt[0]; s.y *= f.wgt[0]; s.z *= f.wgt[0]; s.w *= f.wgt[0];
+        s.x = fmaf(v.x, f.wgt[1], s.x); s.y = fmaf(v.y, f.wgt[1], s.y);
+        s.z = fmaf(v.z, f.wgt[1], s.z); s.w = fmaf(v.w, f.wgt[1], s.w);
+        s.x = fuse_swish(s.x); s.y = fuse_swish(s.y); s.z = fuse_swish(s.z); s.w = fuse_swish(s.w);
+      }
+      if (!(y >= 0 && y < a.H && x >= 0 && x < a.W)) s = make_float4(0.f, 0.f, 0.f, 0.f);
+      *(float4*)(T + px * SF_PITCH + 4 * q) = s;
+    }
+  }
+}
+
+// PC = channels per pass: 32 | 16.  PIPE (plain input / identity + nearest-up fusion only): the next pass's values are
+// requested before the current pass is computed.
+template <int NT, int PARTS, bool FIN, int PC, bool PIPE>
+__global__ __launch_bounds__(256, (PC == 16 && !PIPE) ? 3 : 2) void sepf_kernel(SepArgs a, FuseArgs f, int sig, int rows) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char slds[];
+  constexpr int NPC = split_np(PARTS);
+  constexpr int SF_PC = PC, SF_PITCH = PC + 4;
+  float* T = (float*)slds;                                              // [324][PC + 4] staged input tile, one channel pass
+  uint4* Bs = (uint4*)(slds + (size_t)SF_NPX * SF_PITCH * 4);           // [PC / 16 k-steps][NT][NPC][64 lanes] x 16 B
+  const int C = a.C, H = a.H, W = a.W;
+  const int NTL = (a.Cout + 31) >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int tiles_x = (W + SF_T - 1) / SF_T;
+  // Block -> (sample row b, tile): consecutive block ids go round the 8 XCDs (each with its own L2), so the tiles of one
+  // sample row are given to ONE XCD - sample rows b = xcd (mod 8), tiles in order - and the halo a tile shares with its
+  // neighbours is fetched into that L2 once (rows beyond the last multiple of 8: plain order).
+  int b, tile;
+  {
+    const int ntile = tiles_x * ((H + SF_T - 1) / SF_T);
+    const int L = blockIdx.x, rows8 = rows & ~7;
+    if (L < ntile * rows8) {
+      const int xcd = L & 7, j = L >> 3;
+      b = (j / ntile) * 8 + xcd;
+      tile = j % ntile;
+    } else {
+      const int l2 = L - ntile * rows8;
+      b = rows8 + l2 / ntile;
+      tile = l2 % ntile;
+    }
+  }
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int oy0 = ty * SF_T, ox0 = tx * SF_T;
+  // this lane's output pixel inside the tile = top-left corner of its 3 x 3 window in staged coordinates
+  const int pr = 4 * wave + 2 * lh + (li >> 4), pcx = li & 15;
+  const float* tbase = T + (pr * SF_TP + pcx) * SF_PITCH;
+  const uint4* Wp = (const uint4*)a.wsplit;
+  const float* inb = FIN ? nullptr : a.in + (size_t)(b / a.in_div) * H * W * C;
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][n][r] = 0.f;
+  float amax = 0.f;
+
+#ifdef UDA_SEPF_STAMPS
+  unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = clock64();
+  const unsigned long long st_w0 = wall_clock64();
+#endif
+  const int npass = (C + SF_PC - 1) / SF_PC;
+  constexpr int UP = (SF_NPX * (PC / 4) + 255) / 256;      // elements per thread of a whole pass
+  float4 raw[PIPE ? UP : 1][FIN ? 2 : 1];
+  if constexpr (PIPE) sepf_issue<FIN, UP, PC>(a, f, raw, inb, b, oy0, ox0, 0, (C < SF_PC ? C : SF_PC) >> 2, tid);
+  for (int ps = 0; ps < npass; ++ps) {
+    const int c0 = ps * SF_PC;
+    const int pch = C - c0 < SF_PC ? C - c0 : SF_PC;      // channels of this pass (a multiple of 8)
+    const int pc4 = pch >> 2;
+    const int nks = (pch + 15) >> 4;
+    if (ps) SEPF_STAMP(2); else SEPF_STAMP(5);
+    if (ps) __syncthreads();                              // every wave is done with the previous pass's tile and fragments
+    SEPF_STAMP(3);
+    for (int i = tid; i < nks * NT * NPC * 64; i += 256) {
+      int q = i >> 6;
+      const int part = q % NPC; q /= NPC;
+      const int nt = q % NT, ksl = q / NT;
+      Bs[i] = nt < NTL ? Wp[(((size_t)(ps * (PC / 16) + ksl) * NTL + nt) * NPC + part) * 64 + (i & 63)] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    if constexpr (PIPE) {
+      sepf_finish<FIN, UP, PC>(a, f, raw, T, oy0, ox0, pc4, tid);
+      if (ps + 1 < npass) {
+        const int c1 = c0 + SF_PC;
+        sepf_issue<FIN, UP, PC>(a, f, raw, inb, b, oy0, ox0, c1, (C - c1 < SF_PC ? C - c1 : SF_PC) >> 2, tid);
+      }
+    } else if constexpr (!FIN) {
+      sepf_stage<SF_SIG_PLAIN, PC == 16 ? 6 : 11, PC>(a, f, T, inb, b, oy0, ox0, c0, pc4, tid);
+    } else if (sig == SF_SIG_NU) {
+      sepf_stage<SF_SIG_NU, PC == 16 ? 6 : 11, PC>(a, f, T, inb, b, oy0, ox0, c0, pc4, tid);
+    } else if (sig == SF_SIG_NNP) {
+      sepf_stage<SF_SIG_NNP, PC == 16 ? 1 : 3, PC>(a, f, T, inb, b, oy0, ox0, c0, pc4, tid);
+    } else if (sig == SF_SIG_NP) {
+      sepf_stage<SF_SIG_NP, PC == 16 ? 1 : 3, PC>(a, f, T, inb, b, oy0, ox0, c0, pc4, tid);
+    } else {
+      for (int e = tid; e < SF_NPX * pc4; e += 256) {
+        const int px = e / pc4, q = e - px * pc4;
+        const int sy = px / SF_TP, sx = px - sy * SF_TP;
+        const int y = oy0 - 1 + sy, x = ox0 - 1 + sx;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y >= 0 && y < H && x >= 0 && x < W) v = fuse_value(f, b, y, x, (c0 >> 2) + q);
+        *(float4*)(T + px * SF_PITCH + 4 * q) = v;
+      }
+    }
+    SEPF_STAMP(0);
+    __syncthreads();
+    SEPF_STAMP(1);
+
+    for (int ksl = 0; ksl < nks; ++ksl) {
+      bf16x8 fr[2][NPC];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int cl = ksl * 16 + g * 8;                  // channel offset inside the pass (uniform)
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+        if (cl < pch) {
+          const float* wt = a.wd + c0 + cl;               // uniform address: scalar loads
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+              const float* p = tbase + (ky * SF_TP + kx) * SF_PITCH + cl;
+              const float4 v0 = *(const float4*)p, v1 = *(const float4*)(p + 4);
+              const float* w = wt + (size_t)(ky * 3 + kx) * C;
+              r0.x = fmaf(v0.x, w[0], r0.x); r0.y = fmaf(v0.y, w[1], r0.y);
+              r0.z = fmaf(v0.z, w[2], r0.z); r0.w = fmaf(v0.w, w[3], r0.w);
+              r1.x = fmaf(v1.x, w[4], r1.x); r1.y = fmaf(v1.y, w[5], r1.y);
+              r1.z = fmaf(v1.z, w[6], r1.z); r1.w = fmaf(v1.w, w[7], r1.w);
+            }
+        }
+        split_parts<PARTS>(r0, r1, fr[g], amax);
+      }
+#pragma unroll
+      for (int p = 0; p < NPC; ++p) swap_halves(fr[0][p], fr[1][p]);    // fr[t] = A fragment of row tile t
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        bf16x8 bf[NPC];
+#pragma unroll
+        for (int p = 0; p < NPC; ++p) bf[p] = __builtin_bit_cast(bf16x8, Bs[((ksl * NT + n) * NPC + p) * 64 + lane]);
+        acc[0][n] = mfma_terms<PARTS>(fr[0], bf, acc[0][n]);
+        acc[1][n] = mfma_terms<PARTS>(fr[1], bf, acc[1][n]);
+      }
+    }
+  }
+  split_report<PARTS>(amax, a.oor);
+  SEPF_STAMP(2);
+  __syncthreads();      // the staging rows below alias the tile
+  SEPF_STAMP(3);
+
+  // epilogue: per wave, 32 x 64 values at a time through its own staging rows, out as float4 along the channels
+  float* stg = (float*)slds + wave * 32 * PWB_STG;
+  const size_t out_base = (size_t)b * H * W;
+  const float un = a.wunscale;
+  const int rrow = lane >> 4, c4 = lane & 15;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int p = 0; p < (NT + 1) / 2; ++p) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int n = 2 * p + q;
+        if (n < NT) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * PWB_STG + q * 32 + li] = acc[t][n][r];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int col = 2 * p * 32 + 4 * c4;
+      const bool colok = col < a.Cout && col < NT * 32;
+      const int colc = colok ? col : 0;            // (loads unconditional, stores back to back: see pwb_kernel's epilogue)
+      float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f);
+      float4 sh = make_float4(0.f, 0.f, 0.f, 0.f), mk = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (a.bias) bias = *(const float4*)(a.bias + colc);
+      if (a.bn_scale) {
+        sc = *(const float4*)(a.bn_scale + colc);
+        sh = *(const float4*)(a.bn_shift + colc);
+      }
+      if (a.mask) mk = *(const float4*)(a.mask + (size_t)b * a.Cout + colc);
+      float4 v[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) v[it] = *(const float4*)(stg + (it * 4 + rrow) * PWB_STG + 4 * c4);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        float4 w = v[it];
+        w.x = fmaf(fmaf(w.x, un, bias.x), sc.x, sh.x);
+        w.y = fmaf(fmaf(w.y, un, bias.y), sc.y, sh.y);
+        w.z = fmaf(fmaf(w.z, un, bias.z), sc.z, sh.z);
+        w.w = fmaf(fmaf(w.w, un, bias.w), sc.w, sh.w);
+        if (a.act == UDA_ACT_SWISH) {
+          w.x = swishf_b(w.x); w.y = swishf_b(w.y); w.z = swishf_b(w.z); w.w = swishf_b(w.w);
+        }
+        w.x *= mk.x; w.y *= mk.y; w.z *= mk.z; w.w *= mk.w;
+        v[it] = w;
+      }
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + rrow;                                  // row of the 32-pixel row tile
+        const int y = oy0 + 4 * wave + 2 * t + (row >> 4), x = ox0 + (row & 15);
+        if (colok && y < H && x < W) *(float4*)(a.out + (out_base + (size_t)y * W + x) * a.Cout + col) = v[it];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+#ifdef UDA_SEPF_STAMPS
+  SEPF_STAMP(4);
+  if (tid == 0 && a.H * a.W >= 96 * 160) {      // wave 0 speaks for the block
+    unsigned long long* g = g_sepf_stamps + (blockIdx.x & 63) * 8;
+    for (int i = 0; i < 6; ++i) atomicAdd(&g[i], st_acc[i]);
+    atomicAdd(&g[6], 1ull);
+    atomicAdd(&g[7], wall_clock64() - st_w0);
+  }
+#endif
+}
+
+// channels per pass / pipelining per staging signature: plain and identity + nearest-up inputs run 16-channel passes with the
+// next pass requested ahead; pooled inputs read a 2x larger map, where 64-byte pieces of a pixel doubled the traffic
+// (half-used 128-byte lines): 32-channel passes, not pipelined (11 raw values per element).  UDA_SEPF_PC / UDA_SEPF_PIPE: A/B.
+static void sepf_cfg(int sig, int* pc, int* pipe) {
+  static int epc = -1, epipe = -1;
+  if (epc < 0) {
+    const char* e = getenv("UDA_SEPF_PC"); epc = e ? atoi(e) : 0;
+    const char* q = getenv("UDA_SEPF_PIPE"); epipe = q ? atoi(q) : 0;
+  }
+  const bool simple = sig == SF_SIG_PLAIN || sig == SF_SIG_NU;
+  *pipe = simple && epipe;
+  *pc = epc == 16 || epc == 32 ? epc : (simple ? 16 : 32);
+}
+
+size_t sepf_lds_bytes(int C, int Cout, int scheme) {      // (the larger of the configurations)
+  const int nt = (Cout + 31) / 32, npc = uda_split_pieces(scheme);
+  size_t lds = (size_t)SF_NPX * 36 * 4 + (size_t)2 * nt * npc * 1024;
+  const size_t stg = (size_t)4 * 32 * PWB_STG * 4;
+  return lds < stg ? stg : lds;
+}
+
+bool sepf_supported(int C, int Cout, int scheme) {
+  return scheme != UDA_SPLIT_NONE && C % 8 == 0 && C >= 16 && C <= 128 && Cout % 4 == 0 && Cout >= 4 && Cout <= 128 &&
+         sepf_lds_bytes(C, Cout, scheme) <= 80 * 1024;
+}
+
+template <int NT, bool FIN>
+static void launch_sepf_nt(const SepArgs& a, const FuseArgs& f, int rows, hipStream_t s) {
+  const dim3 grid(((a.W + SF_T - 1) / SF_T) * ((a.H + SF_T - 1) / SF_T) * rows);
+  // which batched staging path fits the fusion (uniform switch inside the kernel)
+  int sig = SF_SIG_GENERIC;
+  if (!FIN) sig = SF_SIG_PLAIN;
+  else if (f.act == UDA_ACT_SWISH && !getenv("UDA_SEPF_GENERIC")) {
+    auto pool_ok = [&](int i) { return f.mode[i] == UDA_RS_MAXPOOL && f.pk[i] == 3 && f.ps[i] == 2; };
+    if (f.n_in == 2 && f.mode[0] == UDA_RS_NONE && f.mode[1] == UDA_RS_NEAREST_UP) sig = SF_SIG_NU;
+    else if (f.n_in == 3 && f.mode[0] == UDA_RS_NONE && f.mode[1] == UDA_RS_NONE && pool_ok(2)) sig = SF_SIG_NNP;
+    else if (f.n_in == 2 && f.mode[0] == UDA_RS_NONE && pool_ok(1)) sig = SF_SIG_NP;
+  }
+  int pc, pipe;
+  sepf_cfg(sig, &pc, &pipe);
+  const int npc = uda_split_pieces(a.wparts);
+  size_t lds = (size_t)SF_NPX * (pc + 4) * 4 + (size_t)(pc / 16) * NT * npc * 1024;
+  const size_t stg = (size_t)4 * 32 * PWB_STG * 4;
+  if (lds < stg) lds = stg;
+  auto go = [&](auto kern) {
+    static size_t attr_lds = 64 * 1024;
+    if (lds > attr_lds) {
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_lds = lds;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a, f, sig, rows);
+#ifdef UDA_SEPF_STAMPS
+    static int n_launch = 0;
+    if (a.H * a.W >= 96 * 160 && ++n_launch % 9 == 0) sepf_stamp_dump();
+#endif
+  };
+  auto by_scheme = [&](auto pcv, auto pipev) {
+    constexpr int PC = decltype(pcv)::value;
+    constexpr bool PIPE = decltype(pipev)::value;
+    if (a.wparts == UDA_SPLIT_BF16X3) go(sepf_kernel<NT, 3, FIN, PC, PIPE>);
+    else if (a.wparts == UDA_SPLIT_F16X2) go(sepf_kernel<NT, 4, FIN, PC, PIPE>);
+    else go(sepf_kernel<NT, 2, FIN, PC, PIPE>);
+  };
+  if (pipe) {
+    if (pc == 16) by_scheme(std::integral_constant<int, 16>{}, std::true_type{});
+    else by_scheme(std::integral_constant<int, 32>{}, std::true_type{});
+  } else {
+    if (pc == 16) by_scheme(std::integral_constant<int, 16>{}, std::false_type{});
+    else by_scheme(std::integral_constant<int, 32>{}, std::false_type{});
+  }
+}
+
+// fused != nullptr: the conv's input is the BiFPN fusion described by *fused (a.in unused)
+void launch_sepf(const SepArgs& a, const FuseArgs* fused, int rows, hipStream_t s) {
+  const int ntl = (a.Cout + 31) / 32;
+  FuseArgs f{};
+  if (fused) f = *fused;
+  auto pick = [&](auto fin) {
+    constexpr bool FIN = decltype(fin)::value;
+    if (ntl == 1) launch_sepf_nt<1, FIN>(a, f, rows, s);
+    else if (ntl == 2) launch_sepf_nt<2, FIN>(a, f, rows, s);
+    else if (ntl == 3) launch_sepf_nt<3, FIN>(a, f, rows, s);
+    else launch_sepf_nt<4, FIN>(a, f, rows, s);
+  };
+  if (fused) pick(std::true_type{}); else pick(std::false_type{});
 }
 
 bool sep_supported(int C, int Cout) { return C % 8 == 0 && C >= 16 && C <= 128 && Cout >= 1; }
@@ -285,14 +795,18 @@ static void launch_sep_nt(const SepMulti& m, int rows, int gy, hipStream_t s) {
   size_t lds = a_img + (size_t)KS * NT * npc * 1024;
   const size_t stg = (a.Cout & 3) ? (size_t)4 * 32 * NT * 32 * 4 : (size_t)4 * 32 * PWB_STG * 4;     // epilogue staging (packed rows | float4 tiles)
   if (lds < stg) lds = stg;
-  const dim3 grid(m.n_lv > 0 ? m.tile0[m.n_lv] : sep_tiles(a.H, a.W), gy, rows);
+  SepMulti mm = m;
+  mm.tiles = m.n_lv > 0 ? m.tile0[m.n_lv] : sep_tiles(a.H, a.W);
+  static const bool remap = !(getenv("UDA_SEP_REMAP") && atoi(getenv("UDA_SEP_REMAP")) == 0);     // (0: plain block order, A/B)
+  mm.rows = remap ? rows : 0;
+  const dim3 grid(mm.tiles * rows, gy);
   auto go = [&](auto kern) {
     static size_t attr_lds = 64 * 1024;
     if (lds > attr_lds) {
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_lds = lds;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, m);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, mm);
   };
   static int occ = -1;
   if (occ < 0) { const char* e = getenv("UDA_SEP_OCC"); occ = e ? atoi(e) : 3; }   // 3 blocks per CU: measured 14 % faster than 2

@@ -452,8 +452,13 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
       uda_destroy(c);
       return 1;
     }
+    if (o.fuse_in && o.kind != UDA_OP_SEP) {
+      fail(nullptr, "op %d: fuse_in is a separable-conv field (kind %d)", i, o.kind);
+      uda_destroy(c);
+      return 1;
+    }
     if (o.kind == UDA_OP_SEP && (o.w_off < 0 || o.w2_off < 0 || !sep_supported(bufs[o.in[0]].C, bufs[o.out].C) ||
-                                 bufs[o.in[0]].H != bufs[o.out].H || bufs[o.in[0]].W != bufs[o.out].W)) {
+                                 (!o.fuse_in && (bufs[o.in[0]].H != bufs[o.out].H || bufs[o.in[0]].W != bufs[o.out].W)))) {
       fail(nullptr, "op %d: fused separable conv %d->%d unsupported (needs both kernels, C %% 8 == 0, 16 <= C <= 128, same size)",
            i, bufs[o.in[0]].C, bufs[o.out].C);
       uda_destroy(c);
@@ -588,7 +593,14 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
         const int K = bufs[o.in[0]].C, Nn = bufs[o.out].C;
         size_t lds = 0;
         if (o.kind == UDA_OP_MBX) lds = mbx_lds_bytes(o.se_scale >= 0 ? o.se_mid : K, Nn, o.k, o.stride, c->wscheme[i], bufs[o.out].H, bufs[o.out].W);
-        else if (o.kind == UDA_OP_SEP) lds = sep_lds_bytes(K, Nn, c->wscheme[i]);
+        else if (o.kind == UDA_OP_SEP) {
+          lds = o.fuse_in ? sepf_lds_bytes(K, Nn, c->wscheme[i]) : sep_lds_bytes(K, Nn, c->wscheme[i]);
+          if (o.fuse_in && !sepf_supported(K, Nn, c->wscheme[i])) {
+            fail(nullptr, "op %d: separable conv %d -> %d (split scheme %d) has no fused-input kernel (planner: plan.sepf_supported)", i, K, Nn, c->wscheme[i]);
+            uda_destroy(c);
+            return 1;
+          }
+        }
         if (lds > (size_t)160 * 1024) {
           fail(nullptr, "op %d (%s, %d -> %d channels, k %d, stride %d, split scheme %d): its launch needs %zu bytes of LDS, a gfx950 "
                         "CU has 163840", i, o.kind == UDA_OP_MBX ? "fused MBConv front half" : "fused separable conv", K, Nn, o.k, o.stride,
@@ -954,6 +966,45 @@ struct ChunkView {
   }
 };
 
+// FuseArgs of op oi's inputs (FUSE / POOL, and SEP with fuse_in: the BiFPN fusion in front of the node's separable conv)
+static int fill_fuse_args(uda_ctx* c, const ChunkView& v, int oi, FuseArgs& a) {
+  const uda_op_t& o = c->ops[oi];
+  const uda_buf_desc_t& ob = c->bufs[o.out];
+  a.n_in = o.n_in;
+  a.H = ob.H; a.W = ob.W;
+  if (o.n_in < 1 || o.n_in > UDA_MAX_FUSE_INPUTS) return fail(c, "op %d: %d fusion inputs", oi, o.n_in);
+  a.C = c->bufs[o.in[0]].C;
+  if (a.C % 4) return fail(c, "op %d: fuse needs channels %% 4 == 0", oi);
+  for (int i = 0; i < o.n_in; ++i) {
+    const uda_buf_desc_t& ib = c->bufs[o.in[i]];
+    if (ib.C != a.C) return fail(c, "op %d: fuse input %d has %d channels, input 0 %d", oi, i, ib.C, a.C);
+    a.in[i] = v.ptr(o.in[i]);
+    a.wgt[i] = (o.kind == UDA_OP_POOL) ? 1.0f : o.fuse_w[i];
+    a.mode[i] = o.resample[i];
+    a.Hi[i] = ib.H; a.Wi[i] = ib.W;
+    a.in_div[i] = v.div(ib, ob);
+    if (a.mode[i] == UDA_RS_NONE) {
+      if (ib.H != ob.H || ib.W != ob.W) return fail(c, "op %d: fuse input %d size mismatch", oi, i);
+    } else if (a.mode[i] == UDA_RS_NEAREST_UP) {
+      if (ib.H > ob.H || ib.W > ob.W) return fail(c, "op %d: nearest-up input %d larger than output", oi, i);
+      a.sy[i] = (float)ib.H / (float)ob.H;
+      a.sx[i] = (float)ib.W / (float)ob.W;
+    } else if (a.mode[i] == UDA_RS_MAXPOOL) {
+      const int sh_ = (ib.H - 1) / ob.H + 1, sw_ = (ib.W - 1) / ob.W + 1;
+      if (sh_ != sw_) return fail(c, "op %d: non-square pooling window", oi);
+      a.ps[i] = sh_;
+      a.pk[i] = sh_ + 1;
+      if ((ib.H + sh_ - 1) / sh_ != ob.H || (ib.W + sh_ - 1) / sh_ != ob.W)
+        return fail(c, "op %d: pooled size mismatch", oi);
+      a.ppt[i] = same_pad_before(ib.H, ob.H, a.pk[i], a.ps[i]);
+      a.ppl[i] = same_pad_before(ib.W, ob.W, a.pk[i], a.ps[i]);
+    } else {
+      return fail(c, "op %d: unknown resample mode %d of input %d", oi, a.mode[i], i);
+    }
+  }
+  return 0;
+}
+
 static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
   const uda_op_t& o = c->ops[oi];
   const uda_buf_desc_t& ob = c->bufs[o.out];
@@ -1134,7 +1185,20 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       a.H = ob.H; a.W = ob.W; a.C = ib.C; a.Cout = ob.C;
       a.in_div = v.div(ib, ob);
       a.act = o.act;
-      launch_sep(a, rows, v.stream());
+      if (o.fuse_in) {
+        // the node's BiFPN fusion is this conv's input, computed on the fly (swish: efficientdet_keras.py:131-136)
+        FuseArgs f{};
+        if (int rc = fill_fuse_args(c, v, oi, f)) return rc;
+        f.act = UDA_ACT_SWISH;
+        if (!sepf_supported(a.C, a.Cout, a.wparts)) return fail(c, "op %d: fused-input separable conv %d -> %d not supported", oi, a.C, a.Cout);
+        a.in = nullptr;
+        launch_sepf(a, &f, rows, v.stream());
+        break;
+      }
+      if (ib.H != ob.H || ib.W != ob.W) return fail(c, "op %d: separable conv changes the map size", oi);
+      static const int sepf_all = getenv("UDA_SEPF_ALL") ? atoi(getenv("UDA_SEPF_ALL")) : 0;     // A/B: the tile kernel for every conv
+      if (sepf_all && sepf_supported(a.C, a.Cout, a.wparts)) launch_sepf(a, nullptr, rows, v.stream());
+      else launch_sep(a, rows, v.stream());
       break;
     }
     case UDA_OP_SE: {
@@ -1160,37 +1224,11 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
     case UDA_OP_FUSE:
     case UDA_OP_POOL: {
       FuseArgs a{};
-      a.n_in = o.n_in;
-      a.H = ob.H; a.W = ob.W; a.C = ob.C;
+      if (int rc = fill_fuse_args(c, v, oi, a)) return rc;
+      if (a.C != ob.C) return fail(c, "op %d: fuse inputs have %d channels, output %d", oi, a.C, ob.C);
       a.out = v.ptr(o.out);
       a.act = o.act;
       a.total = (int64_t)rows * ob.H * ob.W * (ob.C / 4);
-      if (ob.C % 4) return fail(c, "op %d: fuse needs channels %% 4 == 0", oi);
-      for (int i = 0; i < o.n_in; ++i) {
-        const uda_buf_desc_t& ib = c->bufs[o.in[i]];
-        if (ib.C != ob.C) return fail(c, "op %d: fuse input %d has %d channels, output %d", oi, i, ib.C, ob.C);
-        a.in[i] = v.ptr(o.in[i]);
-        a.wgt[i] = (o.kind == UDA_OP_POOL) ? 1.0f : o.fuse_w[i];
-        a.mode[i] = o.resample[i];
-        a.Hi[i] = ib.H; a.Wi[i] = ib.W;
-        a.in_div[i] = v.div(ib, ob);
-        if (a.mode[i] == UDA_RS_NONE) {
-          if (ib.H != ob.H || ib.W != ob.W) return fail(c, "op %d: fuse input %d size mismatch", oi, i);
-        } else if (a.mode[i] == UDA_RS_NEAREST_UP) {
-          if (ib.H > ob.H || ib.W > ob.W) return fail(c, "op %d: nearest-up input %d larger than output", oi, i);
-          a.sy[i] = (float)ib.H / (float)ob.H;
-          a.sx[i] = (float)ib.W / (float)ob.W;
-        } else {
-          const int sh_ = (ib.H - 1) / ob.H + 1, sw_ = (ib.W - 1) / ob.W + 1;
-          if (sh_ != sw_) return fail(c, "op %d: non-square pooling window", oi);
-          a.ps[i] = sh_;
-          a.pk[i] = sh_ + 1;
-          if ((ib.H + sh_ - 1) / sh_ != ob.H || (ib.W + sh_ - 1) / sh_ != ob.W)
-            return fail(c, "op %d: pooled size mismatch", oi);
-          a.ppt[i] = same_pad_before(ib.H, ob.H, a.pk[i], a.ps[i]);
-          a.ppl[i] = same_pad_before(ib.W, ob.W, a.pk[i], a.ps[i]);
-        }
-      }
       launch_fuse(a, v.stream());
       break;
     }

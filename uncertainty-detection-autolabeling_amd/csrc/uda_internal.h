@@ -136,12 +136,19 @@ struct SepLevel {
 struct SepMulti {
   SepArgs one;                         // the single problem (n_lv == 0) / the fields shared by all problems
   int n_lv;
+  int tiles, rows;                     // tiles of one sample row (all problems), sample rows: filled by the launcher
   int tile0[UDA_SEP_MAX_LV + 1];       // first tile of every problem, total in [n_lv]
   SepLevel lv[UDA_SEP_MAX_LV];
 };
 void launch_sep_multi(const SepArgs& common, const SepLevel* lv, int n_lv, int rows, hipStream_t s);
 bool sep_supported(int C, int Cout);
 size_t sep_lds_bytes(int C, int Cout, int scheme);      // dynamic LDS of the launch an op of this shape gets
+struct FuseArgs;
+// The same conv on an LDS-staged 16 x 16 tile (kernels_sep.hip: sepf_kernel); with `fused` the input is the BiFPN fusion
+// described there, computed on the fly (a.in unused).  Outputs are bit-identical to launch_sep's.
+void launch_sepf(const SepArgs& a, const FuseArgs* fused, int rows, hipStream_t s);
+bool sepf_supported(int C, int Cout, int scheme);
+size_t sepf_lds_bytes(int C, int Cout, int scheme);
 
 struct DwArgs {
   const float* in;       // [rows_in, H, W, C]

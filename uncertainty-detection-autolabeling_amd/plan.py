@@ -120,6 +120,18 @@ def mbx_supported(cin, cmid, k, stride):
     return 16 <= cin and stride in (1, 2)
 
 
+def sepf_supported(C, Cout):
+    """The BiFPN fusion of a node can be computed inside its separable conv (mirror of sepf_supported / sepf_lds_bytes in
+    csrc/kernels_sep.hip: an 18 x 18 x (32 + 4) float32 tile + the weight fragments of two k-steps, two blocks per CU)."""
+    import os
+    sch = pw_scheme()
+    if sch == "f32" or not int(os.environ.get("UDA_FUSE_IN", "1")):
+        return False
+    npc = 3 if sch == "bf16x3" else 2
+    lds = 18 * 18 * 36 * 4 + 2 * (-(-Cout // 32)) * npc * 1024
+    return C % 8 == 0 and 16 <= C <= 128 and Cout % 4 == 0 and 4 <= Cout <= 128 and lds <= 80 * 1024
+
+
 def same_out(n, s):
     return -(-n // s)
 
@@ -228,7 +240,7 @@ class Plan:
                  stride=1, act=capi.ACT_NONE, w_off=-1, bias_off=-1, bn_scale_off=-1, bn_shift_off=-1,
                  se_w1_off=-1, se_b1_off=-1, se_w2_off=-1, se_b2_off=-1, se_mid=0, drop_site=-1,
                  resample=[0, 0, 0], fuse_w=[0.0, 0.0, 0.0], drop_site2=-1, w2_off=-1, bn2_scale_off=-1,
-                 bn2_shift_off=-1, launch_group=0)
+                 bn2_shift_off=-1, launch_group=0, fuse_in=0)
         o.update(kw)
         self.ops.append(o)
         return out
@@ -265,9 +277,23 @@ class Plan:
         return out, kw.get("se_partial", -1)
 
     def _sepconv(self, x, cout, dw_kernel, pw_kernel, name, bias=None, bn=None, act=capi.ACT_NONE, site=-1,
-                 out_kind=0, level=0):
+                 out_kind=0, level=0, fusion=None):
         """SeparableConv2D = depthwise 3x3 (no bias / BN / act) -> 1x1 + bias (+BN)(+act)(+dropout).  One fused op
-        when the kernel supports the channel count, else the depthwise / pointwise pair."""
+        when the kernel supports the channel count, else the depthwise / pointwise pair.
+        fusion = dict(ins, resample, fuse_w, H, W): the conv's input is the BiFPN fusion of `ins` (x is None), computed by
+        the conv kernel for its tile - the caller has checked sepf_supported."""
+        if fusion is not None:
+            ibs = [self.bufs[i] for i in fusion["ins"]]
+            ps = any(b.per_sample for b in ibs) or site >= 0
+            out = self._buf(fusion["H"], fusion["W"], cout, ps, out_kind, level, name)
+            kw = dict(k=3, stride=1, w_off=self._pack(self.w[pw_kernel]), w2_off=self._pack(self.w[dw_kernel]), act=act,
+                      drop_site=site, fuse_in=1, resample=(list(fusion["resample"]) + [0, 0, 0])[:3],
+                      fuse_w=(list(fusion["fuse_w"]) + [0, 0, 0])[:3])
+            if bias is not None:
+                kw["bias_off"] = self._pack(self.w[bias])
+            if bn is not None:
+                kw["bn_scale_off"], kw["bn_shift_off"] = self._bn(bn)
+            return self._op(capi.OP_SEP, list(fusion["ins"]), out, **kw)
         xb = self.bufs[x]
         if not (self.fuse_sep and xb.C % 8 == 0 and 16 <= xb.C <= 128):
             d, _ = self._dw(x, 3, 1, dw_kernel, name + "/dw")
@@ -449,9 +475,15 @@ class Plan:
                 else:
                     raise ValueError("unknown weight_method %s" % method)
                 ps = any(self.bufs[i].per_sample for i in ins)
+                op = p + "op_after_combine%d" % nf
+                if self.fuse_sep and sepf_supported(F, F):
+                    # the fusion is computed inside the node's separable conv: no fused tensor, no fuse launch
+                    cell.append(self._sepconv(None, F, op + "/conv/depthwise_kernel", op + "/conv/pointwise_kernel",
+                                              "cell%d/fnode%d/out" % (rep, n), bias=op + "/conv/bias", bn=op + "/bn",
+                                              fusion=dict(ins=ins, resample=modes, fuse_w=fw, H=tgt.H, W=tgt.W)))
+                    continue
                 fused = self._op(capi.OP_FUSE, ins, self._buf(tgt.H, tgt.W, F, ps, name="cell%d/fnode%d/fused" % (rep, n)),
                                  act=capi.ACT_SWISH, resample=(modes + [0, 0, 0])[:3], fuse_w=(fw + [0, 0, 0])[:3])
-                op = p + "op_after_combine%d" % nf
                 cell.append(self._sepconv(fused, F, op + "/conv/depthwise_kernel", op + "/conv/pointwise_kernel",
                                           "cell%d/fnode%d/out" % (rep, n), bias=op + "/conv/bias", bn=op + "/bn"))
             feats = []
@@ -659,7 +691,7 @@ class Plan:
                       "bn_scale_off", "bn_shift_off", "se_w1_off", "se_b1_off", "se_w2_off", "se_b2_off",
                       "se_mid", "drop_site", "drop_site2", "w2_off", "bn2_scale_off", "bn2_shift_off", "launch_group"):
                 setattr(c, k, int(o[k]))
-            c.reserved0 = 0
+            c.fuse_in = int(o.get("fuse_in", 0))
         sites = (capi.DropSite * max(1, len(self.sites)))()
         for i, (_, ch, r) in enumerate(self.sites):
             sites[i].channels, sites[i].rate = ch, np.float32(r)
@@ -729,6 +761,8 @@ def op_costs(plan, n_images):
             ib = plan.bufs[o["ins"][0]]
             by += ib.C * ob.C + 9 * ib.C
             fl = 2 * rows * ob.H * ob.W * (9 * ib.C + ib.C * ob.C)
+            if o.get("fuse_in"):
+                fl += rows * ob.H * ob.W * ib.C * len(o["ins"]) * 2
         elif k == capi.OP_SE:
             fl = 4 * rows * ob.C * o["se_mid"]
         elif k in (capi.OP_FUSE, capi.OP_POOL):
