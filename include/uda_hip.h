@@ -189,6 +189,23 @@ int uda_get_dropout_masks(uda_ctx_t* ctx, float* masks, int64_t n_floats);
  * handle's stream.  post_mode < 0 uses the model default; run_post == 0 stops after the heads. */
 int uda_run(uda_ctx_t* ctx, int32_t post_mode, int32_t run_post);
 int uda_synchronize(uda_ctx_t* ctx);
+/* Pipelined serving of a stream of batches (infer_lib.ServingDriver.serve_images called batch after batch,
+ * infer_lib.py:504-540; the reference runs them strictly one after the other): uda_run_async queues network + post-process
+ * of the current input like uda_run(ctx, post_mode, 1) but does NOT order the handle's main stream behind the
+ * post-process - the next uda_run_async's network starts at once and only its first head-writing op waits for it, so the
+ * ~4 ms of latency-bound aggregate / NMS / gather launches of batch k run beside the backbone of batch k + 1.
+ * *ticket (0 | 1) names the run; at most two may be in flight.  uda_collect waits for that run's post-process only and
+ * copies its detections (same arrays as uda_get_detections; NULL = skip) - the detection outputs and the image scales
+ * exist once per ticket, so a run queued behind it cannot disturb them.  Typical loop:
+ *     run_async(&t0);  for each further batch: { set / swap images; run_async(&t1); collect(t0, ...); t0 = t1; }  collect(t0, ...)
+ * Failures are loud: a range / barrier flag raised by a run whose candidates a newer run has replaced fails the collect
+ * (the batch has to be run again); entry points that rewrite head buffers refuse while a run is in flight.  Results are
+ * bit-identical to uda_run's. */
+int uda_run_async(uda_ctx_t* ctx, int32_t post_mode, int32_t* ticket);
+int uda_collect(uda_ctx_t* ctx, int32_t ticket, float* boxes, float* scores, float* classes, int32_t* valid, float* logits);
+/* The same for the multi-GPU gather: the run's detections as ONE device-resident record buffer (see uda_detections_device
+ * for the layout and `rows`); packed on a stream of its own, complete when the call returns; closes the ticket. */
+int uda_collect_device(uda_ctx_t* ctx, int32_t ticket, int32_t rows, int32_t with_logits, void** dev_ptr, int32_t* cols);
 /* Global NMS over the whole anchor set runs on the score prefix that can be selected at all, checked on the
  * device; this counts the images / problems that failed the check and were redone on the full set (the results
  * are identical either way). */

@@ -297,3 +297,73 @@ def test_bifpn_fusion_inside_the_separable_conv_is_bit_identical(tmp_path):
     for k in outs["1"]:
         if not k.endswith("_nfuse"):
             np.testing.assert_array_equal(outs["1"][k], outs["0"][k], err_msg=k)
+
+
+def _same(a, b, msg):
+    assert len(a) == len(b), msg
+    for i, (x, y) in enumerate(zip(a, b)):
+        np.testing.assert_array_equal(x, y, err_msg="%s [%d]" % (msg, i))
+
+
+@pytest.mark.parametrize("post_mode", ["global", "per_class"])
+def test_pipelined_runs_return_what_synchronous_serves_return(post_mode):
+    """uda_run_async / uda_collect: batch k's post-process (aggregate, NMS, gather) is not joined into the main stream, batch
+    k + 1's network is queued before batch k's detections are fetched and only its head-writing ops wait.  Detections, image
+    scales and the dropout stream are per run: six batches of different images, image counts and raw sizes (resampled and
+    not) through `serve_stream` equal the same batches through `serve`, bit for bit, in order."""
+    from common import FULL_MC, make_images, make_params, make_weights
+    from uda_amd.infer_lib import KerasDriver
+    p = make_params(**FULL_MC)
+    w = make_weights(p, seed=5, cls_spread=20.0)
+    batches = [make_images(3, 128, 192, seed=60), make_images(3, 128, 192, seed=61), make_images(2, 100, 180, seed=62),
+               make_images(3, 90, 200, seed=63), make_images(1, 128, 192, seed=64), make_images(3, 128, 192, seed=65)]
+    sync = KerasDriver("_", False, p["name"], 3, False, p, weights=w, chunk_images=2, post_mode=post_mode)
+    sync.set_dropout_seed(7)
+    want = [sync.serve(b) for b in batches]
+    sync.close()
+    pipe = KerasDriver("_", False, p["name"], 3, False, p, weights=w, chunk_images=2, post_mode=post_mode)
+    pipe.set_dropout_seed(7)
+    got = list(pipe.serve_stream(batches))
+    assert len(got) == len(want)
+    for k, (g, v) in enumerate(zip(got, want)):
+        _same(g, v, "batch %d" % k)
+    assert any(int(v[3].sum()) > 0 for v in want)
+    # the same handle goes back to synchronous serving
+    again = pipe.serve(batches[0])
+    assert all(a.shape == b.shape for a, b in zip(again, want[0])) and np.isfinite(again[0]).all()
+    pipe.close()
+
+
+def test_pipelined_run_bookkeeping_is_enforced():
+    """At most two runs in flight; tickets are collected once; a synchronous run, or anything that rewrites the head buffers,
+    refuses while a pipelined run is in flight; the newest run may also be read through the ordinary readers."""
+    from common import FULL_MC, make_images, make_params, make_weights
+    from uda_amd.infer_lib import KerasDriver
+    p = make_params(**FULL_MC)
+    w = make_weights(p, seed=5, cls_spread=20.0)
+    d = KerasDriver("_", False, p["name"], 2, False, p, weights=w, chunk_images=2)
+    d.set_dropout_seed(3)
+    imgs, imgs2 = make_images(2, 128, 192, seed=66), make_images(2, 120, 150, seed=67)
+    ref, ref2 = d.serve(imgs), d.serve(imgs2)
+    d.stage_images(imgs)
+    t0 = d.run_async()
+    d.stage_images(imgs2)                  # (synchronises: allowed while a run is in flight, it only costs the overlap)
+    t1 = d.run_async()
+    assert {t0, t1} == {0, 1}
+    with pytest.raises(RuntimeError, match="two runs are in flight"):
+        d.run_async()
+    with pytest.raises(RuntimeError, match="in flight"):
+        d.run_resident()
+    with pytest.raises(RuntimeError, match="in flight"):
+        d.predict_resident(np.zeros((1,) + tuple(d.image_size) + (3,), np.float32))
+    first = d.collect(t0)
+    _same(first, ref, "first pipelined run = the synchronous serve with the same seed")
+    with pytest.raises(RuntimeError, match="not in flight"):
+        d._ck(d._lib.uda_collect(d._h, t0, None, None, None, None, None), "uda_collect")
+    newest = d._collect(2)                 # ordinary reader: the newest run's outputs
+    second = d.collect(t1)
+    _same(newest, second, "ordinary reader sees the newest run")
+    _same(second, ref2, "second pipelined run = the synchronous serve of its own images")
+    assert not np.array_equal(second[1], first[1])
+    d.run_resident()                       # nothing in flight any more
+    d.close()

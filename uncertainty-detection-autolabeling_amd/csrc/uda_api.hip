@@ -156,6 +156,28 @@ struct uda_ctx {
   int last_post_mode = 0;
   int last_n = 0;
   int last_chunk_i0 = 0, last_chunk_n = 0;
+  // Pipelined runs (uda_run_async / uda_collect): the post-process of run k (aggregate, NMS, gather: ~4 ms of latency-bound
+  // launches on the post stream) is NOT joined into the main stream; run k + 1's network starts at once and only its first
+  // head-writing op waits for it.  What run k's post-process reads or writes and run k + 1 could touch exists twice, by
+  // ticket: the detection outputs and the image scales (snapshot taken on the main stream when the run is queued).
+  struct AsyncSlot {
+    hipEvent_t ev = nullptr;             // post-process of this run done
+    bool open = false;                   // queued, not collected yet
+    bool joined = true;                  // the main stream has been made to wait for `ev`
+    int64_t seq = 0;
+    int n = 0, mode = 0;
+    bool coop_used = false, oor_armed = false;
+    std::vector<std::pair<int, int>> pending;      // prefix-NMS ranges the host has not checked (rare path: no cooperative NMS)
+    float *oboxes = nullptr, *oscores = nullptr, *oclasses = nullptr, *ologits = nullptr, *scales = nullptr;
+    int32_t* ovalid = nullptr;
+  };
+  AsyncSlot as[2];
+  int as_next = 0;
+  int64_t as_seq = 0;
+  bool as_ready = false;
+  const float* d_scales_post = nullptr;  // what the post-process reads as image scales (null: d_scales)
+  hipStream_t aux_stream = nullptr;      // uda_collect_device packs on it
+  hipEvent_t gate_ev = nullptr;          // run_network: head-writing ops wait for this first (the previous run's post-process)
 
   uint32_t prof_mask = 0;
   ProfSlot prof[32];
@@ -261,8 +283,18 @@ extern "C" void uda_destroy(uda_ctx_t* c) {
   if (!c) return;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->post_stream) hipStreamSynchronize(c->post_stream);      // (a pipelined run nobody collected)
   for (int k = 0; k < 32; ++k) prof_collect(c, k);
   if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
+  if (c->as_ready) {      // the second output set of the pipelined runs; the first one is the handle's own (freed below)
+    const uda_ctx::AsyncSlot& a0 = c->as[0];
+    c->d_oboxes = a0.oboxes; c->d_oscores = a0.oscores; c->d_oclasses = a0.oclasses; c->d_ologits = a0.ologits; c->d_ovalid = a0.ovalid;
+    const uda_ctx::AsyncSlot& a1 = c->as[1];
+    void* sp[] = {a1.oboxes, a1.oscores, a1.oclasses, a1.ologits, a1.ovalid, a0.scales, a1.scales};
+    for (void* p : sp)
+      if (p) hipFree(p);
+    for (auto& a : c->as) if (a.ev) hipEventDestroy(a.ev);
+  }
   for (auto& sl : c->u8) {
     if (sl.d) hipFree(sl.d);
     if (sl.pinned) hipHostFree(sl.pinned);
@@ -297,6 +329,7 @@ extern "C" void uda_destroy(uda_ctx_t* c) {
     if (c->lane_arena[l]) hipFree(c->lane_arena[l]);
   }
   if (c->post_stream) hipStreamDestroy(c->post_stream);
+  if (c->aux_stream) hipStreamDestroy(c->aux_stream);
   for (auto e : c->ev_chunk) if (e) hipEventDestroy(e);
   if (c->ev_post) hipEventDestroy(c->ev_post);
   if (c->ev_start) hipEventDestroy(c->ev_start);
@@ -837,6 +870,12 @@ static int make_current(uda_ctx* c, int si) {
   return 0;
 }
 
+// entry points that rewrite what a pipelined run's post-process reads (head buffers, image count) refuse to run beside it
+static int no_async(uda_ctx* c, const char* what) {
+  if (c->as[0].open || c->as[1].open) return fail(c, "%s: a pipelined run (uda_run_async) is in flight - uda_collect it first", what);
+  return 0;
+}
+
 extern "C" int uda_set_images_u8(uda_ctx_t* c, const uint8_t* images, int32_t n, int32_t h, int32_t w) {
   if (!c || !images) return c ? fail(c, "set_images_u8: NULL images") : 1;
   const int si = c->cur;
@@ -1317,7 +1356,7 @@ static int run_preprocess(uda_ctx* c) {
   return 0;
 }
 
-static int run_network(uda_ctx* c, int post_mode = 0, bool chunk_post = false) {
+static int run_network(uda_ctx* c, int post_mode = 0, bool chunk_post = false, hipEvent_t defer_ev = nullptr) {
   const uda_model_t& m = c->model;
   const int n = c->n_images, T = m.mc_samples;
   // uint8 batch in which no image is resampled (scale 1: raw size within the network size - BASELINE configs[1]-[3]): the stem
@@ -1361,9 +1400,17 @@ static int run_network(uda_ctx* c, int post_mode = 0, bool chunk_post = false) {
   for (int i0 = 0; i0 < n; i0 += m.chunk_images, ++ci) {
     ChunkView v{c, i0, (n - i0 < m.chunk_images) ? n - i0 : m.chunk_images};
     v.lane = ci % lanes;
+    bool gated = false;
     for (int oi = 0; oi < (int)c->ops.size(); ++oi) {
+      // pipelined runs: the previous run's post-process still reads the head buffers - the first op of this chunk that writes
+      // one waits for it (everything before it, i.e. the whole backbone and BiFPN, runs beside that post-process)
+      if (c->gate_ev && !gated && c->bufs[c->ops[oi].out].kind >= 2) {
+        HIPC(c, hipStreamWaitEvent(v.stream(), c->gate_ev, 0));
+        gated = true;
+      }
       const int grp = c->ops[oi].launch_group;
-      if (grp > 1) {
+      static const bool sepf_all_ = getenv("UDA_SEPF_ALL") && atoi(getenv("UDA_SEPF_ALL"));     // A/B: per-level tile-kernel launches
+      if (grp > 1 && !sepf_all_) {
         const int rg = run_sep_group(c, v, oi, grp);
         if (rg > 0) return rg;
         if (rg == 0) {
@@ -1405,8 +1452,12 @@ static int run_network(uda_ctx* c, int post_mode = 0, bool chunk_post = false) {
     }
   }
   if (chunk_post) {
-    HIPC(c, hipEventRecord(c->ev_post, c->post_stream));
-    HIPC(c, hipStreamWaitEvent(c->stream, c->ev_post, 0));
+    if (defer_ev) {
+      HIPC(c, hipEventRecord(defer_ev, c->post_stream));      // pipelined: the main stream goes on without the post-process
+    } else {
+      HIPC(c, hipEventRecord(c->ev_post, c->post_stream));
+      HIPC(c, hipStreamWaitEvent(c->stream, c->ev_post, 0));
+    }
     c->last_post_mode = post_mode;
     c->last_n = n;
   }
@@ -1578,7 +1629,7 @@ static int run_post_global(uda_ctx* c, int i0, int n, hipStream_t st) {
   g.u_cls = c->d_ucls ? c->d_ucls + i0 * k * uc : nullptr;
   g.u_al = c->d_ual ? c->d_ual + i0 * k * 4 : nullptr;
   g.u_ep = c->d_uep ? c->d_uep + i0 * k * 4 : nullptr;
-  g.scales = c->d_scales + i0;
+  g.scales = (c->d_scales_post ? c->d_scales_post : c->d_scales) + i0;
   g.out_boxes = c->d_oboxes + i0 * mm * g.box_cols; g.out_scores = c->d_oscores + i0 * mm;
   g.out_classes = c->d_oclasses + i0 * mm * g.cls_cols;
   g.out_valid = c->d_ovalid + i0; g.out_logits = c->d_ologits + i0 * mm * C;
@@ -1607,7 +1658,7 @@ static int run_post_per_class(uda_ctx* c, int i0, int n, hipStream_t st) {
   }
   MergeArgs g{};
   g.sel_idx = c->ws[1].sel_idx + p0 * mm; g.sel_score = c->ws[1].sel_score + p0 * mm; g.nsel = c->ws[1].nsel + p0;
-  g.boxes = c->d_cboxes + (size_t)i0 * k * 4; g.scales = c->d_scales + i0;
+  g.boxes = c->d_cboxes + (size_t)i0 * k * 4; g.scales = (c->d_scales_post ? c->d_scales_post : c->d_scales) + i0;
   g.keys = c->d_merge_keys + (size_t)i0 * ((size_t)C * M + M);
   g.out_boxes = c->d_oboxes + i0 * mm * 4; g.out_scores = c->d_oscores + i0 * mm;
   g.out_classes = c->d_oclasses + i0 * mm; g.out_valid = c->d_ovalid + i0;
@@ -1665,7 +1716,22 @@ static int check_split_range(uda_ctx* c) {
 
 // Every reader of the post-process outputs comes through here: images whose score prefix turned out not to be
 // sufficient (flag written by prefix_check_kernel) are redone on the full candidate set before anything is read.
+// Pipelined runs whose post-process the main stream has not been made to wait for: every reader / writer of what they
+// touch comes through here first (then the main stream is ordered behind them and everything below works as it always did).
+static int join_async(uda_ctx* c) {
+  for (int s = 0; s < 2; ++s) {
+    uda_ctx::AsyncSlot& a = c->as[s];
+    if (a.open && !a.joined) {
+      HIPC(c, hipStreamWaitEvent(c->stream, a.ev, 0));
+      a.joined = true;
+    }
+  }
+  c->gate_ev = nullptr;
+  return 0;
+}
+
 static int finish_post(uda_ctx* c) {
+  if (int rc = join_async(c)) return rc;
   if (int rc = check_split_range(c)) return rc;
   if (c->coop_used) {        // a barrier of the cooperative NMS that timed out leaves garbage: fail loudly
     c->coop_used = false;
@@ -1724,10 +1790,15 @@ static int finish_post(uda_ctx* c) {
   return rc;
 }
 
+static int use_output_set(uda_ctx* c, int s);
+
 extern "C" int uda_run(uda_ctx_t* c, int32_t post_mode, int32_t do_post) {
   if (!c) return 1;
   if (c->n_images < 1) return fail(c, "uda_run: no images set");
   HIPC(c, hipSetDevice(c->device));
+  if (c->as[0].open || c->as[1].open) return fail(c, "uda_run: a pipelined run (uda_run_async) is in flight - uda_collect it first");
+  if (c->as_ready) { if (int rc = use_output_set(c, 0)) return rc; }
+  c->d_scales_post = nullptr;
   c->pfx_pending.clear();
   if (do_post && c->post_overlap) {
     const int pm = post_mode < 0 ? c->model.post_mode : post_mode;
@@ -1742,6 +1813,176 @@ extern "C" int uda_run(uda_ctx_t* c, int32_t post_mode, int32_t do_post) {
   if (rc) return rc;
   if (do_post) rc = run_post(c, c->n_images, post_mode);
   return rc;
+}
+
+// ---- pipelined runs
+static int use_output_set(uda_ctx* c, int s) {
+  const uda_ctx::AsyncSlot& a = c->as[s];
+  c->d_oboxes = a.oboxes; c->d_oscores = a.oscores; c->d_oclasses = a.oclasses; c->d_ologits = a.ologits; c->d_ovalid = a.ovalid;
+  return 0;
+}
+
+static int async_setup(uda_ctx* c) {
+  if (c->as_ready) return 0;
+  const uda_model_t& m = c->model;
+  const size_t N = (size_t)m.max_images, M = (size_t)m.max_output_size, C = (size_t)m.num_classes;
+  uda_ctx::AsyncSlot& a0 = c->as[0];
+  uda_ctx::AsyncSlot& a1 = c->as[1];
+  a0.oboxes = c->d_oboxes; a0.oscores = c->d_oscores; a0.oclasses = c->d_oclasses; a0.ologits = c->d_ologits; a0.ovalid = c->d_ovalid;
+  HIPC(c, dalloc(&a1.oboxes, N * M * 12));
+  HIPC(c, dalloc(&a1.oscores, N * M));
+  HIPC(c, dalloc(&a1.oclasses, N * M * (1 + C)));
+  HIPC(c, dalloc(&a1.ologits, N * M * C));
+  HIPC(c, dalloc(&a1.ovalid, N));
+  for (int s = 0; s < 2; ++s) {
+    HIPC(c, dalloc(&c->as[s].scales, N));
+    HIPC(c, hipEventCreateWithFlags(&c->as[s].ev, hipEventDisableTiming));
+  }
+  c->as_ready = true;
+  return 0;
+}
+
+// The heavy path of a slot (range / barrier flags, prefix redo: finish_post): only when nothing newer is queued behind it.
+static int resolve_slot_full(uda_ctx* c, int s) {
+  uda_ctx::AsyncSlot& a = c->as[s];
+  use_output_set(c, s);
+  c->d_scales_post = a.scales;
+  c->last_n = a.n; c->last_post_mode = a.mode;
+  c->coop_used = a.coop_used; c->oor_armed = c->oor_armed || a.oor_armed;
+  c->pfx_pending.swap(a.pending);
+  a.pending.clear(); a.coop_used = false; a.oor_armed = false;
+  return finish_post(c);         // joins, synchronises the main stream, redoes what has to be redone
+}
+
+extern "C" int uda_run_async(uda_ctx_t* c, int32_t post_mode, int32_t* ticket) {
+  if (!c || !ticket) return c ? fail(c, "uda_run_async: NULL ticket") : 1;
+  if (c->n_images < 1) return fail(c, "uda_run_async: no images set");
+  HIPC(c, hipSetDevice(c->device));
+  const int pm = post_mode < 0 ? c->model.post_mode : post_mode;
+  if (pm != UDA_POST_GLOBAL && pm != UDA_POST_PER_CLASS) return fail(c, "unknown post mode %d", pm);
+  if (int rc = async_setup(c)) return rc;
+  const int s = c->as_next, o = s ^ 1;
+  if (c->as[s].open) return fail(c, "uda_run_async: two runs are in flight already - collect ticket %d first", s);
+  // leftovers of the run in flight that need the host (prefix-NMS ranges to check: only without the cooperative NMS) are
+  // settled before anything new is queued behind it - its candidates are still in place now
+  if (c->as[o].open && !c->as[o].pending.empty()) {
+    if (int rc = resolve_slot_full(c, o)) return rc;
+  }
+  int rc = prepare_post(c, pm);
+  if (rc) return rc;
+  uda_ctx::AsyncSlot& a = c->as[s];
+  use_output_set(c, s);
+  HIPC(c, hipMemcpyAsync(a.scales, c->d_scales, (size_t)c->n_images * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  c->d_scales_post = a.scales;
+  c->pfx_pending.clear();
+  c->coop_used = false;
+  c->gate_ev = (c->as[o].open && !c->as[o].joined) ? c->as[o].ev : nullptr;
+  if (c->post_overlap) {
+    rc = run_network(c, pm, true, a.ev);
+    a.joined = false;
+  } else {                       // UDA_POST_OVERLAP=0: everything on the main stream, nothing to overlap
+    rc = run_network(c);
+    if (!rc) rc = run_post(c, c->n_images, pm);
+    if (!rc) HIPC(c, hipEventRecord(a.ev, c->stream));
+    a.joined = true;
+  }
+  c->gate_ev = nullptr;
+  if (rc) return rc;
+  if (c->pfx_skip > 0 && c->pfx_pending.empty()) --c->pfx_skip;
+  a.open = true;
+  a.seq = ++c->as_seq;
+  a.n = c->n_images; a.mode = pm;
+  a.coop_used = c->coop_used; c->coop_used = false;
+  a.oor_armed = c->oor_armed; c->oor_armed = false;
+  a.pending.swap(c->pfx_pending);
+  c->pfx_pending.clear();
+  c->as_next = o;
+  *ticket = s;
+  return 0;
+}
+
+// Waits for the post-process of the run behind `ticket` and checks its flags; the slot's output set is valid afterwards.
+static int settle_ticket(uda_ctx* c, int ticket, const char* who) {
+  if (ticket < 0 || ticket > 1 || !c->as[ticket].open) return fail(c, "%s: ticket %d is not in flight", who, ticket);
+  HIPC(c, hipSetDevice(c->device));
+  uda_ctx::AsyncSlot& a = c->as[ticket];
+  const uda_ctx::AsyncSlot& other = c->as[ticket ^ 1];
+  const bool newer_queued = other.open && other.seq > a.seq;
+  if (!newer_queued) {
+    // the newest run: the ordinary path (it may redo the post-process on the full candidate set)
+    if (int rc = resolve_slot_full(c, ticket)) { a.open = false; return rc; }
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+  }
+  // a newer run is queued behind this one: wait for this run's post-process only, check its flags, never touch the streams
+  HIPC(c, hipEventSynchronize(a.ev));
+  if (a.oor_armed) {
+    unsigned f = 0;
+    HIPC(c, hipMemcpy(&f, c->d_oor, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (f) {
+      a.open = false;
+      return fail(c, "an activation above 65504 reached a 1x1 contraction that splits its operands into fp16 pieces "
+                     "(UDA_PW_SCHEME=f16x2) in this or the following pipelined run: the results are invalid.  Re-create the "
+                     "handle with UDA_PW_SCHEME=bf16x3");
+    }
+    c->oor_armed = true;      // (the flag is cumulative: the newest run's readers look again)
+  }
+  if (a.coop_used) {
+    int e = 0;
+    HIPC(c, hipMemcpy(&e, c->d_coop_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (e) {
+      a.open = false;
+      c->coop_off = true;
+      ++c->coop_fallbacks;
+      return fail(c, "cooperative NMS: a grid barrier timed out in a pipelined run whose candidates the next run has already "
+                     "replaced - its detections are invalid.  The handle now uses the two-launch NMS; run the batch again");
+    }
+  }
+  if (!a.pending.empty()) { a.open = false; return fail(c, "%s: internal: unsettled prefix-NMS ranges behind a newer run", who); }
+  return 0;
+}
+
+extern "C" int uda_collect(uda_ctx_t* c, int32_t ticket, float* boxes, float* scores, float* classes, int32_t* valid, float* logits) {
+  if (!c) return 1;
+  if (int rc = settle_ticket(c, ticket, "uda_collect")) return rc;
+  uda_ctx::AsyncSlot& a = c->as[ticket];
+  const size_t n = a.n, M = c->model.max_output_size, C = c->model.num_classes;
+  const int bc = box_cols_of(c->model, a.mode), cc = cls_cols_of(c->model, a.mode);
+  if (boxes) HIPC(c, hipMemcpy(boxes, a.oboxes, n * M * bc * sizeof(float), hipMemcpyDeviceToHost));
+  if (scores) HIPC(c, hipMemcpy(scores, a.oscores, n * M * sizeof(float), hipMemcpyDeviceToHost));
+  if (classes) HIPC(c, hipMemcpy(classes, a.oclasses, n * M * cc * sizeof(float), hipMemcpyDeviceToHost));
+  if (valid) HIPC(c, hipMemcpy(valid, a.ovalid, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (logits && a.mode == UDA_POST_GLOBAL) HIPC(c, hipMemcpy(logits, a.ologits, n * M * C * sizeof(float), hipMemcpyDeviceToHost));
+  a.open = false;
+  return 0;
+}
+
+extern "C" int uda_collect_device(uda_ctx_t* c, int32_t ticket, int32_t rows, int32_t with_logits, void** dev_ptr, int32_t* cols) {
+  if (!c || !dev_ptr) return c ? fail(c, "uda_collect_device: NULL argument") : 1;
+  if (ticket >= 0 && ticket <= 1 && c->as[ticket].open && (rows < c->as[ticket].n || rows > c->model.max_images))
+    return fail(c, "uda_collect_device: rows %d outside [%d images of the run, max_images %d]", rows, c->as[ticket].n, c->model.max_images);
+  if (int rc = settle_ticket(c, ticket, "uda_collect_device")) return rc;
+  uda_ctx::AsyncSlot& a = c->as[ticket];
+  const size_t M = c->model.max_output_size;
+  const int bc = box_cols_of(c->model, a.mode), cc = cls_cols_of(c->model, a.mode);
+  const int C = (with_logits && a.mode == UDA_POST_GLOBAL) ? c->model.num_classes : 0;
+  const int nc = bc + 1 + cc + C + 1;
+  if (!c->d_opacked) {
+    const int widest = box_cols_of(c->model, UDA_POST_GLOBAL) + 1 + cls_cols_of(c->model, UDA_POST_GLOBAL) + c->model.num_classes + 1;
+    HIPC(c, dalloc(&c->d_opacked, (size_t)c->model.max_images * M * widest));
+  }
+  if (!c->aux_stream) HIPC(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+  PackDetArgs p{};
+  p.boxes = a.oboxes; p.scores = a.oscores; p.classes = a.oclasses; p.logits = a.ologits; p.valid = a.ovalid;
+  p.out = c->d_opacked;
+  p.n = a.n; p.rows_out = rows; p.M = (int)M; p.bc = bc; p.cc = cc; p.C = C; p.cols = nc;
+  launch_pack_det(p, c->aux_stream);     // (its own stream: the main and the post stream carry the newer run)
+  HIPC(c, hipGetLastError());
+  HIPC(c, hipStreamSynchronize(c->aux_stream));
+  *dev_ptr = c->d_opacked;
+  if (cols) *cols = nc;
+  a.open = false;
+  return 0;
 }
 
 extern "C" int64_t uda_nms_prefix_fallbacks(const uda_ctx_t* c) { return c ? c->pfx_fallbacks : -1; }
@@ -1960,6 +2201,7 @@ extern "C" uint32_t uda_crc32c(const void* data, uint64_t n, uint32_t crc) {
 
 extern "C" int uda_serve(uda_ctx_t* c, const uint8_t* images, int32_t n, int32_t h, int32_t w,
                          float* boxes, float* scores, float* classes, int32_t* valid, float* logits) {
+  if (c) { if (int rc_ = no_async(c, "uda_serve")) return rc_; }
   int rc = uda_set_images_u8(c, images, n, h, w);
   if (rc) return rc;
   rc = uda_run(c, -1, 1);
@@ -1994,6 +2236,7 @@ extern "C" int uda_get_head_outputs(uda_ctx_t* c, int32_t level, float* cls, flo
 
 extern "C" int uda_set_head_outputs(uda_ctx_t* c, int32_t level, int32_t n, const float* cls, int64_t cls_floats,
                                     const float* box, int64_t box_floats) {
+  if (c) { if (int rc_ = no_async(c, "uda_set_head_outputs")) return rc_; }
   if (!c) return 1;
   if (level < 0 || level >= c->model.num_levels) return fail(c, "set_head_outputs: bad level %d", level);
   if (n < 1 || n > c->model.max_images) return fail(c, "set_head_outputs: n=%d", n);
@@ -2039,6 +2282,7 @@ extern "C" int uda_head_outputs_device(uda_ctx_t* c, int32_t level, int32_t whic
 }
 
 extern "C" int uda_set_num_images(uda_ctx_t* c, int32_t n) {
+  if (c) { if (int rc_ = no_async(c, "uda_set_num_images")) return rc_; }
   if (!c) return 1;
   if (n < 1 || n > c->model.max_images) return fail(c, "set_num_images: n=%d outside [1, %d]", n, c->model.max_images);
   c->n_images = n;
@@ -2046,6 +2290,7 @@ extern "C" int uda_set_num_images(uda_ctx_t* c, int32_t n) {
 }
 
 extern "C" int uda_copy_heads(uda_ctx_t* dst, const uda_ctx_t* src, int32_t n, int32_t sample) {
+  if (dst) { if (int rc_ = no_async(dst, "uda_copy_heads")) return rc_; }
   if (!dst || !src) return 1;
   const uda_model_t& md = dst->model;
   const uda_model_t& ms = src->model;
@@ -2074,6 +2319,7 @@ extern "C" int uda_copy_heads(uda_ctx_t* dst, const uda_ctx_t* src, int32_t n, i
 }
 
 extern "C" int uda_postprocess_heads(uda_ctx_t* c, int32_t n, const float* image_scales, int32_t post_mode) {
+  if (c) { if (int rc_ = no_async(c, "uda_postprocess_heads")) return rc_; }
   if (!c) return 1;
   if (n < 1 || n > c->model.max_images) return fail(c, "postprocess_heads: n=%d", n);
   HIPC(c, hipSetDevice(c->device));
@@ -2084,6 +2330,7 @@ extern "C" int uda_postprocess_heads(uda_ctx_t* c, int32_t n, const float* image
 }
 
 extern "C" int uda_predict(uda_ctx_t* c, const float* images, int32_t n) {
+  if (c) { if (int rc_ = no_async(c, "uda_predict")) return rc_; }
   int rc = uda_set_images_f32(c, images, n, nullptr);
   if (rc) return rc;
   rc = uda_run(c, -1, 0);

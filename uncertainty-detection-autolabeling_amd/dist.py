@@ -89,13 +89,15 @@ def all_gather_detections(det, device=None, group=None, counts=None):
 _GATHER_BUF = {}     # (device, world, n_max, M, cols) -> the receive tensor of the device-resident gather, reused across steps
 
 
-def all_gather_detections_device(driver, n_local, counts, device, group=None, to_host=True):
+def all_gather_detections_device(driver, n_local, counts, device, group=None, to_host=True, ticket=None):
     """The same gather WITHOUT a host hop: the handle packs its detections into one device-resident record
     buffer (`uda_detections_device`, padded with zero rows to the largest shard), RCCL all-gathers straight out of it into
     a reusable tensor, and ONE device-to-host copy of the gathered records follows on the ranks that want them
     (`to_host=False` returns the device tensor [world * n_max, M, cols] and the layout instead).  Before: download of the
     local detections, re-upload of the packed copy, gather, download - three PCIe crossings and two synchronisations per
-    step for an 11 KB / image record that already sat in a device buffer."""
+    step for an 11 KB / image record that already sat in a device buffer.
+    ticket: gather the detections of that pipelined run (`run_async`) instead of the last synchronous one - the next run's
+    network is already queued behind it and keeps the GPU busy while the records travel."""
     import torch
     import torch.distributed as dist
     dev = torch.device(device)
@@ -105,7 +107,7 @@ def all_gather_detections_device(driver, n_local, counts, device, group=None, to
         raise ValueError("counts %s do not describe this rank's %d images" % (counts, n_local))
     n_max = max(counts)
     if n_local > 0:
-        ptr, rows, layout = driver.detections_device(rows=n_max)
+        ptr, rows, layout = driver.detections_device(rows=n_max) if ticket is None else driver.collect_device(ticket, rows=n_max)
         cols = layout["box"] + 1 + layout["cls"] + layout["logits"] + 1
         t = torch.as_tensor(DevArray(ptr, (rows, driver.M, cols)), device=dev)
     else:       # an empty shard (more ranks than images): zero records of the right shape

@@ -210,6 +210,55 @@ class ServingDriver:
             out.append(logits)
         return tuple(out)
 
+    def run_async(self, post_mode=None):
+        """Queue network + post-process of the batch that is set (`stage_images`, `prefetch_images` + `swap_prefetched`)
+        WITHOUT ordering the handle behind the post-process: the next `run_async` starts its network at once, the ~4 ms of
+        aggregate / NMS / gather launches of this batch run beside it (`uda_run_async`).  Returns a ticket for `collect`;
+        at most two runs may be in flight."""
+        mode = self._mode(post_mode)
+        self._next_seed()
+        self._run_id += 1
+        t = C.c_int32(-1)
+        self._ck(self._lib.uda_run_async(self._h, mode, C.byref(t)), "uda_run_async")
+        if not hasattr(self, "_tickets"):
+            self._tickets = {}
+        self._tickets[t.value] = (self._n_last(), mode)
+        return t.value
+
+    def collect(self, ticket):
+        """The detections of a `run_async` (same tuple as `serve`): waits for that run's post-process only."""
+        n, mode = self._tickets.pop(ticket)
+        bc, cc = C.c_int32(), C.c_int32()
+        self._ck(self._lib.uda_detection_cols(self._h, mode, C.byref(bc), C.byref(cc)), "uda_detection_cols")
+        boxes = np.empty((n, self.M, bc.value), np.float32)
+        scores = np.empty((n, self.M), np.float32)
+        classes = np.empty((n, self.M, cc.value), np.float32)
+        valid = np.empty((n,), np.int32)
+        with_logits = self.params["enable_softmax"] and mode == capi.POST_GLOBAL
+        logits = np.empty((n, self.M, self.num_classes), np.float32) if with_logits else None
+        self._ck(self._lib.uda_collect(self._h, ticket, _ptr(boxes), _ptr(scores), _ptr(classes), _ptr(valid), _ptr(logits)),
+                 "uda_collect")
+        if cc.value == 1:
+            classes = classes[..., 0]
+        out = [boxes, scores, classes, valid]
+        if logits is not None:
+            out.append(logits)
+        return tuple(out)
+
+    def collect_device(self, ticket, rows=None):
+        """`collect` for the multi-GPU gather: the run's detections as one device-resident record buffer
+        (device address, rows, layout) - see `detections_device`; closes the ticket."""
+        n, mode = self._tickets.pop(ticket)
+        rows = n if rows is None else int(rows)
+        bc, cc = C.c_int32(), C.c_int32()
+        self._ck(self._lib.uda_detection_cols(self._h, mode, C.byref(bc), C.byref(cc)), "uda_detection_cols")
+        with_logits = bool(self.params["enable_softmax"] and mode == capi.POST_GLOBAL)
+        ptr, cols = C.c_void_p(), C.c_int32()
+        self._ck(self._lib.uda_collect_device(self._h, ticket, rows, int(with_logits), C.byref(ptr), C.byref(cols)), "uda_collect_device")
+        layout = dict(box=bc.value, cls=cc.value, logits=self.num_classes if with_logits else 0)
+        assert cols.value == layout["box"] + 1 + layout["cls"] + layout["logits"] + 1
+        return ptr.value, rows, layout
+
     def detections_device(self, rows=None, mode=None):
         """The detections of the last run as ONE device-resident record buffer: (device address, rows, layout) with the
         float32 buffer [rows, M, cols] laid out as `dist.pack_detections` does on the host.  rows >= the images of the last
@@ -287,6 +336,22 @@ class ServingDriver:
         except StopIteration:
             return
         n = self._feed(first)
+        if while_resident is None:
+            # nothing has to look at a batch's outputs inside the handle: the batches are pipelined - batch i + 1's network is
+            # queued before batch i's detections are fetched, batch i's post-process runs beside it (uda_run_async)
+            self._last_n = n
+            t = self.run_async(mode)
+            while True:
+                nxt = next(it, None)
+                if nxt is not None:
+                    n_next = self._feed(nxt, prefetch=True)
+                    self._ck(self._lib.uda_swap_prefetched(self._h), "uda_swap_prefetched")
+                    self._last_n = n_next
+                    t_next = self.run_async(mode)
+                yield self.collect(t)
+                if nxt is None:
+                    return
+                t = t_next
         while True:
             self._next_seed()
             self._run_id += 1
