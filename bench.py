@@ -52,8 +52,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 KIND_NAMES = {1: "stem", 2: "pw", 3: "dw", 4: "se", 5: "fuse", 6: "pool", 7: "mbx", 8: "sep", 16: "aggregate", 17: "nms",
               18: "preprocess"}
 # kernels behind each op kind (tools/traffic_from_pmc.py groups rocprofv3 kernel names with the same table)
-KIND_KERNELS = {"stem": "stem16_kernel", "pw": "pwb_kernel", "dw": "dw_kernel", "se": "se_kernel", "fuse": "fuse_kernel",
-                "pool": "fuse_kernel", "mbx": "mbxb_kernel+mbxd_kernel+mbxp_kernel", "sep": "sep_kernel", "aggregate": "aggregate_reg_kernel",
+KIND_KERNELS = {"stem": "stem_u8_kernel | stem16_kernel", "pw": "pwb_kernel", "dw": "dw_kernel", "se": "se_kernel", "fuse": "fuse_kernel",
+                "pool": "fuse_kernel", "mbx": "mbxb_kernel+mbxd_kernel+mbxp_kernel", "sep": "sep_kernel+sepf_kernel", "aggregate": "aggregate_reg_kernel",
                 "nms": "nms_coop_kernel", "preprocess": "preprocess_kernel"}
 LAYERWISE_MB_PER_UNIT = {("efficientdet-d0", "1280x768", 7): 1798.7}   # SURVEY 8d, full MC
 CONFIG_NAMES = {1: "BASELINE configs[1]", 2: "BASELINE configs[2], per-GPU share", 3: "BASELINE configs[3]",

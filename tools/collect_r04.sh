@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-side"
+B="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-side --protocol serial"      # (one step at a time: no post-process of the previous step beside the first ops)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- $B > $OUT/${TAG}_stats.log 2>&1
 for f in kernel_stats kernel_trace; do F=$(find $OUT/${TAG}_stats -name "*${f}.csv" | head -1); [ -n "$F" ] && cp $F $OUT/${TAG}_${f}.csv; done
 rm -rf $OUT/${TAG}_stats
@@ -18,7 +18,7 @@ UDA_PW_SCHEME=bf16x3 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output
 F=$(find $OUT/${TAG}_stats6 -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp $F $OUT/${TAG}_bf16x3_kernel_stats.csv
 rm -rf $OUT/${TAG}_stats6
 echo "bf16x3 stats done"
-B1="python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-side"
+B1="python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-side --protocol serial"
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_$C -- $B1 > $OUT/${TAG}_$C.log 2>&1
   F=$(find $OUT/${TAG}_$C -name "*counter_collection.csv" | head -1); [ -n "$F" ] && cp $F $OUT/${TAG}_${C}.csv

@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-side"
+B="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-side --protocol serial"
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/pq -- $B > /tmp/pq.log 2>&1 || { tail -5 /tmp/pq.log; exit 1; }
 F=$(find /tmp/pq -name "*kernel_trace.csv" | head -1)
 EXTRA=""
