@@ -304,7 +304,10 @@ def main():
 
     if a.protocol == "pipelined":
         consume(drv.run_async())                   # untimed: the second output set and the events of the pipelined runs
+        drv.profile_read(dominant)                 # (reset: the dominant kind's events cover the timed region only)
     elapsed, lat = timed_steps(a.protocol, a.steps)
+    dom_ms, dom_launches = drv.profile_read(dominant)
+    drv.profile_enable([])
     for i, l in enumerate(lat):
         log("timed step %d: %.1f ms" % (i + 1, l * 1e3))
     if dist is not None:
@@ -313,8 +316,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    dom_ms, dom_launches = drv.profile_read(dominant)
-    drv.profile_enable([])
     costs = plan_mod.op_costs(drv.plan, a.batch)
     units = world * a.batch * a.samples * a.steps
     value = units / elapsed
