@@ -300,15 +300,23 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
 // that is computed rather than read - the BiFPN fusion act(sum_i w_i resample_i(in_i)) of the node the separable conv
 // belongs to (FIN; efficientdet_keras.py:90-136 + 207-227): the fused tensor never goes to HBM, fuse_kernel's launch, its
 // write and this kernel's read of it disappear.
-//   tile      16 x 16 outputs per block of four waves (halo 18 x 18: 1.27x instead of 1.41x for 8 x 16), staged 32 channels
-//             at a time as [324 pixels][32 + 4] float32 (46.6 KB; the k-steps of a pass accumulate into the same accumulators)
+//   tile      16 x 16 outputs per block of four waves (halo 18 x 18: 1.27x instead of 1.41x for 8 x 16), staged PC = 16 or 32
+//             channels at a time as [324 pixels][PC + 4] float32 (26 / 47 KB; the k-steps of a pass accumulate into the same
+//             accumulators).  16-channel passes (three blocks per CU) for plain and identity + nearest-up inputs; pooled inputs
+//             read a 2x larger map, where 64-byte pieces of a pixel doubled the traffic: 32-channel passes (sepf_cfg)
+//   staging   U elements (pixel, channel quad) per thread with ALL their loads in flight before the first use: branch-free
+//             samplers per mode signature (sepf_stage); a generic one-element-at-a-time loop for anything else
 //   depthwise a wave owns four tile rows = two MFMA row tiles; lane (li, lh) computes pixel li of row tile lh, EIGHT channels
 //             at a time - the same eight channels on every lane, so the 72 taps of a channel group are wave-uniform (scalar
 //             loads, scalar operands of the FMAs: no LDS or vector-memory traffic for the taps); its window arrives in 18
-//             ds_read_b128 (pitch 36 dwords: the 16 pixels of a tile row cover the 64 banks exactly once)
+//             ds_read_b128 (pitch PC + 4 dwords: the 16 pixels of a tile row start on 16 different bank quads)
 //   fragments two channel groups make one k-step: lane halves trade them with v_permlane32_swap (upper half of group 0 <->
 //             lower half of group 1) and each operand register is then the A fragment of row tile 0 / row tile 1 - no LDS
 //             round trip of the depthwise result, no second barrier
+//   blocks    given to XCDs by sample row (a tile's halo is fetched into ONE L2); epilogue per wave through its own staging
+//             rows, loads first, eight stores back to back (see pwb_kernel)
+// What bounds it: bytes in flight per CU - requesting the next pass ahead (PIPE) hides nothing, the matrix stage of
+// a pass is an order of magnitude shorter than the memory latency, and costs the third block per CU.
 constexpr int SF_T = 16, SF_TP = SF_T + 2, SF_NPX = SF_TP * SF_TP;      // (channels per pass PC, tile pitch PC + 4: template)
 
 __device__ __forceinline__ void swap_halves(bf16x8& a, bf16x8& b) {      // a[32..63] <-> b[0..31], per 32-bit register
