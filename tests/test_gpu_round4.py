@@ -122,14 +122,28 @@ dev_t, layout = udist.all_gather_detections_device(d, udist.shard_range(5, rank,
                                                    [udist.shard_range(5, r, world)[1] - udist.shard_range(5, r, world)[0] for r in range(world)],
                                                    tdev, to_host=False)
 assert dev_t.is_cuda and dev_t.shape[1] == d.M
+# pipelined: two batches in flight on every rank, each gathered from its own ticket (uda_collect_device)
+imgs2 = make_images(5, 100, 180, seed=73)
+lo, hi = udist.shard_range(5, rank, world)
+counts = [udist.shard_range(5, r, world)[1] - udist.shard_range(5, r, world)[0] for r in range(world)]
+d.set_image_offset(lo)
+d.stage_images(imgs[lo:hi]); t0 = d.run_async()
+d.stage_images(imgs2[lo:hi]); t1 = d.run_async()
+got_p0 = udist.all_gather_detections_device(d, hi - lo, counts, tdev, ticket=t0)
+got_p1 = udist.all_gather_detections_device(d, hi - lo, counts, tdev, ticket=t1)
 if rank == 0:
     one = KerasDriver("_", False, p["name"], 5, False, p, weights=w, device=local)
     one.set_dropout_seed(17)
     want = one.serve(imgs)
+    want2 = one.serve(imgs2)
     one.close()
     assert len(got) == len(want)
     for g, r in zip(got, want):
         assert g.dtype == r.dtype and np.array_equal(g, r), "device-resident gather differs from serve()"
+    for g, r in zip(got_p0, want):
+        assert np.array_equal(g, r), "pipelined gather (first ticket) differs from serve()"
+    for g, r in zip(got_p1, want2):
+        assert np.array_equal(g, r), "pipelined gather (second ticket) differs from serve()"
     print("rccl gather ok", world)
 d.close()
 dist.barrier(); dist.destroy_process_group()
