@@ -96,6 +96,9 @@ fetch = pmc_per_op(a.fetch, "FETCH_SIZE", 2.0) if a.fetch else None   # gfx950: 
 write = pmc_per_op(a.write, "WRITE_SIZE", 1.0) if a.write else None
 if fetch or write:
     res = [r + ((fetch[i] if fetch else 0.0) + (write[i] if write else 0.0),) for i, r in enumerate(res)]
+    if write:       # write counter against the op's output size (a ratio well above 1: partially written lines)
+        outs = [sum(size(o["out"]) + (size(o["se_partial"]) if o["se_partial"] >= 0 and o["kind"] != capi.OP_SE else 0) for o in unit) * 4 for unit in units]
+        res = [r + (write[i] / max(outs[i], 1),) for i, r in enumerate(res)]
 tot = sum(r[0] for r in res)
 print("chunk of %d images: %d ops in %d launches, %.2f ms kernel time" % (a.chunk, len(pl.ops), nops, tot / 1e3))
 for kind in ("pw", "dw", "mbx", "sep", "se", "fuse", "stem", "pool"):
@@ -108,4 +111,6 @@ print("top ops:")
 for r in sorted(res, reverse=True)[:a.top]:
     dur, desc, name, by, fl, kn, vg = r[:7]
     extra = "  hbm %7.1f MB = %.2fx alg, %6.0f GB/s" % (r[7] / 1e6, r[7] / by, r[7] / dur / 1e3) if len(r) > 7 else ""
+    if len(r) > 8:
+        extra += "  wr %.2fx" % r[8]
     print("  %8.1f us  %-28s %-22s %7.1f GB/s %6.1f TF/s  %s v%s%s" % (dur, desc, name, by / dur / 1e3, fl / dur / 1e6, kn, vg, extra))

@@ -158,8 +158,8 @@ __global__ __launch_bounds__(256) void stem_u8_kernel(StemArgs a) {
   __syncthreads();
   const int cgn = SW ? 1 : a.Co / CG;
   const int64_t total = (int64_t)a.rows * a.Ho * a.Wo * cgn;
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= total) return;
+  const int64_t gid_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t gid = gid_raw < total ? gid_raw : total - 1;      // (threads beyond the end recompute the last unit and store nothing)
   const int cg = SW ? 0 : (int)(gid % cgn);
   int64_t p = gid / cgn;
   const int x = (int)(p % a.Wo);
@@ -208,7 +208,11 @@ __global__ __launch_bounds__(256) void stem_u8_kernel(StemArgs a) {
       acc[q].w = fmaf(v[t], w.w, acc[q].w);
     }
   }
-  float* op = a.out + (size_t)gid * CG;
+  // A thread holds CG consecutive output floats (128 / 64 bytes): stored as they are, one instruction puts 16 bytes into each
+  // of 64 different cache lines (the write counter showed 2.5x the tensor's size).  The wave's 64 x CG values go through a
+  // wave-private LDS tile instead and leave as contiguous kilobytes: eight (four) lanes per unit, 16 bytes each.
+  float* tile = lut + 768 + (threadIdx.x >> 6) * 64 * (CG + 4);
+  const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int q = 0; q < CG / 4; ++q) {
     const float4 s = *(const float4*)(a.bn_scale + cg * CG + q * 4);
@@ -218,7 +222,16 @@ __global__ __launch_bounds__(256) void stem_u8_kernel(StemArgs a) {
     o.y = swishf(fmaf(acc[q].y, s.y, t.y));
     o.z = swishf(fmaf(acc[q].z, s.z, t.z));
     o.w = swishf(fmaf(acc[q].w, s.w, t.w));
-    *(float4*)(op + q * 4) = o;
+    *(float4*)(tile + lane * (CG + 4) + q * 4) = o;
+  }
+  __builtin_amdgcn_wave_barrier();
+  constexpr int LPU = CG / 4;                       // lanes per unit in the store pass
+  const int64_t wave0 = gid_raw - lane;             // first unit of this wave
+  float* ob = a.out + (size_t)wave0 * CG;
+#pragma unroll
+  for (int it = 0; it < LPU; ++it) {
+    const int u = it * (64 / LPU) + lane / LPU, q = lane % LPU;
+    if (wave0 + u < total) *(float4*)(ob + (size_t)u * CG + q * 4) = *(const float4*)(tile + u * (CG + 4) + q * 4);
   }
 }
 
@@ -226,16 +239,17 @@ bool stem_u8_supported(int Co) { return (Co & 15) == 0 && Co <= 64; }
 
 void launch_stem(const StemArgs& a, hipStream_t s) {
   if (a.u8) {
-    const size_t lds = (27 * (size_t)a.Co + 768) * sizeof(float);
+    // weights [27][Co] (not for the scalar-weight variant) | table [3][256] | four wave-private store tiles [64][CG + 4]
+    auto lds_of = [&](int cg_, bool sw) { return ((sw ? 0 : 27 * (size_t)a.Co) + 768 + 4 * 64 * (size_t)(cg_ + 4)) * sizeof(float); };
     if (a.Co == 32) {              // (EfficientNet-B0 ... B2)
       const int64_t total = (int64_t)a.rows * a.Ho * a.Wo;
-      hipLaunchKernelGGL((stem_u8_kernel<32, true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 768 * sizeof(float), s, a);
+      hipLaunchKernelGGL((stem_u8_kernel<32, true>), dim3((unsigned)((total + 255) / 256)), dim3(256), lds_of(32, true), s, a);
     } else if ((a.Co & 31) == 0) {
       const int64_t total = (int64_t)a.rows * a.Ho * a.Wo * (a.Co >> 5);
-      hipLaunchKernelGGL((stem_u8_kernel<32, false>), dim3((unsigned)((total + 255) / 256)), dim3(256), lds, s, a);
+      hipLaunchKernelGGL((stem_u8_kernel<32, false>), dim3((unsigned)((total + 255) / 256)), dim3(256), lds_of(32, false), s, a);
     } else {
       const int64_t total = (int64_t)a.rows * a.Ho * a.Wo * (a.Co >> 4);
-      hipLaunchKernelGGL((stem_u8_kernel<16, false>), dim3((unsigned)((total + 255) / 256)), dim3(256), lds, s, a);
+      hipLaunchKernelGGL((stem_u8_kernel<16, false>), dim3((unsigned)((total + 255) / 256)), dim3(256), lds_of(16, false), s, a);
     }
     return;
   }
