@@ -381,3 +381,75 @@ def test_pipelined_run_bookkeeping_is_enforced():
     assert not np.array_equal(second[1], first[1])
     d.run_resident()                       # nothing in flight any more
     d.close()
+
+
+PIPE_TIMEOUT_WORKER = r"""
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import numpy as np
+from common import FULL_MC, make_images, make_params, make_weights
+from uda_amd.infer_lib import KerasDriver
+# 384x512 input = 36 828 candidates per image: the cooperative NMS takes two blocks per problem
+p = make_params(image_size="512x384", **FULL_MC)
+w = make_weights(p, seed=33, cls_spread=20.0)
+imgs, imgs2 = make_images(2, 300, 480, seed=32), make_images(2, 280, 500, seed=34)
+ref = KerasDriver("_", False, p["name"], 2, False, p, weights=w)
+ref.set_dropout_seed(9)
+want, want2 = ref.serve(imgs), ref.serve(imgs2)
+fb0 = ref.nms_coop_fallbacks()
+ref.close()
+d = KerasDriver("_", False, p["name"], 2, False, p, weights=w)
+d.set_dropout_seed(9)
+# (a) the newest run: its collect redoes the post-process on the two-launch NMS - same detections, counted
+d.stage_images(imgs)
+t = d.run_async()
+got = d.collect(t)
+for g, r in zip(got, want):
+    assert np.array_equal(g, r)
+print("fallbacks", fb0, d.nms_coop_fallbacks())
+d.close()
+# (b) two in flight on a fresh handle (still on the cooperative NMS): the older run's candidates are gone - its collect fails
+d = KerasDriver("_", False, p["name"], 2, False, p, weights=w)
+d.set_dropout_seed(9)
+d.stage_images(imgs)
+t0 = d.run_async()
+d.prefetch_images(imgs2); d.swap_prefetched()       # (no synchronisation in between: t1 is queued right behind t0)
+t1 = d.run_async()
+try:
+    d.collect(t0)
+    print("older collect returned")
+except RuntimeError as e:
+    print("older collect raised:", str(e)[:160])
+got2 = d.collect(t1)            # the newest one is redone
+for g, r in zip(got2, want2):
+    assert np.array_equal(g, r)
+# an intervening synchronisation settles a run while it is still the newest one: then both collects succeed
+d2 = KerasDriver("_", False, p["name"], 2, False, p, weights=w)
+d2.set_dropout_seed(9)
+d2.stage_images(imgs); u0 = d2.run_async()
+d2.stage_images(imgs2); u1 = d2.run_async()          # stage_images synchronises: u0 is checked and redone there
+for g, r in zip(d2.collect(u0), want):
+    assert np.array_equal(g, r)
+for g, r in zip(d2.collect(u1), want2):
+    assert np.array_equal(g, r)
+d2.close()
+again = d.serve(imgs)           # the handle keeps working (two-launch NMS from now on)
+for g, r in zip(again, want):
+    assert np.array_equal(g, r)
+d.close()
+print("pipe timeout ok")
+"""
+
+
+def test_pipelined_run_with_a_timed_out_nms_barrier_fails_or_redoes_loudly():
+    """UDA_NMS_COOP_SPIN=1 forces the cooperative NMS's time-out (test hook).  A pipelined run that is still the newest one is
+    redone by its collect like a synchronous run (same detections, uda_nms_coop_fallbacks counts it); a run whose candidates a
+    newer run has already replaced cannot be redone: its collect raises instead of returning garbage, the newer run is
+    redone and the handle keeps serving on the two-launch NMS.  Without the hook nothing of this happens (other tests)."""
+    e = dict(os.environ, UDA_NMS_COOP_SPIN="1")
+    r = subprocess.run([sys.executable, "-c", PIPE_TIMEOUT_WORKER % {"root": ROOT}], cwd=ROOT, env=e, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "pipe timeout ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    fb = [l for l in r.stdout.splitlines() if l.startswith("fallbacks")][0].split()
+    assert int(fb[1]) >= 1 and int(fb[2]) >= 1, fb          # reference handle and pipelined handle both fell back (and said so)
+    assert "older collect raised:" in r.stdout and "cooperative NMS" in r.stdout, r.stdout[-1500:]

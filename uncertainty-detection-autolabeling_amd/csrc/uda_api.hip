@@ -1732,6 +1732,25 @@ static int join_async(uda_ctx* c) {
 
 static int finish_post(uda_ctx* c) {
   if (int rc = join_async(c)) return rc;
+  {
+    // an ordinary reader (uda_get_detections, calibrators, ...) beside an uncollected pipelined run reads the NEWEST run: that
+    // run's range / barrier / prefix flags are checked here, exactly as uda_collect would check them
+    int s = -1;
+    for (int i = 0; i < 2; ++i)
+      if (c->as[i].open && (s < 0 || c->as[i].seq > c->as[s].seq)) s = i;
+    if (s >= 0) {
+      uda_ctx::AsyncSlot& a = c->as[s];
+      if (a.coop_used || a.oor_armed || !a.pending.empty()) {
+        c->d_oboxes = a.oboxes; c->d_oscores = a.oscores; c->d_oclasses = a.oclasses; c->d_ologits = a.ologits; c->d_ovalid = a.ovalid;
+        c->d_scales_post = a.scales;
+        c->last_n = a.n; c->last_post_mode = a.mode;
+        c->coop_used = c->coop_used || a.coop_used;
+        c->oor_armed = c->oor_armed || a.oor_armed;
+        c->pfx_pending.insert(c->pfx_pending.end(), a.pending.begin(), a.pending.end());
+        a.coop_used = false; a.oor_armed = false; a.pending.clear();
+      }
+    }
+  }
   if (int rc = check_split_range(c)) return rc;
   if (c->coop_used) {        // a barrier of the cooperative NMS that timed out leaves garbage: fail loudly
     c->coop_used = false;
