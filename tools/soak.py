@@ -1,5 +1,7 @@
-"""Soak (run on the GPU box): the pipelined feed (prefetch on the copy stream, two input slots) against plain serve() over many
-steps - any race between an upload and the kernels reading a slot, or between steps, shows up as a mismatch."""
+"""Soak (run on the GPU box): serve_stream - the pipelined feed (prefetch on the copy stream, two input slots) AND, since round 4,
+pipelined steps (uda_run_async / uda_collect: a step's post-process beside the next step's network) - against plain serve() over
+many steps: any race between an upload and the kernels reading a slot, between a post-process and the next network's head writes,
+or between the two output sets shows up as a mismatch."""
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np
@@ -35,4 +37,5 @@ def run(image_size, hw, batch, n_batches, reps, T):
 
 bad = run("192x128", (128, 192), 6, 12, 600, 3)
 bad += run("1280x768", (768, 1280), 8, 6, 60, 10)
+bad += run("1280x768", (768, 1280), 32, 4, 40, 10)          # the headline shape: here the overlap is real (4 ms of post-process)
 sys.exit(1 if bad else 0)
