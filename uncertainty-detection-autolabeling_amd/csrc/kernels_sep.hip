@@ -315,8 +315,8 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
 //             round trip of the depthwise result, no second barrier
 //   blocks    given to XCDs by sample row (a tile's halo is fetched into ONE L2); epilogue per wave through its own staging
 //             rows, loads first, eight stores back to back (see pwb_kernel)
-// What bounds it: bytes in flight per CU - requesting the next pass ahead (PIPE) hides nothing, the matrix stage of
-// a pass is an order of magnitude shorter than the memory latency, and costs the third block per CU.
+// What bounds it: bytes in flight per CU - requesting the next pass ahead of the current pass's matrix stage was
+// built and removed: that stage is an order of magnitude shorter than the memory latency, and the registers cost the third block.
 constexpr int SF_T = 16, SF_TP = SF_T + 2, SF_NPX = SF_TP * SF_TP;      // (channels per pass PC, tile pitch PC + 4: template)
 
 __device__ __forceinline__ void swap_halves(bf16x8& a, bf16x8& b) {      // a[32..63] <-> b[0..31], per 32-bit register
@@ -450,60 +450,9 @@ static void sepf_stamp_dump() {
 #define SEPF_STAMP(i) do { } while (0)
 #endif
 
-// The same in two halves for the pipelined kernel: sepf_issue requests the raw values of a whole pass (U elements per
-// thread, NR = 1 plain | 2 identity + nearest-up), sepf_finish combines them (fuse_value_t's expression) and writes the tile.
-// Between the two the kernel computes the previous pass: the memory latency of passes 1.. hides behind the matrix stage.
-template <bool FIN, int U, int PC>
-__device__ __forceinline__ void sepf_issue(const SepArgs& a, const FuseArgs& f, float4 (&raw)[U][FIN ? 2 : 1], const float* inb, int b,
-                                           int oy0, int ox0, int c0, int pc4, int tid) {
-  constexpr int FULL4 = PC / 4;
-  const int H = a.H, W = a.W, C = a.C;
-  const int ne = SF_NPX * pc4;
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int e = tid + 256 * u < ne ? tid + 256 * u : tid;
-    const int px = pc4 == FULL4 ? e / FULL4 : e / pc4, q = e - px * pc4;
-    const int sy = px / SF_TP, sx = px - sy * SF_TP;
-    const int yc = min(max(oy0 - 1 + sy, 0), H - 1), xc = min(max(ox0 - 1 + sx, 0), W - 1);
-    const int c4 = (c0 >> 2) + q;
-    if constexpr (FIN) {
-      raw[u][0] = fuse_sample_t<UDA_RS_NONE>(f, 0, b, yc, xc, c4);
-      raw[u][1] = fuse_sample_t<UDA_RS_NEAREST_UP>(f, 1, b, yc, xc, c4);
-    } else {
-      raw[u][0] = *(const float4*)(inb + ((size_t)yc * W + xc) * C + 4 * c4);
-    }
-  }
-}
-template <bool FIN, int U, int PC>
-__device__ __forceinline__ void sepf_finish(const SepArgs& a, const FuseArgs& f, const float4 (&raw)[U][FIN ? 2 : 1], float* T,
-                                            int oy0, int ox0, int pc4, int tid) {
-  constexpr int SF_PITCH = PC + 4, FULL4 = PC / 4;
-  const int ne = SF_NPX * pc4;
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int e = tid + 256 * u;
-    if (e < ne) {
-      const int px = pc4 == FULL4 ? e / FULL4 : e / pc4, q = e - px * pc4;
-      const int sy = px / SF_TP, sx = px - sy * SF_TP;
-      const int y = oy0 - 1 + sy, x = ox0 - 1 + sx;
-      float4 s = raw[u][0];
-      if constexpr (FIN) {
-        const float4 v = raw[u][1];
-        s.x *= f.wgt[0]; s.y *= f.wgt[0]; s.z *= f.wgt[0]; s.w *= f.wgt[0];
-        s.x = fmaf(v.x, f.wgt[1], s.x); s.y = fmaf(v.y, f.wgt[1], s.y);
-        s.z = fmaf(v.z, f.wgt[1], s.z); s.w = fmaf(v.w, f.wgt[1], s.w);
-        s.x = fuse_swish(s.x); s.y = fuse_swish(s.y); s.z = fuse_swish(s.z); s.w = fuse_swish(s.w);
-      }
-      if (!(y >= 0 && y < a.H && x >= 0 && x < a.W)) s = make_float4(0.f, 0.f, 0.f, 0.f);
-      *(float4*)(T + px * SF_PITCH + 4 * q) = s;
-    }
-  }
-}
-
-// PC = channels per pass: 32 | 16.  PIPE (plain input / identity + nearest-up fusion only): the next pass's values are
-// requested before the current pass is computed.
-template <int NT, int PARTS, bool FIN, int PC, bool PIPE>
-__global__ __launch_bounds__(256, (PC == 16 && !PIPE) ? 3 : 2) void sepf_kernel(SepArgs a, FuseArgs f, int sig, int rows) {
+// PC = channels per pass: 16 (three blocks per CU) | 32 (two)
+template <int NT, int PARTS, bool FIN, int PC>
+__global__ __launch_bounds__(256, PC == 16 ? 3 : 2) void sepf_kernel(SepArgs a, FuseArgs f, int sig, int rows) {
   extern __shared__ __attribute__((aligned(16))) unsigned char slds[];
   constexpr int NPC = split_np(PARTS);
   constexpr int SF_PC = PC, SF_PITCH = PC + 4;
@@ -553,9 +502,6 @@ __global__ __launch_bounds__(256, (PC == 16 && !PIPE) ? 3 : 2) void sepf_kernel(
   const unsigned long long st_w0 = wall_clock64();
 #endif
   const int npass = (C + SF_PC - 1) / SF_PC;
-  constexpr int UP = (SF_NPX * (PC / 4) + 255) / 256;      // elements per thread of a whole pass
-  float4 raw[PIPE ? UP : 1][FIN ? 2 : 1];
-  if constexpr (PIPE) sepf_issue<FIN, UP, PC>(a, f, raw, inb, b, oy0, ox0, 0, (C < SF_PC ? C : SF_PC) >> 2, tid);
   for (int ps = 0; ps < npass; ++ps) {
     const int c0 = ps * SF_PC;
     const int pch = C - c0 < SF_PC ? C - c0 : SF_PC;      // channels of this pass (a multiple of 8)
@@ -570,13 +516,7 @@ __global__ __launch_bounds__(256, (PC == 16 && !PIPE) ? 3 : 2) void sepf_kernel(
       const int nt = q % NT, ksl = q / NT;
       Bs[i] = nt < NTL ? Wp[(((size_t)(ps * (PC / 16) + ksl) * NTL + nt) * NPC + part) * 64 + (i & 63)] : make_uint4(0u, 0u, 0u, 0u);
     }
-    if constexpr (PIPE) {
-      sepf_finish<FIN, UP, PC>(a, f, raw, T, oy0, ox0, pc4, tid);
-      if (ps + 1 < npass) {
-        const int c1 = c0 + SF_PC;
-        sepf_issue<FIN, UP, PC>(a, f, raw, inb, b, oy0, ox0, c1, (C - c1 < SF_PC ? C - c1 : SF_PC) >> 2, tid);
-      }
-    } else if constexpr (!FIN) {
+    if constexpr (!FIN) {
       sepf_stage<SF_SIG_PLAIN, PC == 16 ? 6 : 11, PC>(a, f, T, inb, b, oy0, ox0, c0, pc4, tid);
     } else if (sig == SF_SIG_NU) {
       sepf_stage<SF_SIG_NU, PC == 16 ? 6 : 11, PC>(a, f, T, inb, b, oy0, ox0, c0, pc4, tid);
@@ -703,18 +643,13 @@ __global__ __launch_bounds__(256, (PC == 16 && !PIPE) ? 3 : 2) void sepf_kernel(
 #endif
 }
 
-// channels per pass / pipelining per staging signature: plain and identity + nearest-up inputs run 16-channel passes with the
-// next pass requested ahead; pooled inputs read a 2x larger map, where 64-byte pieces of a pixel doubled the traffic
-// (half-used 128-byte lines): 32-channel passes, not pipelined (11 raw values per element).  UDA_SEPF_PC / UDA_SEPF_PIPE: A/B.
-static void sepf_cfg(int sig, int* pc, int* pipe) {
-  static int epc = -1, epipe = -1;
-  if (epc < 0) {
-    const char* e = getenv("UDA_SEPF_PC"); epc = e ? atoi(e) : 0;
-    const char* q = getenv("UDA_SEPF_PIPE"); epipe = q ? atoi(q) : 0;
-  }
-  const bool simple = sig == SF_SIG_PLAIN || sig == SF_SIG_NU;
-  *pipe = simple && epipe;
-  *pc = epc == 16 || epc == 32 ? epc : (simple ? 16 : 32);
+// channels per pass per staging signature: plain and identity + nearest-up inputs run 16-channel passes; pooled inputs read a
+// 2x larger map, where 64-byte pieces of a pixel doubled the traffic (half-used 128-byte lines): 32-channel passes.
+// UDA_SEPF_PC = 16 | 32 forces one (A/B).
+static int sepf_pc(int sig) {
+  static int epc = -1;
+  if (epc < 0) { const char* e = getenv("UDA_SEPF_PC"); epc = e ? atoi(e) : 0; }
+  return epc == 16 || epc == 32 ? epc : ((sig == SF_SIG_PLAIN || sig == SF_SIG_NU) ? 16 : 32);
 }
 
 size_t sepf_lds_bytes(int C, int Cout, int scheme) {      // (the larger of the configurations)
@@ -741,8 +676,7 @@ static void launch_sepf_nt(const SepArgs& a, const FuseArgs& f, int rows, hipStr
     else if (f.n_in == 3 && f.mode[0] == UDA_RS_NONE && f.mode[1] == UDA_RS_NONE && pool_ok(2)) sig = SF_SIG_NNP;
     else if (f.n_in == 2 && f.mode[0] == UDA_RS_NONE && pool_ok(1)) sig = SF_SIG_NP;
   }
-  int pc, pipe;
-  sepf_cfg(sig, &pc, &pipe);
+  const int pc = sepf_pc(sig);
   const int npc = uda_split_pieces(a.wparts);
   size_t lds = (size_t)SF_NPX * (pc + 4) * 4 + (size_t)(pc / 16) * NT * npc * 1024;
   const size_t stg = (size_t)4 * 32 * PWB_STG * 4;
@@ -759,20 +693,14 @@ static void launch_sepf_nt(const SepArgs& a, const FuseArgs& f, int rows, hipStr
     if (a.H * a.W >= 96 * 160 && ++n_launch % 9 == 0) sepf_stamp_dump();
 #endif
   };
-  auto by_scheme = [&](auto pcv, auto pipev) {
+  auto by_scheme = [&](auto pcv) {
     constexpr int PC = decltype(pcv)::value;
-    constexpr bool PIPE = decltype(pipev)::value;
-    if (a.wparts == UDA_SPLIT_BF16X3) go(sepf_kernel<NT, 3, FIN, PC, PIPE>);
-    else if (a.wparts == UDA_SPLIT_F16X2) go(sepf_kernel<NT, 4, FIN, PC, PIPE>);
-    else go(sepf_kernel<NT, 2, FIN, PC, PIPE>);
+    if (a.wparts == UDA_SPLIT_BF16X3) go(sepf_kernel<NT, 3, FIN, PC>);
+    else if (a.wparts == UDA_SPLIT_F16X2) go(sepf_kernel<NT, 4, FIN, PC>);
+    else go(sepf_kernel<NT, 2, FIN, PC>);
   };
-  if (pipe) {
-    if (pc == 16) by_scheme(std::integral_constant<int, 16>{}, std::true_type{});
-    else by_scheme(std::integral_constant<int, 32>{}, std::true_type{});
-  } else {
-    if (pc == 16) by_scheme(std::integral_constant<int, 16>{}, std::false_type{});
-    else by_scheme(std::integral_constant<int, 32>{}, std::false_type{});
-  }
+  if (pc == 16) by_scheme(std::integral_constant<int, 16>{});
+  else by_scheme(std::integral_constant<int, 32>{});
 }
 
 // fused != nullptr: the conv's input is the BiFPN fusion described by *fused (a.in unused)
