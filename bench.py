@@ -462,6 +462,10 @@ def main():
             "roofline": roof,
             "pipeline": pipeline,
         }
+        if other_protocol is not None:      # both protocols at the top level too
+            tag = other_protocol["protocol"]
+            line["ms_per_step_" + tag] = other_protocol["ms_per_step"]
+            line["value_" + tag] = other_protocol["value"]
         line.update(side)
         if world == 1 and not a.no_side:
             log("GPU part done (%.2f units/s); child legs: other schemes, other BASELINE configs, side regimes ..." % value)
