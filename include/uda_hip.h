@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define UDA_ABI_VERSION 3
+#define UDA_ABI_VERSION 4
 #define UDA_MAX_LEVELS 8
 #define UDA_MAX_FUSE_INPUTS 3
 
@@ -64,7 +64,9 @@ enum uda_op_kind {
                        (+bias)(+BN)(+swish)(+dropout); the depthwise result never leaves the CU
                        (efficientdet_keras.py:207-227,421-446,584-626) */
 };
-enum uda_act { UDA_ACT_NONE = 0, UDA_ACT_SWISH = 1 };
+/* utils.activation_fn (reference utils.py:42-59): swish / silu / swish_native are one function; mish and srelu are refused
+ * by the planner (ValueError, as the reference raises for an unknown act_type) */
+enum uda_act { UDA_ACT_NONE = 0, UDA_ACT_SWISH = 1, UDA_ACT_RELU = 2, UDA_ACT_RELU6 = 3, UDA_ACT_HSWISH = 4 };
 enum uda_resample { UDA_RS_NONE = 0, UDA_RS_NEAREST_UP = 1, UDA_RS_MAXPOOL = 2 };
 
 typedef struct uda_op {
@@ -95,6 +97,8 @@ typedef struct uda_op {
                                       0 / 1 elsewhere. */
   int32_t fuse_in;                 /* SEP: 1 = the conv input is the BiFPN fusion swish(sum_i fuse_w[i] * resample[i](in[i])) of in[0 .. n_in),
                                       computed on the fly for the tile (no fused tensor in memory); 0 elsewhere */
+  int32_t fuse_act;                /* SEP with fuse_in: uda_act of that fusion (act_type; UDA_ACT_NONE under conv_bn_act_pattern,
+                                      efficientdet_keras.py:229-236) */
 } uda_op_t;
 
 /* ---- MC dropout sites -------------------------------------------------------------------- */

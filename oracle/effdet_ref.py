@@ -11,6 +11,9 @@ installable here).
   BiFPN node / fusion / cells   efficientdet_keras.py:86-127,174-182,229-236,788-801; fpn_configs.py:27-78
   class / box heads             efficientdet_keras.py:449-483,629-664
   MC loop and stacking          efficientdet_keras.py:979-1050; utils_extra.py:201-217
+  act_type family               utils.py:42-59 (the same function in backbone, BiFPN and heads: efficientdet_keras.py:864-868)
+  architecture switches         apply_bn_for_resampling / conv_after_downsample :313-338, conv_bn_act_pattern :218,229-236,
+                                fpn weight methods attn | fastattn | sum :96-124, fpn_config.nodes :773-781
 
 Dropout is injected: `masks[site]` is a float32 array [N, T, C] holding the
 keep-scale (0 or 1/(1-p)) of SpatialDropout2D (noise shape [N,1,1,C]) for
@@ -90,6 +93,22 @@ def swish(x):
     return x * torch.sigmoid(x)
 
 
+def activation(params):
+    """utils.activation_fn(features, act_type) as a function of the tensor (utils.py:42-59)."""
+    name = params.get("act_type", "swish")
+    if name in ("silu", "swish", "swish_native"):
+        return swish
+    if name == "hswish":
+        return lambda x: x * F.relu6(x + 3) / 6
+    if name == "relu":
+        return F.relu
+    if name == "relu6":
+        return F.relu6
+    if name == "mish":
+        return lambda x: x * torch.tanh(F.softplus(x))
+    raise ValueError("Unsupported act_type {}".format(name))
+
+
 def max_pool_same(x, k, s):
     return F.max_pool2d(_same_pad(x, k, s, value=float("-inf")), k, s)
 
@@ -119,8 +138,9 @@ def backbone(w, params, x, masks, t, taps=None):
     """Returns block outputs at reduction_1..5 (list of NCHW tensors)."""
     bb = params["backbone_name"]
     table = block_table(bb)
-    x = swish(batch_norm(conv2d(x, w[bb + "/stem/conv2d/kernel"], 2),
-                         w, bb + "/stem/tpu_batch_normalization"))
+    act = activation(params)
+    x = act(batch_norm(conv2d(x, w[bb + "/stem/conv2d/kernel"], 2),
+                       w, bb + "/stem/tpu_batch_normalization"))
     _tap(taps, "stem", x)
     feats = []
     for i, (k, s, e, cin, cout, _se) in enumerate(table):
@@ -129,21 +149,21 @@ def backbone(w, params, x, masks, t, taps=None):
         nb = 0
         bn_name = lambda j: p + "tpu_batch_normalization" + ("" if j == 0 else "_%d" % j)
         if e != 1:
-            x = swish(batch_norm(conv2d(x, w[p + "conv2d/kernel"]), w, bn_name(nb)))
+            x = act(batch_norm(conv2d(x, w[p + "conv2d/kernel"]), w, bn_name(nb)))
             nb += 1
             x = _drop(x, masks, "blocks_%d/expand" % i, t)
             _tap(taps, "blocks_%d/expand" % i, x)
             proj = p + "conv2d_1/kernel"
         else:
             proj = p + "conv2d/kernel"
-        x = swish(batch_norm(depthwise(x, w[p + "depthwise_conv2d/depthwise_kernel"], s),
-                             w, bn_name(nb)))
+        x = act(batch_norm(depthwise(x, w[p + "depthwise_conv2d/depthwise_kernel"], s),
+                           w, bn_name(nb)))
         nb += 1
         x = _drop(x, masks, "blocks_%d/dw" % i, t)
         _tap(taps, "blocks_%d/dw" % i, x)
         # squeeze-excite: global mean -> 1x1+bias -> swish -> 1x1+bias -> sigmoid -> scale
         sq = x.mean(dim=(2, 3), keepdim=True)
-        sq = swish(conv2d(sq, w[p + "se/conv2d/kernel"], 1, w[p + "se/conv2d/bias"]))
+        sq = act(conv2d(sq, w[p + "se/conv2d/kernel"], 1, w[p + "se/conv2d/bias"]))
         sq = conv2d(sq, w[p + "se/conv2d_1/kernel"], 1, w[p + "se/conv2d_1/bias"])
         _tap(taps, "blocks_%d/se" % i, torch.sigmoid(sq))
         x = torch.sigmoid(sq) * x
@@ -156,21 +176,28 @@ def backbone(w, params, x, masks, t, taps=None):
     return feats
 
 
-def _resample(w, prefix, feat, th, tw, F_ch):
-    """ResampleFeatureMap.call with conv_after_downsample=False, apply_bn=True."""
+def _resample(w, prefix, feat, th, tw, F_ch, params=None):
+    """ResampleFeatureMap.call (efficientdet_keras.py:313-350)."""
     H, W = feat.shape[-2:]
+    params = params or {}
+    apply_bn = params.get("apply_bn_for_resampling", True)
+    after = params.get("conv_after_downsample", False)
 
     def maybe_1x1(f):
         if f.shape[1] != F_ch:
             f = conv2d(f, w[prefix + "/conv2d/kernel"], 1, w[prefix + "/conv2d/bias"])
-            f = batch_norm(f, w, prefix + "/bn")
+            if apply_bn:
+                f = batch_norm(f, w, prefix + "/bn")
         return f
 
     if H > th and W > tw:
-        feat = maybe_1x1(feat)
+        if not after:
+            feat = maybe_1x1(feat)
         sh, sw = (H - 1) // th + 1, (W - 1) // tw + 1
         assert sh == sw, "square pooling windows only"
         feat = max_pool_same(feat, sh + 1, sh)
+        if after:
+            feat = maybe_1x1(feat)
     elif H <= th and W <= tw:
         feat = maybe_1x1(feat)
         if H < th or W < tw:
@@ -180,9 +207,9 @@ def _resample(w, prefix, feat, th, tw, F_ch):
     return feat
 
 
-def _sepconv(x, w, prefix, dwk="depthwise_kernel", pwk="pointwise_kernel"):
+def _sepconv(x, w, prefix, dwk="depthwise_kernel", pwk="pointwise_kernel", use_bias=True):
     x = depthwise(x, w[prefix + "/" + dwk], 1)
-    return conv2d(x, w[prefix + "/" + pwk], 1, w[prefix + "/bias"])
+    return conv2d(x, w[prefix + "/" + pwk], 1, w[prefix + "/bias"] if use_bias else None)
 
 
 def bifpn_nodes(min_level, max_level):
@@ -204,15 +231,24 @@ def fpn(w, params, feats, taps=None):
     F_ch, lo, hi = params["fpn_num_filters"], params["min_level"], params["max_level"]
     nodes = bifpn_nodes(lo, hi)
     method = params.get("fpn_weight_method") or "fastattn"
+    if params.get("fpn_config"):
+        nodes = [(int(n["feat_level"]), [int(o) for o in n["inputs_offsets"]]) for n in params["fpn_config"]["nodes"]]
+        method = params["fpn_config"].get("weight_method") or "fastattn"
+    act = activation(params)
+    cba = bool(params.get("conv_bn_act_pattern", False))
     for rep in range(params["fpn_cell_repeats"]):
         cell = list(feats)
         for n, (lvl, offsets) in enumerate(nodes):
             p = "fpn_cells/cell_%d/fnode%d/" % (rep, n)
             nf = len(cell)
             th, tw = cell[lvl - lo].shape[-2:]
-            ins = [_resample(w, p + "resample_%d_%d_%d" % (i, off, nf), cell[off], th, tw, F_ch)
+            ins = [_resample(w, p + "resample_%d_%d_%d" % (i, off, nf), cell[off], th, tw, F_ch, params)
                    for i, off in enumerate(offsets)]
-            if method == "fastattn":
+            if method == "attn":
+                ew = torch.softmax(torch.stack([_t(w[p + "WSM" + ("" if i == 0 else "_%d" % i)]).reshape(())
+                                                for i in range(len(ins))]), 0)
+                new = (torch.stack(ins, -1) * ew).sum(-1)
+            elif method == "fastattn":
                 ew = [torch.relu(_t(w[p + "WSM" + ("" if i == 0 else "_%d" % i)]))
                       for i in range(len(ins))]
                 tot = ew[0]
@@ -229,8 +265,12 @@ def fpn(w, params, feats, taps=None):
             else:
                 raise ValueError("unknown weight_method %s" % method)
             op = p + "op_after_combine%d" % nf
-            _tap(taps, "cell%d/fnode%d/fused" % (rep, n), swish(new))
-            new = batch_norm(_sepconv(swish(new), w, op + "/conv"), w, op + "/bn")
+            if not cba:
+                new = act(new)
+            _tap(taps, "cell%d/fnode%d/fused" % (rep, n), new)
+            new = batch_norm(_sepconv(new, w, op + "/conv", use_bias=not cba), w, op + "/bn")
+            if cba:
+                new = act(new)
             _tap(taps, "cell%d/fnode%d/out" % (rep, n), new)
             cell.append(new)
         feats = []
@@ -245,10 +285,11 @@ def fpn(w, params, feats, taps=None):
 def head(w, params, feats, net, tag, masks, t):
     outs = []
     lo = params["min_level"]
+    act = activation(params)
     for li, x in enumerate(feats):
         for i in range(params["box_class_repeats"]):
             x = _sepconv(x, w, "%s/%s-%d" % (net, tag, i))
-            x = swish(batch_norm(x, w, "%s/%s-%d-bn-%d" % (net, tag, i, lo + li)))
+            x = act(batch_norm(x, w, "%s/%s-%d-bn-%d" % (net, tag, i, lo + li)))
             x = _drop(x, masks, "%s-%d-%d" % (tag, i, lo + li), t)
         outs.append(_sepconv(x, w, "%s/%s-predict" % (net, tag)))
     return outs
@@ -263,7 +304,7 @@ def forward_once(w, params, images, masks=None, t=0, taps=None):
         for lvl in range(len(feats) + params["min_level"], params["max_level"] + 1):
             h, wd = feats[-1].shape[-2:]
             feats.append(_resample(w, "resample_p%d" % lvl, feats[-1],
-                                   (h + 1) // 2, (wd + 1) // 2, F_ch))
+                                   (h + 1) // 2, (wd + 1) // 2, F_ch, params))
             _tap(taps, "p%d_in" % lvl, feats[-1])
         pyr = fpn(w, params, feats, taps)
         cls = head(w, params, pyr, "class_net", "class", masks, t)

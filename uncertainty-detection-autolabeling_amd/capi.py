@@ -14,12 +14,12 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("UDA_LIB") or os.path.join(CSRC, "libuda_hip.so")   # UDA_LIB: an alternative build for A/B runs
 HEADER = os.path.join(os.path.dirname(HERE), "include", "uda_hip.h")
 
-UDA_ABI_VERSION = 3
+UDA_ABI_VERSION = 4
 MAX_LEVELS = 8
 MAX_FUSE = 3
 
 OP_STEM, OP_PW, OP_DW, OP_SE, OP_FUSE, OP_POOL, OP_MBX, OP_SEP = 1, 2, 3, 4, 5, 6, 7, 8
-ACT_NONE, ACT_SWISH = 0, 1
+ACT_NONE, ACT_SWISH, ACT_RELU, ACT_RELU6, ACT_HSWISH = 0, 1, 2, 3, 4
 RS_NONE, RS_NEAREST_UP, RS_MAXPOOL = 0, 1, 2
 DECODE_PLAIN, DECODE_LNORM, DECODE_FALSEDEC, DECODE_SAMPLE = 0, 1, 2, 3
 POST_GLOBAL, POST_PER_CLASS = 0, 1
@@ -43,7 +43,7 @@ class Op(C.Structure):
                 ("drop_site", C.c_int32), ("resample", C.c_int32 * MAX_FUSE),
                 ("fuse_w", C.c_float * MAX_FUSE), ("n_in", C.c_int32), ("drop_site2", C.c_int32),
                 ("w2_off", C.c_int64), ("bn2_scale_off", C.c_int64), ("bn2_shift_off", C.c_int64),
-                ("launch_group", C.c_int32), ("fuse_in", C.c_int32)]
+                ("launch_group", C.c_int32), ("fuse_in", C.c_int32), ("fuse_act", C.c_int32)]
 
 
 class DropSite(C.Structure):

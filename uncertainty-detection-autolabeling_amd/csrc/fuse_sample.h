@@ -54,6 +54,8 @@ __device__ __forceinline__ float4 fuse_value(const FuseArgs& a, int b, int y, in
   }
   if (a.act == UDA_ACT_SWISH) {
     s.x = fuse_swish(s.x); s.y = fuse_swish(s.y); s.z = fuse_swish(s.z); s.w = fuse_swish(s.w);
+  } else if (a.act >= UDA_ACT_RELU) {
+    s.x = act_relu_family(s.x, a.act); s.y = act_relu_family(s.y, a.act); s.z = act_relu_family(s.z, a.act); s.w = act_relu_family(s.w, a.act);
   }
   return s;
 }

@@ -68,11 +68,12 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
   }
   const float4 s = *(const float4*)(a.bn_scale + c4 * 4);
   const float4 t = *(const float4*)(a.bn_shift + c4 * 4);
-  float4 o;
-  o.x = swishf(fmaf(acc.x, s.x, t.x));
-  o.y = swishf(fmaf(acc.y, s.y, t.y));
-  o.z = swishf(fmaf(acc.z, s.z, t.z));
-  o.w = swishf(fmaf(acc.w, s.w, t.w));
+  float4 o = make_float4(fmaf(acc.x, s.x, t.x), fmaf(acc.y, s.y, t.y), fmaf(acc.z, s.z, t.z), fmaf(acc.w, s.w, t.w));
+  if (a.act == UDA_ACT_SWISH) {
+    o.x = swishf(o.x); o.y = swishf(o.y); o.z = swishf(o.z); o.w = swishf(o.w);
+  } else if (a.act >= UDA_ACT_RELU) {
+    o.x = act_relu_family(o.x, a.act); o.y = act_relu_family(o.y, a.act); o.z = act_relu_family(o.z, a.act); o.w = act_relu_family(o.w, a.act);
+  }
   *(float4*)(a.out + (size_t)gid * 4) = o;
 }
 
@@ -255,7 +256,7 @@ void launch_stem(const StemArgs& a, hipStream_t s) {
   }
   static int wide = -1;
   if (wide < 0) { const char* e = getenv("UDA_STEM16"); wide = e ? atoi(e) : 1; }
-  if (wide && (a.Co & 15) == 0) {
+  if (wide && (a.Co & 15) == 0 && a.act == UDA_ACT_SWISH) {     // (stem16 / stem_u8 are swish kernels; the executor keeps other activations off the uint8 route)
     const int64_t total = (int64_t)a.rows * a.Ho * a.Wo * (a.Co >> 4);
     hipLaunchKernelGGL(stem16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 27 * a.Co * sizeof(float), s, a);
     return;
@@ -416,6 +417,7 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(PwArgs a) {
         float v = acc[n][r] + bias;
         v = fmaf(v, sc, sh);
         if (a.act == UDA_ACT_SWISH) v = swishf(v);
+        else if (a.act >= UDA_ACT_RELU) v = act_relu_family(v, a.act);
         v *= mk;
         if (a.res) v += a.res[(res_base + m) * a.Cout + col];
         a.out[(out_base + m) * a.Cout + col] = v;
@@ -462,6 +464,8 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(PwArgs a) {
         v.w = fmaf(v.w + bias.w, sc.w, sh.w);
         if (a.act == UDA_ACT_SWISH) {
           v.x = swishf(v.x); v.y = swishf(v.y); v.z = swishf(v.z); v.w = swishf(v.w);
+        } else if (a.act >= UDA_ACT_RELU) {
+          v.x = act_relu_family(v.x, a.act); v.y = act_relu_family(v.y, a.act); v.z = act_relu_family(v.z, a.act); v.w = act_relu_family(v.w, a.act);
         }
         v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
         if (a.res) {
@@ -606,6 +610,8 @@ __global__ __launch_bounds__(256, (K == 5) ? 2 : 3) void dw_kernel(DwArgs a) {
               v.w = fmaf(acc[o].w, sc.w, sh.w);
               if (a.act == UDA_ACT_SWISH) {
                 v.x = swishf(v.x); v.y = swishf(v.y); v.z = swishf(v.z); v.w = swishf(v.w);
+              } else if (a.act >= UDA_ACT_RELU) {
+                v.x = act_relu_family(v.x, a.act); v.y = act_relu_family(v.y, a.act); v.z = act_relu_family(v.z, a.act); v.w = act_relu_family(v.w, a.act);
               }
               v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
               *(float4*)(outp + (size_t)x * a.C) = v;
@@ -747,7 +753,8 @@ __global__ __launch_bounds__(SE_THREADS) void se_kernel(SeArgs a) {
     __syncthreads();
     if (part == 0) {
       for (int q = 1; q < P; ++q) s += redf[q * a.mid + j];
-      mid[j] = swishf(s + a.b1[j]);
+      const float h = s + a.b1[j];
+      mid[j] = a.act == UDA_ACT_SWISH ? swishf(h) : (a.act >= UDA_ACT_RELU ? act_relu_family(h, a.act) : h);
     }
   }
   __syncthreads();

@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256, OCC) void pwb_kernel(PwArgs a) {
           float v = fmaf(acc[m_][n][r], un, bias);
           v = fmaf(v, sc, sh);
           if (a.act == UDA_ACT_SWISH) v = swishf_b(v);
+          else if (a.act >= UDA_ACT_RELU) v = act_relu_family(v, a.act);
           v *= mk;
           if (a.res) v += a.res[(res_base + m) * a.Cout + col];
           a.out[(out_base + m) * a.Cout + col] = v;
@@ -238,6 +239,8 @@ __global__ __launch_bounds__(256, OCC) void pwb_kernel(PwArgs a) {
         t.w = fmaf(fmaf(t.w, un, bias.w), sc.w, sh.w);
         if (a.act == UDA_ACT_SWISH) {
           t.x = swishf_b(t.x); t.y = swishf_b(t.y); t.z = swishf_b(t.z); t.w = swishf_b(t.w);
+        } else if (a.act >= UDA_ACT_RELU) {
+          t.x = act_relu_family(t.x, a.act); t.y = act_relu_family(t.y, a.act); t.z = act_relu_family(t.z, a.act); t.w = act_relu_family(t.w, a.act);
         }
         t.x *= mk.x; t.y *= mk.y; t.z *= mk.z; t.w *= mk.w;
         if (a.res) { t.x += rr[it].x; t.y += rr[it].y; t.z += rr[it].z; t.w += rr[it].w; }
@@ -347,6 +350,8 @@ __global__ __launch_bounds__(256, 3) void pwb_shared_kernel(PwArgs a) {
         v.w = fmaf(v.w + bias.w, sc.w, sh.w);
         if (a.act == UDA_ACT_SWISH) {
           v.x = swishf_b(v.x); v.y = swishf_b(v.y); v.z = swishf_b(v.z); v.w = swishf_b(v.w);
+        } else if (a.act >= UDA_ACT_RELU) {
+          v.x = act_relu_family(v.x, a.act); v.y = act_relu_family(v.y, a.act); v.z = act_relu_family(v.z, a.act); v.w = act_relu_family(v.w, a.act);
         }
         v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
         if (a.res) {

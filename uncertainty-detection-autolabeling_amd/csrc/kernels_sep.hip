@@ -216,6 +216,7 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
       for (int r = 0; r < 16; ++r) {
         float v = fmaf(fmaf(acc[n][r], un, bias), sc, sh);
         if (a.act == UDA_ACT_SWISH) v = swishf_b(v);
+        else if (a.act >= UDA_ACT_RELU) v = act_relu_family(v, a.act);
         v *= mk;
         st[((r & 3) + 8 * (r >> 2) + 4 * lh) * cw + n * 32 + li] = v;
       }
@@ -281,6 +282,8 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
       t.w = fmaf(fmaf(t.w, un, bias.w), sc.w, sh.w);
       if (a.act == UDA_ACT_SWISH) {
         t.x = swishf_b(t.x); t.y = swishf_b(t.y); t.z = swishf_b(t.z); t.w = swishf_b(t.w);
+      } else if (a.act >= UDA_ACT_RELU) {
+        t.x = act_relu_family(t.x, a.act); t.y = act_relu_family(t.y, a.act); t.z = act_relu_family(t.z, a.act); t.w = act_relu_family(t.w, a.act);
       }
       t.x *= mk.x; t.y *= mk.y; t.z *= mk.z; t.w *= mk.w;
       v[it] = t;
@@ -619,6 +622,8 @@ __global__ __launch_bounds__(256, PC == 16 ? 3 : 2) void sepf_kernel(SepArgs a, 
         w.w = fmaf(fmaf(w.w, un, bias.w), sc.w, sh.w);
         if (a.act == UDA_ACT_SWISH) {
           w.x = swishf_b(w.x); w.y = swishf_b(w.y); w.z = swishf_b(w.z); w.w = swishf_b(w.w);
+        } else if (a.act >= UDA_ACT_RELU) {
+          w.x = act_relu_family(w.x, a.act); w.y = act_relu_family(w.y, a.act); w.z = act_relu_family(w.z, a.act); w.w = act_relu_family(w.w, a.act);
         }
         w.x *= mk.x; w.y *= mk.y; w.z *= mk.z; w.w *= mk.w;
         v[it] = w;

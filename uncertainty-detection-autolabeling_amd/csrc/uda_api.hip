@@ -85,6 +85,7 @@ struct uda_ctx {
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_pre_done[2] = {nullptr, nullptr};   // the preprocess kernel has consumed slot i (its buffer may be refilled)
   bool have_u8 = false;
+  int stem_act = UDA_ACT_SWISH; // activation of the stem op (the uint8 stem is a swish kernel)
   bool stem_from_u8 = false;   // this run's stem ops read the uint8 slot (set by run_network)
   bool pre_valid = false;      // d_images holds the preprocessed current batch (false: the stem read the uint8 images itself)
   int stem_co = 0;             // output channels of the stem op (0: no stem op in the plan)
@@ -442,7 +443,10 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
   c->bufs.assign(bufs, bufs + n_bufs);
   c->ops.assign(ops, ops + n_ops);
   for (int i = 0; i < n_ops; ++i)
-    if (ops[i].kind == UDA_OP_STEM && ops[i].out >= 0 && ops[i].out < n_bufs) c->stem_co = bufs[ops[i].out].C;
+    if (ops[i].kind == UDA_OP_STEM && ops[i].out >= 0 && ops[i].out < n_bufs) {
+      c->stem_co = bufs[ops[i].out].C;
+      c->stem_act = ops[i].act;
+    }
   if (model->n_drop_sites > 0 && sites) c->sites.assign(sites, sites + model->n_drop_sites);
   c->device = device;
   c->n_weights = n_weights;
@@ -482,6 +486,18 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
         (!okbuf(o.se_scale) || o.se_mid != 16 || bufs[o.in[0]].C > 32 || bufs[o.in[0]].C % 8 || bufs[o.se_scale].C != bufs[o.in[0]].C ||
          o.se_w1_off < 0 || o.se_b1_off < 0 || o.se_w2_off < 0)) {
       fail(nullptr, "op %d: fused projection needs a [rows, C0 <= 32] gate, a 16-channel projection and its kernel / BN offsets", i);
+      uda_destroy(c);
+      return 1;
+    }
+    if (o.act < UDA_ACT_NONE || o.act > UDA_ACT_HSWISH || o.fuse_act < UDA_ACT_NONE || o.fuse_act > UDA_ACT_HSWISH) {
+      fail(nullptr, "op %d: unknown activation %d / %d", i, o.act, o.fuse_act);
+      uda_destroy(c);
+      return 1;
+    }
+    if (o.kind == UDA_OP_MBX && o.act != UDA_ACT_SWISH) {
+      // the fused MBConv kernels fold the swish into their BN scales (swish_core / swish_folded): the planner keeps any
+      // other act_type on the unfused expand / depthwise ops
+      fail(nullptr, "op %d: the fused MBConv front half is a swish kernel (act %d)", i, o.act);
       uda_destroy(c);
       return 1;
     }
@@ -1064,6 +1080,7 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       a.pad_t = same_pad_before(ib.H, ob.H, 3, 2);
       a.pad_l = same_pad_before(ib.W, ob.W, 3, 2);
       a.rows = rows;
+      a.act = o.act;
       if (c->stem_from_u8) {
         if (ib.kind != 1 || ib.per_sample) return fail(c, "op %d: the uint8 stem reads the image buffer", oi);
         const uda_ctx::U8Slot& sl = c->u8[c->cur];
@@ -1225,10 +1242,11 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       a.in_div = v.div(ib, ob);
       a.act = o.act;
       if (o.fuse_in) {
-        // the node's BiFPN fusion is this conv's input, computed on the fly (swish: efficientdet_keras.py:131-136)
+        // the node's BiFPN fusion is this conv's input, computed on the fly (act_type, or none under conv_bn_act_pattern:
+        // efficientdet_keras.py:229-236)
         FuseArgs f{};
         if (int rc = fill_fuse_args(c, v, oi, f)) return rc;
-        f.act = UDA_ACT_SWISH;
+        f.act = o.fuse_act;
         if (!sepf_supported(a.C, a.Cout, a.wparts)) return fail(c, "op %d: fused-input separable conv %d -> %d not supported", oi, a.C, a.Cout);
         a.in = nullptr;
         launch_sepf(a, &f, rows, v.stream());
@@ -1255,6 +1273,7 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       // deferred dropout site (plan.py): the squeezed tensor is per image, its keep-scale per sample row
       a.mask = v.mask(o.drop_site);
       a.in_div = v.div(pb, ob);
+      a.act = o.act;
       if (o.drop_site >= 0 && !ob.per_sample && c->model.mc_samples > 1) return fail(c, "op %d: deferred dropout needs a per-sample gate", oi);
       if (pb.per_sample != src.per_sample) return fail(c, "op %d: SE sums and source disagree on the sample axis", oi);
       launch_se(a, rows, v.stream());
@@ -1366,7 +1385,7 @@ static int run_network(uda_ctx* c, int post_mode = 0, bool chunk_post = false, h
   if (c->have_u8) {
     static const bool on = !(getenv("UDA_STEM_U8") && atoi(getenv("UDA_STEM_U8")) == 0);
     const uda_ctx::U8Slot& sl = c->u8[c->cur];
-    stem_u8 = on && c->stem_co > 0 && stem_u8_supported(c->stem_co);
+    stem_u8 = on && c->stem_co > 0 && stem_u8_supported(c->stem_co) && c->stem_act == UDA_ACT_SWISH;
     for (int i = 0; i < n && stem_u8; ++i) stem_u8 = sl.geo[i].sh == sl.geo[i].h && sl.geo[i].sw == sl.geo[i].w;
     c->pre_valid = false;
     if (!stem_u8) {

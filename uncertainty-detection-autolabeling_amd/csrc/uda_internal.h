@@ -47,6 +47,18 @@ __device__ __forceinline__ void philox_normal2(uint64_t seed, uint32_t i0, uint3
   z0 = r * cos(th);
   z1 = r * sin(th);
 }
+
+// The activations of utils.activation_fn (reference utils.py:42-59) other than swish, which every kernel keeps as its own
+// first branch (`act == UDA_ACT_SWISH`): relu = max(x, 0), relu6 = min(max(x, 0), 6), hswish = x * relu6(x + 3) / 6.
+// One clamp with two wave-uniform constants (+ a multiply for hswish; the division by six is a multiplication by its
+// float32 reciprocal, 1 ulp like the hardware rcp / exp2 of the swish path): four vector instructions and no live register
+// beyond the value, so the epilogues of the tuned kernels keep their register counts (tools/codeobj.py resources).
+__device__ __forceinline__ float act_relu_family(float v, int act) {
+  const float off = act == UDA_ACT_HSWISH ? 3.0f : 0.0f;
+  const float hi = act == UDA_ACT_RELU ? __builtin_inff() : 6.0f;
+  const float r = __builtin_amdgcn_fmed3f(v + off, 0.0f, hi);
+  return act == UDA_ACT_HSWISH ? (v * r) * 0.16666667163372040f : r;
+}
 #endif
 
 // ---------------------------------------------------------------- split-precision schemes of the 1x1 contractions
@@ -77,6 +89,7 @@ struct StemArgs {
   const PreGeo* geo;  // [images] (device)
   int img0;           // first image of this launch in geo
   float mean[3], stdv[3];
+  int act;            // uda_act (the specialised stems are swish kernels: any other activation runs stem_kernel)
 };
 
 struct PwArgs {
@@ -235,6 +248,7 @@ struct SeArgs {
   float inv_hw;
   const float* mask;     // [rows, C] deferred dropout keep-scale of the squeezed tensor, or null
   int in_div;            // partial sums are per input row: rows / in_div
+  int act;               // uda_act of the reduce layer (relu_fn, efficientnet_model.py:225)
 };
 
 struct FuseArgs {

@@ -27,6 +27,7 @@ draws a random-init set.  Keyword-only extras (device, chunk_images, weights, po
 the build's additions and never positional, so the reference's call expressions bind unchanged.
 """
 import ctypes as C
+import logging
 import time
 
 import numpy as np
@@ -76,6 +77,9 @@ class ServingDriver:
         if chunk_images is None:
             chunk_images = min(self._cap, int(self.params.get("uda_chunk_images", 16)))
         self.plan = plan_mod.Plan(self.params, weights, chunk_images=chunk_images, max_images=self._cap, post_only=post_only)
+        if self.plan.unknown_keys:
+            # not one of hparams_config's keys and not a `uda_*` knob: nothing here reads it (plan.MODEL_PARAM_HANDLING)
+            logging.warning("model_params keys the HIP path does not know (ignored): %s", ", ".join(self.plan.unknown_keys))
         self._post_mode = capi.POST_PER_CLASS if post_mode == "per_class" else capi.POST_GLOBAL
         self._lib = capi.load()
         m, bufs, ops, sites, blob, anchors = self.plan.to_c(self._post_mode)

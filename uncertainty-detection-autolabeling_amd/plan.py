@@ -136,6 +136,116 @@ def same_out(n, s):
     return -(-n // s)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Every key of hparams_config.default_detection_configs() and what the HIP path does with it.  The boundary promises the
+# reference's `model_params` dict: a key is either CONSUMED (the planner / the post-process reads it and the result
+# changes with it), INERT at inference (the reference itself never reads it on the serve path, or reads it only under
+# training=True), or checked by `check_model_params`, which raises the reference's kind of ValueError for a value the
+# path does not implement - never a silently different network (tests/test_plan_host.py walks this table).
+ACT_CODES = {"swish": capi.ACT_SWISH, "silu": capi.ACT_SWISH, "swish_native": capi.ACT_SWISH,
+             "relu": capi.ACT_RELU, "relu6": capi.ACT_RELU6, "hswish": capi.ACT_HSWISH}
+MODEL_PARAM_HANDLING = {
+    # --- network structure (efficientdet_keras.py:850-970, efficientnet_model.py:731-834)
+    "name": "inert: a label (the structure comes from the keys below)",
+    "backbone_name": "consumed: arch.backbone_blocks (efficientnet-b0..b7; anything else raises)",
+    "backbone_config": "consumed: arch.backbone_blocks (custom block table)",
+    "image_size": "consumed", "num_classes": "consumed", "min_level": "consumed", "max_level": "consumed",
+    "num_scales": "consumed", "aspect_ratios": "consumed", "anchor_scale": "consumed",
+    "mean_rgb": "consumed", "stddev_rgb": "consumed",
+    "box_class_repeats": "consumed", "fpn_cell_repeats": "consumed", "fpn_num_filters": "consumed",
+    "act_type": "consumed: swish | silu | swish_native | relu | relu6 | hswish; mish / srelu raise (utils.py:42-59)",
+    "separable_conv": "checked: False (dense 3x3 convs in BiFPN and heads) raises",
+    "apply_bn_for_resampling": "consumed (efficientdet_keras.py:313-318)",
+    "conv_after_downsample": "consumed (efficientdet_keras.py:331-338)",
+    "conv_bn_act_pattern": "consumed (efficientdet_keras.py:218,229-236)",
+    "fpn_name": "checked: None | bifpn | bifpn_dyn; qufpn raises",
+    "fpn_weight_method": "consumed: fastattn | attn | sum; channel_attn / channel_fastattn raise",
+    "fpn_config": "checked: None, or {nodes, weight_method} with at most three inputs per node",
+    "heads": "checked: must be ['object_detection'] (segmentation head is not on the path)",
+    "data_format": "checked: channels_last only",
+    "survival_prob": "inert: drop_connect acts under training=True only (efficientdet_keras.py:464-465)",
+    "is_training_bn": "inert: BN layers run with training=False at inference (moving statistics)",
+    "strategy": "inert: selects the BN class / TPU placement, same inference arithmetic",
+    "mixed_precision": "inert: the HIP path always computes in float32-class arithmetic (a superset)",
+    "grad_checkpoint": "inert: training memory option",
+    # --- uncertainty switches
+    "loss_attenuation": "consumed", "uncert_adjust_method": "consumed (l-norm | n-flow | falsedec | sample; else raises)",
+    "decode_nsamples": "consumed", "mc_dropout": "consumed", "mc_dropoutrate": "consumed", "mc_classheadrate": "consumed",
+    "mc_boxheadrate": "consumed", "mc_dropoutsamp": "consumed", "enable_softmax": "consumed",
+    "nms_configs": "consumed (method hard | gaussian; anything else raises; pyfunc is served by uda_nms_np)",
+    "tflite_max_detections": "inert: TFLite export only",
+    "max_instances_per_image": "inert: training / eval padding",
+    "clip_min_uncert": "inert: loss only", "clip_max_uncert": "inert: loss only",
+    "calibrate_classification": "consumed by calibration.py (above the driver)", "calib_method_class": "consumed by calibration.py",
+    "calibrate_regression": "consumed by calibration.py", "calib_method_box": "consumed by calibration.py",
+    "infer_draw_uncert": "consumed by visualize", "label_map": "consumed by infer_lib / writers",
+    # --- training-only keys the shipped YAMLs set
+    "assign_gt_box": "inert: validation matching above the driver", "early_stopping_patience": "inert: training",
+    "count_classes": "inert: training", "boxloss_type": "inert: training", "save_freq": "inert: training",
+    "sample_images": "inert: training", "sample_images_freq": "inert: training", "save_train_images": "inert: training",
+    "autoaugment_policy": "inert: training", "map_freq": "inert: training", "box_loss_weight": "inert: training",
+    "moving_average_decay": "consumed by weights.resolve_weights (EMA shadows)",
+}
+
+
+def act_code(cfg):
+    """uda_act of config.act_type; the reference's ValueError for anything utils.activation_fn does not know, and for the two
+    it knows that have no kernel here (mish, srelu - the latter carries a trainable beta)."""
+    name = cfg.get("act_type", "swish")
+    if name in ACT_CODES:
+        return ACT_CODES[name]
+    if name in ("mish", "srelu"):
+        raise ValueError("act_type %r is not available on the HIP path (implemented: %s)" % (name, ", ".join(sorted(ACT_CODES))))
+    raise ValueError("Unsupported act_type {}".format(name))
+
+
+def fpn_nodes(cfg):
+    """(nodes, weight_method) the way FPNCells / FPNCell pick them (efficientdet_keras.py:773-781,811-834):
+    config.fpn_config when given, else fpn_configs.get_fpn_config(fpn_name, ...)."""
+    lo, hi = cfg["min_level"], cfg["max_level"]
+    fc = cfg.get("fpn_config")
+    if fc:
+        fc = fc if isinstance(fc, dict) else fc.as_dict()
+        nodes = [dict(feat_level=int(n["feat_level"]), inputs_offsets=[int(o) for o in n["inputs_offsets"]]) for n in fc["nodes"]]
+        for n in fc["nodes"]:
+            if n.get("weight_method") not in (None, fc.get("weight_method")):
+                raise ValueError("fpn_config: per-node weight_method (qufpn) is not available on the HIP path")
+        return nodes, fc.get("weight_method") or "fastattn"
+    name = cfg.get("fpn_name")
+    if name not in (None, "", "bifpn", "bifpn_dyn"):
+        if name == "qufpn":
+            raise ValueError("fpn_name 'qufpn' is not available on the HIP path (bifpn only)")
+        raise KeyError(name)        # fpn_configs.get_fpn_config: name_to_config[fpn_name]
+    return arch.bifpn_nodes(lo, hi), cfg.get("fpn_weight_method") or "fastattn"
+
+
+def check_model_params(cfg):
+    """Raise for every architecture switch of `model_params` whose non-default value the HIP path does not implement
+    (a planner that builds the default network whatever the switch says is the worst failure mode of a
+    drop-in).  Called first thing by Plan.__init__ and by weights.variable_specs."""
+    act_code(cfg)
+    if not cfg.get("separable_conv", True):
+        raise ValueError("separable_conv=False (dense 3x3 convolutions in the BiFPN and the heads) is not available on the HIP path")
+    if cfg.get("data_format", "channels_last") != "channels_last":
+        raise ValueError("data_format %r: the HIP path is NHWC (channels_last) only" % (cfg.get("data_format"),))
+    heads = cfg.get("heads") or ["object_detection"]
+    if list(heads) != ["object_detection"]:
+        raise ValueError("heads %r: only ['object_detection'] is on the HIP path" % (list(heads),))
+    nodes, method = fpn_nodes(cfg)
+    if method not in ("fastattn", "attn", "sum"):
+        if method in ("channel_attn", "channel_fastattn"):
+            raise ValueError("fpn weight_method %r (per-channel fusion weights) is not available on the HIP path" % method)
+        raise ValueError("unknown weight_method %s" % method)
+    lo, hi = cfg["min_level"], cfg["max_level"]
+    for n in nodes:
+        if not 1 <= len(n["inputs_offsets"]) <= capi.MAX_FUSE:
+            raise ValueError("fpn node with %d inputs: the HIP fusion takes 1..%d" % (len(n["inputs_offsets"]), capi.MAX_FUSE))
+        if not lo <= n["feat_level"] <= hi:
+            raise ValueError("fpn node at level %d outside [%d, %d]" % (n["feat_level"], lo, hi))
+    unknown = sorted(k for k in cfg if k not in MODEL_PARAM_HANDLING and not k.startswith("uda_"))
+    return unknown      # keys the reference's defaults do not have (callers' own additions): reported, not refused
+
+
 class _Buf:
     __slots__ = ("H", "W", "C", "per_sample", "kind", "level", "offset", "first", "last", "name")
 
@@ -150,6 +260,8 @@ class Plan:
 
     def __init__(self, config, weights, chunk_images=1, max_images=1, post_only=False):
         self.cfg = dict(config)
+        self.unknown_keys = check_model_params(self.cfg)
+        self.act = act_code(self.cfg)
         self.post_only = bool(post_only)
         self.w = weights
         self.T = arch.mc_flags(self.cfg)[2]
@@ -240,7 +352,7 @@ class Plan:
                  stride=1, act=capi.ACT_NONE, w_off=-1, bias_off=-1, bn_scale_off=-1, bn_shift_off=-1,
                  se_w1_off=-1, se_b1_off=-1, se_w2_off=-1, se_b2_off=-1, se_mid=0, drop_site=-1,
                  resample=[0, 0, 0], fuse_w=[0.0, 0.0, 0.0], drop_site2=-1, w2_off=-1, bn2_scale_off=-1,
-                 bn2_shift_off=-1, launch_group=0, fuse_in=0)
+                 bn2_shift_off=-1, launch_group=0, fuse_in=0, fuse_act=capi.ACT_NONE)
         o.update(kw)
         self.ops.append(o)
         return out
@@ -287,7 +399,8 @@ class Plan:
             ps = any(b.per_sample for b in ibs) or site >= 0
             out = self._buf(fusion["H"], fusion["W"], cout, ps, out_kind, level, name)
             kw = dict(k=3, stride=1, w_off=self._pack(self.w[pw_kernel]), w2_off=self._pack(self.w[dw_kernel]), act=act,
-                      drop_site=site, fuse_in=1, resample=(list(fusion["resample"]) + [0, 0, 0])[:3],
+                      drop_site=site, fuse_in=1, fuse_act=fusion.get("act", capi.ACT_SWISH),
+                      resample=(list(fusion["resample"]) + [0, 0, 0])[:3],
                       fuse_w=(list(fusion["fuse_w"]) + [0, 0, 0])[:3])
             if bias is not None:
                 kw["bias_off"] = self._pack(self.w[bias])
@@ -334,9 +447,14 @@ class Plan:
         """ResampleFeatureMap.call: optional 1x1+BN to F channels, then (mode for the consumer)."""
         F = self.cfg["fpn_num_filters"]
         xb = self.bufs[x]
+        bn = prefix + "/bn" if self.cfg.get("apply_bn_for_resampling", True) else None      # (:313-318)
+        if xb.C != F and xb.H > th and xb.W > tw and self.cfg.get("conv_after_downsample", False):
+            # downsampling with conv_after_downsample: pool the wide tensor first, 1x1 (+BN) on the small map (:331-338)
+            pooled = self._op(capi.OP_POOL, [x], self._buf(th, tw, xb.C, xb.per_sample, name=name + "/pool"),
+                              resample=[capi.RS_MAXPOOL, 0, 0], fuse_w=[1.0, 0, 0])
+            return self._pw(pooled, F, prefix + "/conv2d/kernel", name + "/conv", bias=prefix + "/conv2d/bias", bn=bn), capi.RS_NONE
         if xb.C != F:
-            x = self._pw(x, F, prefix + "/conv2d/kernel", name + "/conv", bias=prefix + "/conv2d/bias",
-                         bn=prefix + "/bn")
+            x = self._pw(x, F, prefix + "/conv2d/kernel", name + "/conv", bias=prefix + "/conv2d/bias", bn=bn)
             xb = self.bufs[x]
         if xb.H > th and xb.W > tw:
             return x, capi.RS_MAXPOOL
@@ -356,7 +474,7 @@ class Plan:
         x = self._op(capi.OP_STEM, [img],
                      self._buf(same_out(H, 2), same_out(W, 2), arch.stem_filters(bb), False, name="stem"),
                      w_off=self._pack(w[bb + "/stem/conv2d/kernel"]), bn_scale_off=sc, bn_shift_off=sh,
-                     act=capi.ACT_SWISH, k=3, stride=2)
+                     act=self.act, k=3, stride=2)
         reductions = []
         red_ids = set(arch.reduction_block_ids(blocks))
         pending_proj = None      # (gate buffer, projection kernel, BN name) of a block whose 1x1 projection the next block absorbs
@@ -366,7 +484,8 @@ class Plan:
             inp, nb = x, 0
             deferred = -1
             mid = b["cin"] * b["expand"]
-            if b["expand"] != 1 and mbx_supported(b["cin"], mid, b["kernel"], b["stride"]):
+            swish = self.act == capi.ACT_SWISH     # the fused MBConv kernels fold the swish into their BN scales: other activations stay unfused
+            if b["expand"] != 1 and swish and mbx_supported(b["cin"], mid, b["kernel"], b["stride"]):
                 # fused expand + depthwise: the expanded tensor stays on-chip
                 xb = self.bufs[x]
                 Ho, Wo = same_out(xb.H, b["stride"]), same_out(xb.W, b["stride"])
@@ -396,7 +515,7 @@ class Plan:
             else:
                 if b["expand"] != 1:
                     x = self._pw(x, mid, p + "conv2d/kernel", "blocks_%d/expand" % i,
-                                 bn=bn_names[nb], act=capi.ACT_SWISH, site=self._site("blocks_%d/expand" % i))
+                                 bn=bn_names[nb], act=self.act, site=self._site("blocks_%d/expand" % i))
                     nb += 1
                     proj = p + "conv2d_1/kernel"
                 else:
@@ -406,7 +525,7 @@ class Plan:
                 # the SE gate, the depthwise runs once per image (block 0 under full MC dropout)
                 deferred = dsite if (dsite >= 0 and b["se"] and not self.bufs[x].per_sample and self.defer_dropout) else -1
                 x, part = self._dw(x, b["kernel"], b["stride"], p + "depthwise_conv2d/depthwise_kernel",
-                                   "blocks_%d/dw" % i, bn=bn_names[nb], act=capi.ACT_SWISH,
+                                   "blocks_%d/dw" % i, bn=bn_names[nb], act=self.act,
                                    site=dsite, with_se=bool(b["se"]), defer_site=deferred >= 0)
                 nb += 1
             gate = -1
@@ -414,14 +533,14 @@ class Plan:
                 xb = self.bufs[x]
                 gate = self._op(capi.OP_SE, [part, x],
                                 self._buf(1, 1, xb.C, xb.per_sample or deferred >= 0, name="blocks_%d/se" % i),
-                                drop_site=deferred,
+                                drop_site=deferred, act=self.act,
                                 k=b["kernel"], stride=b["stride"], se_mid=b["se"],
                                 se_w1_off=self._pack(w[p + "se/conv2d/kernel"]),
                                 se_b1_off=self._pack(w[p + "se/conv2d/bias"]),
                                 se_w2_off=self._pack(w[p + "se/conv2d_1/kernel"]),
                                 se_b2_off=self._pack(w[p + "se/conv2d_1/bias"]))
             nxt = blocks[i + 1] if i + 1 < len(blocks) else None
-            absorb = (self.fuse_proj and nxt is not None and b["expand"] == 1 and gate >= 0 and not b["skip"] and b["cout"] == 16
+            absorb = (self.fuse_proj and swish and nxt is not None and b["expand"] == 1 and gate >= 0 and not b["skip"] and b["cout"] == 16
                       and nxt["cin"] == 16 and nxt["expand"] != 1 and not nxt["skip"] and self.bufs[x].C <= 32
                       and mbx_supported(16, 16 * nxt["expand"], nxt["kernel"], nxt["stride"])
                       and (i not in red_ids or len([r for r in red_ids if r <= i]) < cfg["min_level"]))
@@ -443,14 +562,14 @@ class Plan:
             src = self.bufs[feats[-1]]
             th, tw = (src.H + 1) // 2, (src.W + 1) // 2
             xr, mode = self._resample(feats[-1], th, tw, "resample_p%d" % lvl, "resample_p%d" % lvl)
-            if mode == capi.RS_NONE:        # a 1x1 map cannot shrink further: the level repeats (keras :339-342)
+            if mode == capi.RS_NONE:        # a 1x1 map cannot shrink further: the level repeats (keras :339-342); or pooled + 1x1 already
                 feats.append(xr)
                 continue
             out = self._buf(th, tw, F, self.bufs[xr].per_sample, name="p%d_in" % lvl)
             feats.append(self._op(capi.OP_POOL, [xr], out, resample=[capi.RS_MAXPOOL, 0, 0], fuse_w=[1.0, 0, 0]))
         # ---- BiFPN
-        nodes = arch.bifpn_nodes(lo, hi)
-        method = cfg.get("fpn_weight_method") or "fastattn"
+        nodes, method = fpn_nodes(cfg)
+        cba = bool(cfg.get("conv_bn_act_pattern", False))       # conv -> BN -> act instead of act -> conv(+bias) -> BN (:218,229-236)
         for rep in range(cfg["fpn_cell_repeats"]):
             cell = list(feats)
             for n, node in enumerate(nodes):
@@ -470,22 +589,29 @@ class Plan:
                     for e in ew:
                         tot = np.float32(tot + e)
                     fw = [float(np.float32(e / np.float32(tot + np.float32(0.0001)))) for e in ew]
+                elif method == "attn":      # softmax of the scalar edge weights (:96-99), float32 like the reference's
+                    ev = np.asarray([np.asarray(w[p + "WSM" + ("" if i == 0 else "_%d" % i)], np.float32).reshape(())
+                                     for i in range(len(ins))], np.float32)
+                    ex = np.exp(ev - ev.max(), dtype=np.float32)
+                    fw = [float(v) for v in (ex / ex.sum(dtype=np.float32)).astype(np.float32)]
                 elif method == "sum":
                     fw = [1.0] * len(ins)
                 else:
                     raise ValueError("unknown weight_method %s" % method)
                 ps = any(self.bufs[i].per_sample for i in ins)
                 op = p + "op_after_combine%d" % nf
+                fuse_act, conv_act = (capi.ACT_NONE, self.act) if cba else (self.act, capi.ACT_NONE)
+                bias = None if cba else op + "/conv/bias"       # use_bias = not conv_bn_act_pattern (:218)
                 if self.fuse_sep and sepf_supported(F, F):
                     # the fusion is computed inside the node's separable conv: no fused tensor, no fuse launch
                     cell.append(self._sepconv(None, F, op + "/conv/depthwise_kernel", op + "/conv/pointwise_kernel",
-                                              "cell%d/fnode%d/out" % (rep, n), bias=op + "/conv/bias", bn=op + "/bn",
-                                              fusion=dict(ins=ins, resample=modes, fuse_w=fw, H=tgt.H, W=tgt.W)))
+                                              "cell%d/fnode%d/out" % (rep, n), bias=bias, bn=op + "/bn", act=conv_act,
+                                              fusion=dict(ins=ins, resample=modes, fuse_w=fw, H=tgt.H, W=tgt.W, act=fuse_act)))
                     continue
                 fused = self._op(capi.OP_FUSE, ins, self._buf(tgt.H, tgt.W, F, ps, name="cell%d/fnode%d/fused" % (rep, n)),
-                                 act=capi.ACT_SWISH, resample=(modes + [0, 0, 0])[:3], fuse_w=(fw + [0, 0, 0])[:3])
+                                 act=fuse_act, resample=(modes + [0, 0, 0])[:3], fuse_w=(fw + [0, 0, 0])[:3])
                 cell.append(self._sepconv(fused, F, op + "/conv/depthwise_kernel", op + "/conv/pointwise_kernel",
-                                          "cell%d/fnode%d/out" % (rep, n), bias=op + "/conv/bias", bn=op + "/bn"))
+                                          "cell%d/fnode%d/out" % (rep, n), bias=bias, bn=op + "/bn", act=conv_act))
             feats = []
             for lvl in range(lo, hi + 1):
                 for i, node in enumerate(reversed(nodes)):
@@ -511,7 +637,7 @@ class Plan:
                 for li in range(len(feats)):
                     xs[li] = self._sepconv(xs[li], F, pre + "/depthwise_kernel", pre + "/pointwise_kernel",
                                            "%s-%d-%d" % (tag, i, lo + li), bias=pre + "/bias",
-                                           bn="%s/%s-%d-bn-%d" % (net, tag, i, lo + li), act=capi.ACT_SWISH,
+                                           bn="%s/%s-%d-bn-%d" % (net, tag, i, lo + li), act=self.act,
                                            site=self._site("%s-%d-%d" % (tag, i, lo + li)))
                 self._mark_launch_group(first)
             pre = "%s/%s-predict" % (net, tag)
@@ -692,6 +818,7 @@ class Plan:
                       "se_mid", "drop_site", "drop_site2", "w2_off", "bn2_scale_off", "bn2_shift_off", "launch_group"):
                 setattr(c, k, int(o[k]))
             c.fuse_in = int(o.get("fuse_in", 0))
+            c.fuse_act = int(o.get("fuse_act", 0))
         sites = (capi.DropSite * max(1, len(self.sites)))()
         for i, (_, ch, r) in enumerate(self.sites):
             sites[i].channels, sites[i].rate = ch, np.float32(r)

@@ -30,9 +30,13 @@ def variable_specs(config):
 
     kind ∈ conv, dw, se_w, bias0, vs_dw, vs_pw, glorot, cls_bias, wsm, bn
     """
+    from . import plan as plan_mod
+    plan_mod.check_model_params(config)
     bb = config["backbone_name"]
     blocks = arch.backbone_blocks(bb, config.get("backbone_config"))
     specs = []
+    resample_bn = bool(config.get("apply_bn_for_resampling", True))         # efficientdet_keras.py:313-318
+    cba = bool(config.get("conv_bn_act_pattern", False))                    # use_bias = not conv_bn_act_pattern (:218)
 
     def bn(prefix, c):
         specs.append((prefix, (c,), "bn"))
@@ -75,11 +79,12 @@ def variable_specs(config):
         if level_ch[-1] != F:
             specs.append((name + "/conv2d/kernel", (1, 1, level_ch[-1], F), "glorot"))
             specs.append((name + "/conv2d/bias", (F,), "bias0"))
-            bn(name + "/bn", F)
+            if resample_bn:
+                bn(name + "/bn", F)
         level_ch.append(F)
 
-    nodes = arch.bifpn_nodes(min_l, max_l)
-    weighted = (config.get("fpn_weight_method") or "fastattn") in ("fastattn", "attn")
+    nodes, method = plan_mod.fpn_nodes(config)
+    weighted = method in ("fastattn", "attn")
     for rep in range(config["fpn_cell_repeats"]):
         ch = list(level_ch) if rep == 0 else [F] * len(level_ch)
         for n, node in enumerate(nodes):
@@ -90,13 +95,15 @@ def variable_specs(config):
                     rp = p + "resample_%d_%d_%d" % (i, off, nfeats)
                     specs.append((rp + "/conv2d/kernel", (1, 1, ch[off], F), "glorot"))
                     specs.append((rp + "/conv2d/bias", (F,), "bias0"))
-                    bn(rp + "/bn", F)
+                    if resample_bn:
+                        bn(rp + "/bn", F)
                 if weighted:
                     specs.append((p + "WSM" + ("" if i == 0 else "_%d" % i), (), "wsm"))
             op = p + "op_after_combine%d" % nfeats
             specs.append((op + "/conv/depthwise_kernel", (3, 3, F, 1), "glorot"))
             specs.append((op + "/conv/pointwise_kernel", (1, 1, F, F), "glorot"))
-            specs.append((op + "/conv/bias", (F,), "bias0"))
+            if not cba:
+                specs.append((op + "/conv/bias", (F,), "bias0"))
             bn(op + "/bn", F)
             ch.append(F)
 
