@@ -17,6 +17,7 @@
 // Pinned-down numerics shared with the oracle (oracle/post_ref.py header):
 //   exp32(x) = float(exp(double(x))), sigmoid(x) = float(1/(1+exp(-double(x)))),
 //   MC reductions are sequential float32 sums over t = 0..T-1.
+#include <type_traits>
 #include <hip/hip_fp16.h>
 
 #include "uda_internal.h"
@@ -1788,6 +1789,7 @@ __device__ unsigned long long g_nms_dbg[8];
 __device__ unsigned long long g_nms_dbg2[2];
 __device__ unsigned long long g_nms_dbg3[8];
 __device__ unsigned long long g_nms_hist[16];
+__device__ unsigned long long g_nms_win[10];     // steps that settled 1, 2, ... winners (UDA_NMS_STATS)
 #ifdef UDA_NMS_STATS
 #define NMS_STAT(slot, v) atomicAdd(&g_nms_dbg[slot], (unsigned long long)(v))
 #else
@@ -1805,22 +1807,104 @@ __device__ __forceinline__ float coop_chain(const NmsArgs& a, const RegLds& S, f
 constexpr int COOP_LIST = 3072;      // entries of the block-wide work list
 constexpr int COOP_HEAVY = 1024;     // entries of the list of chains handed to whole waves
 constexpr int COOP_HEAVY_LINKS = 6;  // overlapping links above which a chain is evaluated by a wave
+constexpr int COOP_W = 8;            // winners one grid-wide step can settle, at most (round 5)
+constexpr int COOP_KL = 512;         // exact keys >= the step's bound a block can rank for its contribution
+constexpr unsigned long long COOP_OVF = 2ull;    // exchange word: "more keys than I could rank" (keys are >= 2^63, 1 = nothing)
+
+// Several winners per grid-wide step (tests/test_nms_multiwinner_model.py states the rule on the CPU):
+//   A  every block offers the exact score of its best candidate by upper bound; the step's bound is the W-th largest of
+//      those keys - at least W candidates are then KNOWN to have an exact key >= bound;
+//   B  every candidate whose upper bound reaches the bound takes its exact score; every block contributes its W best exact
+//      keys; the W best of the problem, e_1 >= e_2 >= ..., are all >= bound, i.e. above everything that was not evaluated;
+//   C  e_1 is the winner of epoch k; e_j is the winner of epoch k + j - 1 as long as its box does not strictly overlap
+//      e_1 .. e_{j-1} (its own score is unchanged - IoU 0, weight exactly 1 - and no other score can have grown);
+//   D  the pops of those epochs, per candidate and in epoch order: while its stale key outranks e_{t+1} it is popped in
+//      epoch k + t (links begin .. k + t - 1, newest first; begin = k + t) - the reference's pops, hence its products.
+// One pair of exchanges settles up to W selections instead of one.
+struct CoopLds {
+  unsigned long long mine[COOP_W];   // this block's words for the next exchange
+  unsigned long long top[COOP_W];    // result of an exchange: the largest keys of the problem, descending, 0-padded
+  int ovf;                           // a block could not rank its keys: only top[0] is usable
+  int nwin;                          // winners this step settles
+  int kcount;                        // entries of the key list
+};
+
+// Grid-wide step of a problem with `nm` words per block (X.mine[0 .. nm): keys, 0 = none, COOP_OVF): data and arrival are
+// one word each, as in coop_exchange; wave 0 polls the problem's bpi x nm words (bpi <= 64: at most COOP_W per lane) and
+// leaves the COOP_W largest keys in X.top (keys are unique: the candidate index is part of them).
+__device__ __forceinline__ void coop_exchange_top(unsigned long long* slots, int blk, int bpi, int nm, CoopLds& X, int* err, unsigned spin_max) {
+  __syncthreads();                           // X.mine is complete
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    if (lane < nm) {
+      const unsigned long long v = X.mine[lane];
+      __hip_atomic_store(&slots[blk * nm + lane], v ? v : 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int total = bpi * nm;
+    unsigned long long loc[COOP_W];
+    bool ovf = false, dead = false;
+#pragma unroll
+    for (int q = 0; q < COOP_W; ++q) {
+      unsigned long long v = 1ull;
+      const int w = lane + 64 * q;
+      if (w < total && !dead) {
+        unsigned spins = 0;
+        while ((v = __hip_atomic_load(&slots[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0ull) {
+          ++spins;
+          if ((spins & 4095u) == 0u || spins > spin_max) {
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { dead = true; break; }
+            if (spins > spin_max) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dead = true; break; }
+          }
+        }
+      }
+      if (v == COOP_OVF) ovf = true;
+      loc[q] = v <= COOP_OVF ? 0ull : v;
+    }
+#pragma unroll
+    for (int r = 0; r < COOP_W; ++r) {
+      unsigned long long m = loc[0];
+#pragma unroll
+      for (int q = 1; q < COOP_W; ++q) m = loc[q] > m ? loc[q] : m;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(m, off, 64);
+        m = o > m ? o : m;
+      }
+      if (lane == 0) X.top[r] = m;
+#pragma unroll
+      for (int q = 0; q < COOP_W; ++q)
+        if (loc[q] == m) loc[q] = 0ull;
+    }
+    const bool any = __ballot(ovf) != 0ull;
+    if (lane == 0) X.ovf = any ? 1 : 0;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ bool coop_strict_overlap(const float* p, const float* q) {      // the test of chain_mask
+  const float y0 = fminf(p[0], p[2]), x0 = fminf(p[1], p[3]), y1 = fmaxf(p[0], p[2]), x1 = fmaxf(p[1], p[3]);
+  const float sy0 = fminf(q[0], q[2]), sx0 = fminf(q[1], q[3]), sy1 = fmaxf(q[0], q[2]), sx1 = fmaxf(q[1], q[3]);
+  return (fminf(y1, sy1) > fmaxf(y0, sy0)) && (fminf(x1, sx1) > fmaxf(x0, sx0));
+}
 
 template <int IPT>
-__global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float* scores, unsigned long long* slots_all, int* err, int bpi, int n0, unsigned spin_max) {
+__global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float* scores, unsigned long long* slots_all, int* err, int bpi, int n0, unsigned spin_max,
+                                                           int wcfg) {
   // Per candidate: the stale score in a register of its thread (scanned every epoch, candidate i0 + j * 1024 + tid), the
   // cached exact score / upper bound in LDS (scanned every epoch, 128 KB), begin / epoch / a copy of the stale score in
   // the workspace arrays in memory (touched only when a chain is evaluated, together with the candidate's box).
-  extern __shared__ float U[];                    // [IPT * 1024] | work list [COOP_LIST] | "exact this epoch" bits
+  extern __shared__ float U[];                    // [IPT * 1024] | work list [COOP_LIST] | heavy list | "exact this epoch" bits | key list
   int* wlist = (int*)(U + IPT * SOLO_T);
   int* hlist = wlist + COOP_LIST;
   unsigned* ebits = (unsigned*)(hlist + COOP_HEAVY);  // [IPT * 1024 / 32]
+  unsigned long long* klist = (unsigned long long*)(ebits + IPT * 32);     // [COOP_KL] (8-byte aligned: every part above is a multiple of 8 bytes)
   __shared__ RegLds S;
+  __shared__ CoopLds X;
   __shared__ int wcount, hcount;
   const int n = n0 + blockIdx.x / bpi, blk = blockIdx.x % bpi, tid = threadIdx.x;   // n0: first problem of this launch
   const size_t bbase = (size_t)n * a.K;           // one problem per image (segs == 1)
   const int i0 = blk * IPT * SOLO_T;
-  unsigned long long* slots = slots_all + (size_t)n * a.M * 2 * bpi;      // [epoch][bound | winner][block]
+  unsigned long long* slots = slots_all + (size_t)n * a.M * (1 + COOP_W) * bpi;      // [step][bound: bpi | winners: bpi x COOP_W]
   float st[IPT];
 #pragma unroll
   for (int j = 0; j < IPT; ++j) {
@@ -1838,18 +1922,23 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
   // (the padded form of the outputs - index 0 / score 0 in the slots that stay empty - is written by the launcher's
   // memsets: a slot must have ONE writer inside the kernel, the L2s of different XCDs are not coherent with each other)
   int nsel = 0;
-  if (tid == 0) { wcount = 0; hcount = 0; }
+  if (tid == 0) { wcount = 0; hcount = 0; X.kcount = 0; X.nwin = 1; }
   for (int f = tid; f < IPT * 32; f += SOLO_T) ebits[f] = 0u;
   __syncthreads();
 
-  // Exact scores (epoch k: links begin .. k-1, newest first) of the candidates flagged in the threads' bit masks.  These
-  // are spatial neighbours, so a few threads would carry all the chains: they go through a block-wide list and every
-  // thread takes entries round-robin (entries beyond the capacity stay with their owners).  A thread runs the cheap mask
-  // pass of its entry; chains with few overlapping links it finishes itself, the others - big boxes overlap most of
-  // the selected ones, up to 100 IoU + exp in a row - go to a second list that whole waves work off (chain_wave).
-  // stale / begin / box come from memory in one round trip; "already exact in this epoch" is a bit per candidate in
-  // LDS.  `fn(rel, v)` receives every candidate with its exact score, once, from some thread.
-  auto run_balanced = [&](unsigned mask, int k, auto&& fn) {
+  // Exact scores of the candidates flagged in the threads' bit masks.  These are spatial neighbours, so a few threads
+  // would carry all the chains: they go through a block-wide list and every thread takes entries round-robin (entries
+  // beyond the capacity stay with their owners).  A thread runs the cheap mask pass of its entry; chains with few
+  // overlapping links it finishes itself, the others - big boxes overlap most of the selected ones, up to 100 IoU + exp
+  // in a row - go to a second list that whole waves work off (chain_wave).  stale / begin / box come from memory in one
+  // round trip; "already exact in this epoch" is a bit per candidate in LDS.
+  //   pops == false (phase B): exact score in epoch k (links begin .. k-1); `fn(rel, v)` receives every candidate once.
+  //   pops == true  (phase D): the candidate's pops of the epochs k .. k + nw - 1 (X.top[0 .. nw) are their winners'
+  //                 keys): first pop in the first epoch k + t whose winner its stale key outranks (the long chain: this
+  //                 is what goes through the lists), later ones - one new link each - by the same thread; stale / begin
+  //                 in memory and U[] receive the final state.
+  auto run_balanced = [&](unsigned mask, int k, int nw, auto pops_tag, auto&& fn) {
+    constexpr bool POPS = decltype(pops_tag)::value;
     // (wcount / hcount are 0 here: reset at the end of the previous call, with block barriers in between)
     unsigned left = 0u;
     {
@@ -1868,25 +1957,53 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
     const unsigned long long tb0 = wall_clock64();
     if (tid == 0) { atomicAdd(&g_nms_dbg3[0], (unsigned long long)wcount); atomicMax(&g_nms_dbg3[1], (unsigned long long)wcount); }
 #endif
+    // epoch of the candidate's first pop: the first winner its stale key outranks (the mask guarantees there is one)
+    auto first_pop = [&](float stale, int gi) {
+      const unsigned long long key = nms_key(stale, gi);
+      int t = 0;
+      while (t < nw - 1 && !(key > X.top[t])) ++t;
+      return t;
+    };
+    // the candidate's later pops after a first pop in epoch k + t: one epoch at a time, each over the links that are new
+    auto later_pops = [&](int rel, size_t g, float v, int t, const float* bx) {
+      int b = k + t;
+      if (POPS) {
+        for (int u = t + 1; u < nw && v != -INFINITY; ++u) {
+          if (nms_key(v, i0 + rel) > X.top[u]) {
+            v = reg_chain(a, S, v, b, bx, k + u);
+            b = k + u;
+          }
+        }
+        a.stale[g] = v;
+        a.begin[g] = b;
+      }
+      U[rel] = v;
+      return v;
+    };
     auto one = [&](int rel) {
-      if ((ebits[rel >> 5] >> (rel & 31)) & 1u) { fn(rel, U[rel]); return; }
+      const bool cached = (ebits[rel >> 5] >> (rel & 31)) & 1u;
+      if (!POPS && cached) { fn(rel, U[rel]); return; }
       const size_t g = bbase + i0 + rel;
       const int begin = a.begin[g];
       const float stale = a.stale[g];
+      const float4 b4 = *(const float4*)(a.boxes + g * 4);
+      const float bx[4] = {b4.x, b4.y, b4.z, b4.w};
+      const int t = POPS ? first_pop(stale, i0 + rel) : 0;
+      const int kk = k + t;
       float v = stale;
-      if (k > begin) {
-        const float4 b4 = *(const float4*)(a.boxes + g * 4);
-        const float bx[4] = {b4.x, b4.y, b4.z, b4.w};
+      if (POPS && t == 0 && cached) {
+        v = U[rel];                          // exact in epoch k already (phase B): the same links in the same order
+      } else if (kk > begin) {
         unsigned long long m[2];
-        chain_mask(a, S, begin, bx, k, m);
+        chain_mask(a, S, begin, bx, kk, m);
         if (__popcll(m[0]) + __popcll(m[1]) > COOP_HEAVY_LINKS) {
           const int pos = atomicAdd(&hcount, 1);
           if (pos < COOP_HEAVY) { hlist[pos] = rel; return; }
         }
         v = chain_product(a, S, stale, bx, m);
       }
-      U[rel] = v;
-      atomicOr(&ebits[rel >> 5], 1u << (rel & 31));
+      v = later_pops(rel, g, v, t, bx);
+      if (!POPS) atomicOr(&ebits[rel >> 5], 1u << (rel & 31));
       fn(rel, v);
     };
     for (int e = tid; e < cnt; e += SOLO_T) one(wlist[e]);
@@ -1911,10 +2028,12 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
       const size_t g = bbase + i0 + rel;
       const float4 b4 = *(const float4*)(a.boxes + g * 4);
       const float bx[4] = {b4.x, b4.y, b4.z, b4.w};
-      const float v = chain_wave(a, S, a.stale[g], a.begin[g], bx, k);
+      const float stale = a.stale[g];
+      const int t = POPS ? first_pop(stale, i0 + rel) : 0;
+      float v = chain_wave(a, S, stale, a.begin[g], bx, k + t);
       if ((tid & 63) == 0) {
-        U[rel] = v;
-        atomicOr(&ebits[rel >> 5], 1u << (rel & 31));
+        v = later_pops(rel, g, v, t, bx);
+        if (!POPS) atomicOr(&ebits[rel >> 5], 1u << (rel & 31));
         fn(rel, v);
       }
     }
@@ -1925,11 +2044,13 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
     if (tid == 0) { wcount = 0; hcount = 0; }
   };
 
-  for (int k = 0; k < a.M; ++k) {
+  int k = 0;
+  for (int step = 0; k < a.M; ++step) {
     // (the candidate index is rebuilt from an opaque base in every epoch: otherwise the per-candidate index words and
     // addresses of all IPT candidates are hoisted out of the epoch loop and spill)
     int ib = i0 + tid;
     asm volatile("" : "+v"(ib));
+    unsigned long long* sslots = slots + (size_t)step * (1 + COOP_W) * bpi;
 #ifdef UDA_NMS_STATS
     const unsigned long long t0 = wall_clock64();
 #endif
@@ -1962,17 +2083,26 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
       if (tid == 0) {
         U[bi - i0] = score;
         atomicOr(&ebits[(bi - i0) >> 5], 1u << ((bi - i0) & 31));
-        S.L = (score != -INFINITY) ? nms_key(score, bi) : 0ull;
+        X.mine[0] = (score != -INFINITY) ? nms_key(score, bi) : 0ull;
       }
     }
-    if (bk == 0ull && tid == 0) S.L = 0ull;
+    if (tid == 0) {
+      if (bk == 0ull) X.mine[0] = 0ull;
+      X.kcount = 0;
+    }
 #ifdef UDA_NMS_STATS
     __syncthreads();
     const unsigned long long t1 = wall_clock64();
 #endif
-    __syncthreads();
-    const unsigned long long lk = S.L;       // this block's exact lower bound
-    const unsigned long long bd = coop_exchange(slots + (size_t)(2 * k) * bpi, blk, bpi, lk, S, err, spin_max);
+    coop_exchange_top(sslots, blk, bpi, 1, X, err, spin_max);
+    // the step's bound: the weff-th largest block key (fewer blocks alive: the smallest one; none: 0 = everything is evaluated)
+    int nz = 0;
+#pragma unroll
+    for (int r = 0; r < COOP_W; ++r) nz += X.top[r] != 0ull ? 1 : 0;
+    int weff = wcfg < nz ? wcfg : nz;
+    if (weff > a.M - k) weff = a.M - k;
+    if (weff < 1) weff = 1;
+    const unsigned long long bd = nz ? X.top[weff - 1] : 0ull;
 #ifdef UDA_NMS_STATS
     const unsigned long long t2 = wall_clock64();
 #endif
@@ -1991,57 +2121,112 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
         }
       }
     }
-    run_balanced(need, k, [&](int rel, float v) {
+    run_balanced(need, k, 1, std::false_type{}, [&](int rel, float v) {
       if (v != -INFINITY) {
         const unsigned long long key = nms_key(v, i0 + rel);
         ke = key > ke ? key : ke;
+        if (weff > 1 && key >= bd) {         // ranked below for this block's contribution
+          const int pos = atomicAdd(&X.kcount, 1);
+          if (pos < COOP_KL) klist[pos] = key;
+        }
       }
     });
     ke = reg_max(S, ke);
-
+    // this block's weff best exact keys (wave 0; the list is complete: run_balanced ends with a barrier)
+    if (tid < 64) {
+      const int cnt = X.kcount;
+      if (weff == 1 || cnt > COOP_KL) {
+        if (tid < COOP_W) X.mine[tid] = tid == 0 ? ke : ((tid == 1 && weff > 1) ? COOP_OVF : 0ull);
+      } else {
+        unsigned long long loc[COOP_KL / 64];
+#pragma unroll
+        for (int q = 0; q < COOP_KL / 64; ++q) loc[q] = (tid + 64 * q < cnt) ? klist[tid + 64 * q] : 0ull;
+#pragma unroll
+        for (int r = 0; r < COOP_W; ++r) {
+          unsigned long long m = loc[0];
+#pragma unroll
+          for (int q = 1; q < COOP_KL / 64; ++q) m = loc[q] > m ? loc[q] : m;
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(m, off, 64);
+            m = o > m ? o : m;
+          }
+          if (tid == 0) X.mine[r] = r < weff ? m : 0ull;
+#pragma unroll
+          for (int q = 0; q < COOP_KL / 64; ++q)
+            if (loc[q] == m) loc[q] = 0ull;
+        }
+      }
+    }
 #ifdef UDA_NMS_STATS
     const unsigned long long t3 = wall_clock64();
 #endif
-    const unsigned long long wk = coop_exchange(slots + (size_t)(2 * k + 1) * bpi, blk, bpi, ke, S, err, spin_max);
+    coop_exchange_top(sslots + bpi, blk, bpi, COOP_W, X, err, spin_max);
 #ifdef UDA_NMS_STATS
     const unsigned long long t4 = wall_clock64();
 #endif
+    const unsigned long long wk = X.top[0];
     if (wk == 0ull) break;                  // no live candidate in the whole problem (uniform over its blocks)
-    const int widx = (int)(0xFFFFFFFFu - (uint32_t)wk);
-    if (tid < 4) S.sel[4 * k + tid] = a.boxes[(bbase + widx) * 4 + tid];
-    // ---- C. pops and the winner (chains of epoch k use the selected boxes 0 .. k-1 only)
+    // ---- C. the winners this step settles: boxes of the weff best keys, then the prefix that does not overlap
+    if (tid < 4 * COOP_W) {
+      const int t = tid >> 2;
+      const unsigned long long key = X.top[t];
+      if (t < weff && key != 0ull) S.sel[4 * (k + t) + (tid & 3)] = a.boxes[(bbase + (size_t)(0xFFFFFFFFu - (uint32_t)key)) * 4 + (tid & 3)];
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int nw = 1;
+      if (!X.ovf && (a.soft || a.iou_thr >= 0.f)) {
+        for (; nw < weff; ++nw) {
+          const unsigned long long key = X.top[nw];
+          if (key == 0ull || key < bd) break;
+          bool ov = false;
+          for (int p = 0; p < nw; ++p) ov = ov || coop_strict_overlap(S.sel + 4 * (k + nw), S.sel + 4 * (k + p));
+          if (ov) break;
+        }
+      }
+      X.nwin = nw;
+    }
+    __syncthreads();
+    const int nw = X.nwin;
+#ifdef UDA_NMS_STATS
+    if (tid == 0 && blk == 0) atomicAdd(&g_nms_win[nw < 9 ? nw : 9], 1ull);
+#endif
+    // ---- D. the winners' records and the pops of the epochs k .. k + nw - 1
     unsigned pops = 0u;
     {
-      const int rel = widx - i0;           // the winner's slot, if it lives in this block
-      const bool mine = rel >= 0 && rel < IPT * SOLO_T && (rel % SOLO_T) == tid;
-      const int jw = mine ? rel / SOLO_T : -1;
-      if (mine) {
-        const size_t o = (size_t)n * a.M + k;
-        a.sel_idx[o] = widx;
-        a.sel_score[o] = U[rel];
-        *(float4*)(a.sel_box + o * 4) = *(const float4*)(a.boxes + (bbase + widx) * 4);
-        a.stale[bbase + widx] = -INFINITY;
+      unsigned wmask = 0u;                  // this thread's candidates among the winners
+      for (int t = 0; t < nw; ++t) {
+        const int widx = (int)(0xFFFFFFFFu - (uint32_t)X.top[t]);
+        const int rel = widx - i0;
+        if (rel >= 0 && rel < IPT * SOLO_T && (rel % SOLO_T) == tid) {
+          const size_t o = (size_t)n * a.M + k + t;
+          a.sel_idx[o] = widx;
+          a.sel_score[o] = U[rel];          // exact in epoch k = exact in epoch k + t (no link of the step touches it)
+          *(float4*)(a.sel_box + o * 4) = *(const float4*)(a.boxes + (bbase + widx) * 4);
+          a.stale[bbase + widx] = -INFINITY;
+          wmask |= 1u << (rel / SOLO_T);
+        }
       }
-      // key(st, i) > wk  <=>  ord(st) > ord(wk)  or  (equal and ~i > low word of wk)
-      const uint32_t wo = (uint32_t)(wk >> 32), wl = (uint32_t)wk;
+      // key(st, i) > low  <=>  ord(st) > ord(low)  or  (equal and ~i > low word): low = the last winner's key
+      const unsigned long long low = X.top[nw - 1];
+      const uint32_t wo = (uint32_t)(low >> 32), wl = (uint32_t)low;
 #pragma unroll
       for (int j = 0; j < IPT; ++j) {
-        if (j == jw) st[j] = -INFINITY;
+        if ((wmask >> j) & 1u) st[j] = -INFINITY;
         if (st[j] != -INFINITY) {
           const uint32_t o = ord32(st[j]);
           if (o > wo || (o == wo && 0xFFFFFFFFu - (uint32_t)(ib + j * SOLO_T) > wl)) pops |= 1u << j;
         }
       }
     }
-    run_balanced(pops, k, [&](int rel, float v) {
-      a.stale[bbase + i0 + rel] = v;
-      a.begin[bbase + i0 + rel] = k;
-    });                                      // (ends with a barrier: U[] of the popped candidates is complete)
+    run_balanced(pops, k, nw, std::true_type{}, [&](int, float) {});      // (ends with a barrier: U[] of the popped candidates is complete)
 #pragma unroll
     for (int j = 0; j < IPT; ++j)
       if ((pops >> j) & 1u) st[j] = U[j * SOLO_T + tid];
-    nsel = k + 1;
-    for (int f = tid; f < IPT * 32; f += SOLO_T) ebits[f] = 0u;      // "exact in this epoch" bits of the next epoch
+    k += nw;
+    nsel = k;
+    for (int f = tid; f < IPT * 32; f += SOLO_T) ebits[f] = 0u;      // "exact in this epoch" bits of the next step
     __syncthreads();
 #ifdef UDA_NMS_STATS
     if (tid == 0) {
@@ -2049,7 +2234,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
       NMS_STAT(4, t1 - t0); NMS_STAT(5, t2 - t1); NMS_STAT(6, t3 - t2); NMS_STAT(7, t4 - t3);
       atomicAdd(&g_nms_dbg2[0], t5 - t4); atomicAdd(&g_nms_dbg2[1], 1ull);
       {
-        const unsigned long long te = t5 - t0;        // whole epoch of this block, 10 ns ticks
+        const unsigned long long te = t5 - t0;        // whole step of this block, 10 ns ticks
         int bkt = 0;
         while (bkt < 7 && te >= (2000ull << bkt)) ++bkt;     // < 20, 40, 80, 160, 320, 640, 1280 us, more
         atomicAdd(&g_nms_hist[bkt], 1ull);
@@ -2062,11 +2247,12 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
 }
 
 // 64-bit words of exchange slots per problem (the caller's scratch: n_img x this; a launch uses M x 2 x its blocks per problem)
-size_t nms_coop_slot_words(int M) { return (size_t)M * 2 * COOP_MAX_BPI; }
+size_t nms_coop_slot_words(int M) { return (size_t)M * (1 + COOP_W) * COOP_MAX_BPI; }
 
 template <int IPT>
 constexpr size_t coop_lds_bytes() {
-  return (size_t)IPT * SOLO_T * sizeof(float) + (size_t)(COOP_LIST + COOP_HEAVY) * sizeof(int) + (size_t)IPT * 32 * sizeof(unsigned);
+  return (size_t)IPT * SOLO_T * sizeof(float) + (size_t)(COOP_LIST + COOP_HEAVY) * sizeof(int) + (size_t)IPT * 32 * sizeof(unsigned) +
+         (size_t)COOP_KL * sizeof(unsigned long long);
 }
 
 // co-resident blocks of nms_coop_kernel<IPT> on the current device (occupancy x CUs; 0 = cannot run), cached per HIP device
@@ -2115,10 +2301,10 @@ static int coop_capacity(int dev, int* n_cu) {
 }
 
 template <int IPT>
-static void coop_launch(const NmsArgs& a, const float* scores, unsigned long long* slots, int* err, int bpi, int per, unsigned spin_max, hipStream_t s) {
+static void coop_launch(const NmsArgs& a, const float* scores, unsigned long long* slots, int* err, int bpi, int per, unsigned spin_max, int wcfg, hipStream_t s) {
   for (int n0 = 0; n0 < a.n_img; n0 += per) {
     const int cnt = a.n_img - n0 < per ? a.n_img - n0 : per;
-    hipLaunchKernelGGL((nms_coop_kernel<IPT>), dim3((unsigned)(bpi * cnt)), dim3(SOLO_T), coop_lds_bytes<IPT>(), s, a, scores, slots, err, bpi, n0, spin_max);
+    hipLaunchKernelGGL((nms_coop_kernel<IPT>), dim3((unsigned)(bpi * cnt)), dim3(SOLO_T), coop_lds_bytes<IPT>(), s, a, scores, slots, err, bpi, n0, spin_max, wcfg);
   }
 }
 
@@ -2157,24 +2343,32 @@ int launch_nms_coop(const NmsArgs& a, const float* scores, unsigned long long* s
     return -1;
   }
   const int per = capacity / bpi;          // problems per launch: more problems than the device holds run in consecutive grids
-  hipMemsetAsync(slots, 0, (size_t)a.n_img * a.M * 2 * bpi * sizeof(unsigned long long), s);
+  // winners one grid-wide step may settle (UDA_NMS_WINNERS = 1 .. 8; 1 = one selection per step, as rounds 2-4 ran): the
+  // step's bound is the W-th largest of the blocks' offers, so W stays at half the blocks of a problem - a bound taken from
+  // the weakest blocks would have the strong ones evaluate most of what they hold
+  static int wenv = -1;
+  if (wenv < 0) { const char* e = getenv("UDA_NMS_WINNERS"); wenv = e ? atoi(e) : 0; }
+  int wcfg = wenv > 0 ? wenv : bpi / 2;
+  if (wcfg > COOP_W) wcfg = COOP_W;
+  if (wcfg < 1) wcfg = 1;
+  hipMemsetAsync(slots, 0, (size_t)a.n_img * a.M * (1 + COOP_W) * bpi * sizeof(unsigned long long), s);
   hipMemsetAsync(a.sel_idx, 0, (size_t)a.n_img * a.M * sizeof(int32_t), s);
   hipMemsetAsync(a.sel_score, 0, (size_t)a.n_img * a.M * sizeof(float), s);
   // An ordinary launch: the grid fits the device (checked above against the occupancy of this kernel), so every block
   // becomes resident as soon as whatever else runs on the device drains - other kernels never wait for this one - and the
   // bounded spin is the safety net.  (hipLaunchCooperativeKernel gives the same placement plus a formal check, but
   // rocprofv3's kernel tracing crashes at process exit after a cooperative launch, ROCm 7.2.)
-  if (ipt == 4) coop_launch<4>(a, scores, slots, err, bpi, per, spin_max, s);
-  else if (ipt == 8) coop_launch<8>(a, scores, slots, err, bpi, per, spin_max, s);
-  else if (ipt == 16) coop_launch<16>(a, scores, slots, err, bpi, per, spin_max, s);
-  else if (ipt == 24) coop_launch<24>(a, scores, slots, err, bpi, per, spin_max, s);
-  else coop_launch<32>(a, scores, slots, err, bpi, per, spin_max, s);
+  if (ipt == 4) coop_launch<4>(a, scores, slots, err, bpi, per, spin_max, wcfg, s);
+  else if (ipt == 8) coop_launch<8>(a, scores, slots, err, bpi, per, spin_max, wcfg, s);
+  else if (ipt == 16) coop_launch<16>(a, scores, slots, err, bpi, per, spin_max, wcfg, s);
+  else if (ipt == 24) coop_launch<24>(a, scores, slots, err, bpi, per, spin_max, wcfg, s);
+  else coop_launch<32>(a, scores, slots, err, bpi, per, spin_max, wcfg, s);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     if (dbg) fprintf(stderr, "[uda] cooperative NMS: launch refused: %s\n", hipGetErrorString(e));
     return -1;
   }
-  if (dbg) fprintf(stderr, "[uda] cooperative NMS: %d problems x %d blocks of %d candidates per thread (capacity %d)\n", a.n_img, bpi, ipt, capacity);
+  if (dbg) fprintf(stderr, "[uda] cooperative NMS: %d problems x %d blocks of %d candidates per thread (capacity %d), up to %d winners per step\n", a.n_img, bpi, ipt, capacity, wcfg);
 #ifdef UDA_NMS_STATS
   {
     hipStreamSynchronize(s);
@@ -2187,6 +2381,10 @@ int launch_nms_coop(const NmsArgs& a, const float* scores, unsigned long long* s
     hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_nms_hist), sizeof(hh));
     fprintf(stderr, "[uda] nms epoch-time histogram (block-epochs : total ms) <20us %llu:%.1f <40 %llu:%.1f <80 %llu:%.1f <160 %llu:%.1f <320 %llu:%.1f <640 %llu:%.1f <1280 %llu:%.1f more %llu:%.1f\n",
             hh[0], hh[8] * 1e-5, hh[1], hh[9] * 1e-5, hh[2], hh[10] * 1e-5, hh[3], hh[11] * 1e-5, hh[4], hh[12] * 1e-5, hh[5], hh[13] * 1e-5, hh[6], hh[14] * 1e-5, hh[7], hh[15] * 1e-5);
+    unsigned long long hw[10];
+    hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_nms_win), sizeof(hw));
+    fprintf(stderr, "[uda] nms winners per grid-wide step (problems x steps, cumulative): 1:%llu 2:%llu 3:%llu 4:%llu 5:%llu 6:%llu 7:%llu 8:%llu\n",
+            hw[1], hw[2], hw[3], hw[4], hw[5], hw[6], hw[7], hw[8]);
     unsigned long long h3[8];
     hipMemcpyFromSymbol(h3, HIP_SYMBOL(g_nms_dbg3), sizeof(h3));
     if (h2[1]) fprintf(stderr, "[uda] nms lists per block-phase: entries mean %.1f max %llu, heavy mean %.1f max %llu; stage1 mean %.1f max %llu, stage2 mean %.1f max %llu ticks\n",

@@ -672,6 +672,12 @@ class Plan:
                 buf.last = oi
         for f in self.fpn_out:
             self.bufs[f].last = len(self.ops)
+        if self.cfg.get("uda_keep_buffers"):
+            # parity aid (tests): no arena recycling - every named activation of the last chunk can be read back after the run
+            # (ServingDriver.read_buffer) and compared with the oracle's taps; costs memory, changes no arithmetic
+            for b in self.bufs:
+                if b.first is not None:
+                    b.last = len(self.ops)
         # ops that share a launch run concurrently: nothing they touch may be recycled before the last of them
         for oi, o in enumerate(self.ops):
             n = o.get("launch_group", 0)
