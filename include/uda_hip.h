@@ -210,6 +210,15 @@ int uda_collect(uda_ctx_t* ctx, int32_t ticket, float* boxes, float* scores, flo
 /* The same for the multi-GPU gather: the run's detections as ONE device-resident record buffer (see uda_detections_device
  * for the layout and `rows`); packed on a stream of its own, complete when the call returns; closes the ticket. */
 int uda_collect_device(uda_ctx_t* ctx, int32_t ticket, int32_t rows, int32_t with_logits, void** dev_ptr, int32_t* cols);
+/* Abandon every pipelined run in flight (results discarded, tickets closed, flags cleared): what a consumer that drops
+ * ServingDriver.serve_stream half way, or whose uda_collect failed, calls before it uses the handle synchronously again. */
+int uda_drain(uda_ctx_t* ctx);
+/* The default scheme splits the operands of the 1x1 contractions into two fp16 pieces (float32-class products at the
+ * matrix-core cost of bf16): an operand above 65504 cannot be split.  The reference computes in float32 and never rejects
+ * an input on magnitude (utils.py:595-609), so neither does the handle: the op that saw such an operand is re-packed with
+ * three bf16 pieces (float32 exponent range), the run is served again from its unchanged inputs before any reader sees
+ * it, and the op stays that way.  This counts the ops re-packed so far (0 for every weight set the tests initialise). */
+int64_t uda_range_demotions(const uda_ctx_t* ctx);
 /* Global NMS over the whole anchor set runs on the score prefix that can be selected at all, checked on the
  * device; this counts the images / problems that failed the check and were redone on the full set (the results
  * are identical either way). */

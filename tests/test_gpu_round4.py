@@ -65,7 +65,8 @@ def test_two_chunk_lanes_are_bit_identical_to_one(tmp_path):
 
 
 def _read_device(ptr, shape):
-    hip = C.CDLL("libamdhip64.so")
+    from uda_amd import capi
+    hip = capi.load()           # hipMemcpy of the runtime the library itself is linked against (dlsym through its dependencies)
     out = np.empty(shape, np.float32)
     rc = hip.hipMemcpy(C.c_void_p(out.ctypes.data), C.c_void_p(ptr), C.c_size_t(out.nbytes), C.c_int(2))      # device to host
     assert rc == 0, rc
@@ -180,9 +181,9 @@ OVERFLOW_WORKER = r"""
 import sys
 sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
 import numpy as np
-from common import LOSS_ATT, make_images, make_params, make_weights
+from common import FULL_MC, LOSS_ATT, make_images, make_params, make_weights
 from uda_amd.infer_lib import KerasDriver
-p = make_params(**LOSS_ATT)
+p = make_params(**(FULL_MC if sys.argv[2] == "mc" else LOSS_ATT))
 w = dict(make_weights(p, seed=81))
 # blow the batch-norm scale behind block 3's depthwise conv up by 3e5 and shrink the projection kernel that follows by the
 # same factor: the network computes what it computed before (the squeeze-excite gate saturates, nothing else changes
@@ -193,29 +194,110 @@ assert len(k) == 1 and len(q) == 1, (k, q)
 w[k[0]] = w[k[0]] * np.float32(3.0e5)
 w[q[0]] = w[q[0]] / np.float32(3.0e5)
 d = KerasDriver("_", False, p["name"], 2, False, p, weights=w)
-try:
-    det = d.serve(make_images(2, 100, 180, seed=82))
-    print("served", bool(np.isfinite(det[0]).all()))
-except RuntimeError as e:
-    print("raised", str(e)[:300])
+d.set_dropout_seed(5)
+out = {}
+a = make_images(2, 100, 180, seed=82)
+b = make_images(2, 128, 192, seed=83)
+det = d.serve(a)
+out["n_after_first"] = np.int64(d.range_demotions())
+cls, box = d.head_outputs(2)
+det2 = d.serve(a)
+out["n_after_second"] = np.int64(d.range_demotions())
+for i, (x, y) in enumerate(zip(det, det2)):
+    assert np.array_equal(x, y), "the second serve of the same batch differs"
+    out["det_%%d" %% i] = x
+for i, x in enumerate(cls + box):
+    out["head_%%d" %% i] = x
+# pipelined serves of further batches on the same handle (the op stays re-packed)
+for j, dets in enumerate(d.serve_stream([b, a, b])):
+    for i, x in enumerate(dets):
+        out["stream%%d_%%d" %% (j, i)] = x
+out["n_final"] = np.int64(d.range_demotions())
+out["finite"] = np.bool_(all(np.isfinite(v).all() for k_, v in out.items() if k_.startswith(("det_", "head_", "stream"))))
+np.savez(sys.argv[1], **out)
 d.close()
+print("saved")
+"""
+
+OVERFLOW_STREAM_WORKER = r"""
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import numpy as np
+from common import FULL_MC, make_images, make_params, make_weights
+from uda_amd.infer_lib import KerasDriver
+p = make_params(**FULL_MC)
+w = dict(make_weights(p, seed=81))
+k = [n for n in w if n.endswith("blocks_3/tpu_batch_normalization_1/gamma")]
+q = [n for n in w if n.endswith("blocks_3/conv2d_1/kernel")]
+w[k[0]] = w[k[0]] * np.float32(3.0e5)
+w[q[0]] = w[q[0]] / np.float32(3.0e5)
+batches = [make_images(2, 100, 180, seed=82), make_images(2, 128, 192, seed=83), make_images(1, 90, 200, seed=84), make_images(2, 128, 192, seed=85)]
+out = {}
+for tag in ("stream", "serial"):
+    d = KerasDriver("_", False, p["name"], 2, False, p, weights=w)      # a FRESH handle: the flag is first raised inside the stream
+    d.set_dropout_seed(5)
+    if tag == "stream":
+        res = list(d.serve_stream(batches))
+    else:
+        res = [d.serve(x) for x in batches]
+    out["n_" + tag] = np.int64(d.range_demotions())
+    for j, dets in enumerate(res):
+        for i, x in enumerate(dets):
+            out["%%s%%d_%%d" %% (tag, j, i)] = x
+    d.close()
+np.savez(sys.argv[1], **out)
+print("saved")
 """
 
 
-def test_fp16_pieces_fail_loudly_on_an_activation_above_65504(tmp_path):
-    """Two fp16 pieces cannot hold an operand above 65504.  Every kernel that splits operands tracks the largest one and
-    raises the handle's range flag; every reader of the run's results checks it: the serve() fails with a message that
-    names the remedy - it does not return infinities.  The same weights serve under three bf16 pieces."""
-    res = {}
-    for scheme in ("f16x2", "bf16x3"):
-        e = dict(os.environ, UDA_PW_SCHEME=scheme)
-        e.pop("UDA_PW_TERMS", None)
-        r = subprocess.run([sys.executable, "-c", OVERFLOW_WORKER % {"root": ROOT}], cwd=ROOT, env=e, capture_output=True,
-                           text=True, timeout=600)
-        assert r.returncode == 0, (scheme, r.stdout[-1500:], r.stderr[-1500:])
-        res[scheme] = [l for l in r.stdout.splitlines() if l.startswith(("served", "raised"))][-1]
-    assert res["f16x2"].startswith("raised") and "65504" in res["f16x2"] and "bf16x3" in res["f16x2"], res
-    assert res["bf16x3"] == "served True", res
+def _overflow_run(worker, tmp_path, tag, scheme, *args):
+    e = dict(os.environ, UDA_PW_SCHEME=scheme)
+    e.pop("UDA_PW_TERMS", None)
+    out = str(tmp_path / ("%s_%s.npz" % (tag, scheme)))
+    r = subprocess.run([sys.executable, "-c", worker % {"root": ROOT}, out, *args], cwd=ROOT, env=e, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "saved" in r.stdout, (scheme, r.stdout[-1500:], r.stderr[-2500:])
+    return dict(np.load(out)), r.stderr
+
+
+@pytest.mark.parametrize("mode", ["det", "mc"])
+def test_fp16_range_overflow_is_served_on_three_bf16_pieces(tmp_path, mode):
+    """Two fp16 pieces cannot hold an operand above 65504.  Every kernel that splits operands raises its OP's flag word;
+    every reader of a run's results looks first.  The reference computes in float32 and always returns
+    (infer_lib.py:337-343) - so the handle re-packs the first flagged op with three bf16 pieces, serves the run again from
+    its unchanged inputs and only then returns: finite detections, ONE demotion (the ops behind the offender only saw its
+    infinities), no second demotion when the batch is served again or when further batches stream through the handle.
+    What comes back equals, within the float32 bar, what a handle that runs EVERYTHING on three bf16 pieces returns."""
+    got, err = _overflow_run(OVERFLOW_WORKER, tmp_path, "ovf_" + mode, "f16x2", mode)
+    ref, _ = _overflow_run(OVERFLOW_WORKER, tmp_path, "ovf_" + mode, "bf16x3", mode)
+    assert bool(got["finite"]) and bool(ref["finite"])
+    assert int(got["n_after_first"]) == 1 and int(got["n_after_second"]) == 1 and int(got["n_final"]) == 1, (got["n_after_first"], got["n_final"])
+    assert int(ref["n_final"]) == 0
+    assert err.count("fp16 range: op") == 1 and "served again" in err
+    heads = sorted(k for k in got if k.startswith("head_"))
+    assert len(heads) == 10
+    for k in heads:
+        g, r = got[k].astype(np.float64), ref[k].astype(np.float64)
+        assert np.sqrt(np.mean((g - r) ** 2)) <= 1e-5 * np.sqrt(np.mean(r * r)) + 1e-7, k
+    for k in got:
+        if k.startswith(("det_", "stream")) and k.endswith("_3"):
+            np.testing.assert_array_equal(got[k], ref[k], err_msg=k)        # valid_len
+    for k in ("det_0", "det_1"):
+        np.testing.assert_allclose(got[k], ref[k], rtol=1e-3, atol=1e-3, err_msg=k)
+
+
+def test_fp16_range_overflow_inside_a_stream_is_served_too(tmp_path):
+    """The flag is first raised by the FIRST of several pipelined runs, with the second already queued behind it: everything
+    in flight is let finish, the op is re-packed, that run is served again into its own output set, the queued run keeps its
+    own flags (it overflowed as well: it is served again when it is collected).  The stream returns what one-at-a-time
+    serves on a fresh handle return, bit for bit, and both handles re-packed the same single op."""
+    got, err = _overflow_run(OVERFLOW_STREAM_WORKER, tmp_path, "ovf_stream", "f16x2")
+    assert int(got["n_stream"]) == 1 and int(got["n_serial"]) == 1
+    keys = sorted(k for k in got if k.startswith("stream"))
+    assert len(keys) >= 4 * 4
+    for k in keys:
+        np.testing.assert_array_equal(got[k], got["serial" + k[len("stream"):]], err_msg=k)
+        assert np.isfinite(got[k]).all(), k
 
 
 STEM_WORKER = r"""

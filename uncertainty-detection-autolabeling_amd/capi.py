@@ -88,6 +88,8 @@ _SIGNATURES = {
     "uda_run_async": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32)]),
     "uda_collect": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
     "uda_collect_device": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int32)]),
+    "uda_drain": (C.c_int, [_P]),
+    "uda_range_demotions": (C.c_int64, [_P]),
     "uda_nms_prefix_fallbacks": (C.c_int64, [_P]),
     "uda_nms_coop_fallbacks": (C.c_int64, [_P]),
     "uda_nms_coop_not_launched": (C.c_int64, [_P]),

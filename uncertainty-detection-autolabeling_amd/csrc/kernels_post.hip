@@ -1757,32 +1757,25 @@ void launch_nms_reg(const NmsArgs& a, const float* scores, hipStream_t s) {
 // on a multi-XCD part a release / acquire pair writes back and invalidates the whole L2 - measured: every load
 // after a fenced barrier missed).  The spin is bounded: a time-out raises *err and every later step falls through.
 constexpr int COOP_MAX_BPI = 64;     // blocks per problem: one exchange slot per lane of the polling wave
-__device__ __forceinline__ unsigned long long coop_exchange(unsigned long long* slots, int blk, int bpi, unsigned long long mine,
-                                                            RegLds& S, int* err, unsigned spin_max) {
-  __syncthreads();                           // `mine` may come out of LDS traffic of the whole block
-  if (threadIdx.x < 64) {
-    if (threadIdx.x == 0) __hip_atomic_store(&slots[blk], mine ? mine : 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long v = 1ull;
-    if ((int)threadIdx.x < bpi) {
-      unsigned spins = 0;
-      while ((v = __hip_atomic_load(&slots[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0ull) {
-        ++spins;
-        if ((spins & 4095u) == 0u || spins > spin_max) {
-          if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-          if (spins > spin_max) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        }
-      }
-    }
-    if (v <= 1ull) v = 0ull;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {  // bpi <= 64
-      const unsigned long long o = __shfl_xor(v, off, 64);
-      v = o > v ? o : v;
-    }
-    if (threadIdx.x == 0) S.L = v;
-  }
-  __syncthreads();
-  return S.L;
+
+// Maximum of a 64-bit key over the 64 lanes of a wave, in every lane: two 32-bit DPP reductions (row_shr 1 / 2 / 4 / 8, row_bcast
+// 15 / 31 - seven instructions each, no LDS traffic; a __shfl_xor ladder is six dependent ds_bpermute round trips per word):
+// the high word (ordered score) first, then the low word (~index) among the lanes that hold the maximal high word.
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  unsigned t;
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); v = t > v ? t : v;   // row_shr:1
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); v = t > v ? t : v;   // row_shr:2
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, false); v = t > v ? t : v;   // row_shr:4, banks 1-3
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, false); v = t > v ? t : v;   // row_shr:8, banks 2-3
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); v = t > v ? t : v;   // row_bcast:15, rows 1 and 3
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); v = t > v ? t : v;   // row_bcast:31, rows 2 and 3
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned long long wave_max_key(unsigned long long k) {
+  const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
+  const unsigned mh = wave_max_u32(hi);
+  const unsigned ml = wave_max_u32(hi == mh ? lo : 0u);
+  return ((unsigned long long)mh << 32) | ml;
 }
 
 __device__ unsigned long long g_nms_dbg[8];
@@ -1831,8 +1824,8 @@ struct CoopLds {
 
 // Grid-wide step of a problem with `nm` words per block (X.mine[0 .. nm): keys, 0 = none, COOP_OVF): data and arrival are
 // one word each, as in coop_exchange; wave 0 polls the problem's bpi x nm words (bpi <= 64: at most COOP_W per lane) and
-// leaves the COOP_W largest keys in X.top (keys are unique: the candidate index is part of them).
-__device__ __forceinline__ void coop_exchange_top(unsigned long long* slots, int blk, int bpi, int nm, CoopLds& X, int* err, unsigned spin_max) {
+// leaves the nt largest keys in X.top[0 .. nt) (keys are unique: the candidate index is part of them), 0 behind them.
+__device__ __forceinline__ void coop_exchange_top(unsigned long long* slots, int blk, int bpi, int nm, int nt, CoopLds& X, int* err, unsigned spin_max) {
   __syncthreads();                           // X.mine is complete
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
@@ -1860,20 +1853,18 @@ __device__ __forceinline__ void coop_exchange_top(unsigned long long* slots, int
       if (v == COOP_OVF) ovf = true;
       loc[q] = v <= COOP_OVF ? 0ull : v;
     }
+    for (int r = 0; r < COOP_W; ++r) {        // the nt largest (the rest of X.top: 0)
+      unsigned long long m = 0ull;
+      if (r < nt) {
+        m = loc[0];
 #pragma unroll
-    for (int r = 0; r < COOP_W; ++r) {
-      unsigned long long m = loc[0];
+        for (int q = 1; q < COOP_W; ++q) m = loc[q] > m ? loc[q] : m;
+        m = wave_max_key(m);
 #pragma unroll
-      for (int q = 1; q < COOP_W; ++q) m = loc[q] > m ? loc[q] : m;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_xor(m, off, 64);
-        m = o > m ? o : m;
+        for (int q = 0; q < COOP_W; ++q)
+          if (loc[q] == m) loc[q] = 0ull;
       }
       if (lane == 0) X.top[r] = m;
-#pragma unroll
-      for (int q = 0; q < COOP_W; ++q)
-        if (loc[q] == m) loc[q] = 0ull;
     }
     const bool any = __ballot(ovf) != 0ull;
     if (lane == 0) X.ovf = any ? 1 : 0;
@@ -2094,7 +2085,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
     __syncthreads();
     const unsigned long long t1 = wall_clock64();
 #endif
-    coop_exchange_top(sslots, blk, bpi, 1, X, err, spin_max);
+    coop_exchange_top(sslots, blk, bpi, 1, wcfg, X, err, spin_max);
     // the step's bound: the weff-th largest block key (fewer blocks alive: the smallest one; none: 0 = everything is evaluated)
     int nz = 0;
 #pragma unroll
@@ -2136,22 +2127,17 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
     if (tid < 64) {
       const int cnt = X.kcount;
       if (weff == 1 || cnt > COOP_KL) {
-        if (tid < COOP_W) X.mine[tid] = tid == 0 ? ke : ((tid == 1 && weff > 1) ? COOP_OVF : 0ull);
+        if (tid < COOP_W) X.mine[tid] = tid == 0 ? ke : ((tid == 1 && weff > 1) ? COOP_OVF : 0ull);      // (words behind weff are not sent)
       } else {
         unsigned long long loc[COOP_KL / 64];
 #pragma unroll
         for (int q = 0; q < COOP_KL / 64; ++q) loc[q] = (tid + 64 * q < cnt) ? klist[tid + 64 * q] : 0ull;
-#pragma unroll
-        for (int r = 0; r < COOP_W; ++r) {
+        for (int r = 0; r < weff; ++r) {
           unsigned long long m = loc[0];
 #pragma unroll
           for (int q = 1; q < COOP_KL / 64; ++q) m = loc[q] > m ? loc[q] : m;
-#pragma unroll
-          for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long o = __shfl_xor(m, off, 64);
-            m = o > m ? o : m;
-          }
-          if (tid == 0) X.mine[r] = r < weff ? m : 0ull;
+          m = wave_max_key(m);
+          if (tid == 0) X.mine[r] = m;
 #pragma unroll
           for (int q = 0; q < COOP_KL / 64; ++q)
             if (loc[q] == m) loc[q] = 0ull;
@@ -2161,7 +2147,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
 #ifdef UDA_NMS_STATS
     const unsigned long long t3 = wall_clock64();
 #endif
-    coop_exchange_top(sslots + bpi, blk, bpi, COOP_W, X, err, spin_max);
+    coop_exchange_top(sslots + bpi, blk, bpi, weff, weff, X, err, spin_max);
 #ifdef UDA_NMS_STATS
     const unsigned long long t4 = wall_clock64();
 #endif

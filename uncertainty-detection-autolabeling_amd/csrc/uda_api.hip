@@ -43,8 +43,28 @@ struct uda_ctx {
   std::vector<int> wscheme;        // per op: the scheme its packed weights use (an op whose weights do not suit fp16 pieces keeps bf16 x3)
   std::vector<float> wunscale;     // per op: 1 / (power-of-two factor folded into the packed weights); 1 unless fp16 pieces
   int n_f16_ops = 0, n_f16_demoted = 0;
-  unsigned* d_oor = nullptr;       // fp16 pieces: bit 0 set by any kernel that split an operand above 65504
-  bool oor_armed = false;          // a run with fp16-piece ops has been queued since the flag was last read
+  // fp16 pieces: a kernel that splits an operand above 65504 sets bit 0 of ITS OP's flag word.  Two arrays of n_ops + 1
+  // words (index n_ops: launches outside the op list): pipelined run s raises its flags in array s, everything else in array 0.
+  unsigned* d_oor = nullptr;
+  unsigned* oor_cur = nullptr;     // the array the launches being queued raise their flags in
+  int oor_half = 0;                // the array the readers of the current results look at (check_split_range)
+  bool oor_armed = false;          // a run with fp16-piece ops has been queued since the flags were last read
+  // An op that raises its flag is re-packed with three bf16 pieces (float32 exponent range) and the run is served again
+  // on the same handle (demote_ops / replay_run): the reference computes in float32 and never rejects an input on magnitude.
+  std::vector<float> h_weights;    // host copy of the weight blob (for the re-packing)
+  std::vector<uint16_t*> wovr;     // per op: device copy of its re-packed weights (null: its slice of d_wsplit)
+  std::vector<int64_t> wovr_par;   // per op: uint16 offset of the parameter block inside wovr (-1: none)
+  int64_t range_demotions = 0;     // ops re-packed so far (uda_range_demotions)
+  // What a run read, so that it can be served again: input slot / float image generation, seed, image offset, masks.
+  struct RunRec {
+    bool valid = false, do_post = false, have_u8 = false, masks_injected = false;
+    int pm = 0, cur = 0, n = 0;
+    uint64_t slot_gen = 0, f32_gen = 0, masks_gen = 0, seed = 0;
+    int64_t image_offset = 0;
+  };
+  RunRec last_run;                 // the last synchronous uda_run
+  const RunRec* replay_rec = nullptr;   // the run whose results the readers are looking at (null: cannot be served again)
+  uint64_t f32_gen = 0, masks_gen = 0;
   float* d_arena = nullptr;
   uint4* d_w0frag[2] = {nullptr, nullptr};   // gated, split projection kernel per gate row for the fused block-1 kernel (launch_w0gate), per chunk lane
   size_t w0frag_cap[2] = {0, 0};
@@ -75,6 +95,7 @@ struct uda_ctx {
     size_t pcap = 0;
     int n = 0;
     bool valid = false, uploaded = false;
+    uint64_t gen = 0;            // bumped by every upload into this slot (a run can be served again only from unchanged inputs)
     std::vector<PreGeo> geo;     // per image: offset, raw size, scaled size, sampling ratios (dataloader.py:123-152)
     PreGeo* d_geo = nullptr;     // = d (the table leads the buffer)
     uint8_t* d_img = nullptr;    // = d + header
@@ -168,6 +189,8 @@ struct uda_ctx {
     int64_t seq = 0;
     int n = 0, mode = 0;
     bool coop_used = false, oor_armed = false;
+    bool cands_lost = false;             // an older run was served again after this one: its candidates are gone (no redo of its post-process)
+    RunRec rec;                          // what this run read (replay_run)
     std::vector<std::pair<int, int>> pending;      // prefix-NMS ranges the host has not checked (rare path: no cooperative NMS)
     float *oboxes = nullptr, *oscores = nullptr, *oclasses = nullptr, *ologits = nullptr, *scales = nullptr;
     int32_t* ovalid = nullptr;
@@ -305,6 +328,7 @@ extern "C" void uda_destroy(uda_ctx_t* c) {
   if (c->copy_stream) hipStreamDestroy(c->copy_stream);
   for (auto& p : c->d_w0frag) if (p) hipFree(p);
   if (c->d_oor) hipFree(c->d_oor);
+  for (uint16_t* p : c->wovr) if (p) hipFree(p);
   void* ptrs[] = {c->d_weights, c->d_wsplit, c->d_arena, c->d_anchors, c->d_images, c->d_scales, c->d_masks,
                   c->d_site_off, c->d_site_ch, c->d_site_rate, c->d_cboxes, c->d_cscores, c->d_clogits,
                   c->d_cclasses, c->d_ucls, c->d_ual, c->d_uep, c->d_clsmean, c->d_cand_flat, c->d_merge_keys,
@@ -549,8 +573,12 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
     c->wpar_off.assign(n_ops, -1);
     c->wscheme.assign(n_ops, c->pw_parts);
     c->wunscale.assign(n_ops, 1.0f);
-    CK(dalloc(&c->d_oor, 1));
-    CK(hipMemset(c->d_oor, 0, sizeof(unsigned)));
+    CK(dalloc(&c->d_oor, 2 * ((size_t)n_ops + 1)));
+    CK(hipMemset(c->d_oor, 0, 2 * ((size_t)n_ops + 1) * sizeof(unsigned)));
+    c->oor_cur = c->d_oor;
+    c->wovr.assign(n_ops, nullptr);
+    c->wovr_par.assign(n_ops, -1);
+    c->h_weights.assign(weights, weights + n_weights);
     const char* em = getenv("UDA_MBX_BF16");
     const bool mbx_bf16 = em ? atoi(em) != 0 : true;
     if (c->pw_parts) {
@@ -870,6 +898,7 @@ static int fill_slot(uda_ctx* c, int si, const void* images, const uint8_t* cons
   HIPC(c, hipEventRecord(sl.ev, st));
   sl.n = n;
   sl.valid = true;
+  ++sl.gen;
   return 0;
 }
 
@@ -955,6 +984,7 @@ extern "C" int uda_set_images_f32(uda_ctx_t* c, const float* images, int32_t n, 
   c->n_images = n;
   c->have_u8 = false;
   c->stem_from_u8 = false;
+  ++c->f32_gen;
   return 0;
 }
 
@@ -980,6 +1010,7 @@ extern "C" int uda_set_dropout_masks(uda_ctx_t* c, const float* masks, int64_t n
   HIPC(c, hipSetDevice(c->device));
   if (n_floats) HIPC(c, hipMemcpyAsync(c->d_masks, masks, n_floats * sizeof(float), hipMemcpyHostToDevice, c->stream));
   c->masks_injected = true;
+  ++c->masks_gen;
   c->masks_rows = c->sum_site_ch ? (int)(n_floats / c->sum_site_ch) : 0;
   return 0;
 }
@@ -1020,6 +1051,13 @@ struct ChunkView {
     return (out.per_sample && !in.per_sample) ? c->model.mc_samples : 1;
   }
 };
+
+// packed 1x1 weights / parameter block of op oi: its slice of d_wsplit, or its re-packed copy after a range demotion
+static inline const uint16_t* wsplit_of(const uda_ctx* c, int oi) { return c->wovr[oi] ? c->wovr[oi] : c->d_wsplit + c->wsplit_off[oi]; }
+static inline bool has_wpar(const uda_ctx* c, int oi) { return c->wovr[oi] ? c->wovr_par[oi] >= 0 : c->wpar_off[oi] >= 0; }
+static inline const uint16_t* wpar_of(const uda_ctx* c, int oi) {
+  return c->wovr[oi] ? c->wovr[oi] + c->wovr_par[oi] : c->d_wsplit + c->wpar_off[oi];
+}
 
 // FuseArgs of op oi's inputs (FUSE / POOL, and SEP with fuse_in: the BiFPN fusion in front of the node's separable conv)
 static int fill_fuse_args(uda_ctx* c, const ChunkView& v, int oi, FuseArgs& a) {
@@ -1115,10 +1153,10 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       a.res_div = o.residual >= 0 ? v.div(c->bufs[o.residual], ob) : 1;
       a.act = o.act;
       if (c->wsplit_off[oi] >= 0) {
-        a.wsplit = c->d_wsplit + c->wsplit_off[oi];
+        a.wsplit = wsplit_of(c, oi);
         a.wparts = c->wscheme[oi];
         a.wunscale = c->wunscale[oi];
-        a.oor = c->d_oor;
+        a.oor = c->oor_cur + oi;
         if (a.wparts == UDA_SPLIT_F16X2) c->oor_armed = true;
         launch_pwb(a, rows, v.stream());
       } else {
@@ -1184,11 +1222,11 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
         a.se_partial = v.ptr(o.se_partial);
       }
       if (c->wsplit_off[oi] >= 0) {
-        a.wsplit = c->d_wsplit + c->wsplit_off[oi];
+        a.wsplit = wsplit_of(c, oi);
         a.wparts = c->wscheme[oi];
-        a.oor = c->d_oor;
+        a.oor = c->oor_cur + oi;
         if (a.wparts == UDA_SPLIT_F16X2) c->oor_armed = true;
-        a.wpar = (const float*)(c->d_wsplit + c->wpar_off[oi]);
+        a.wpar = (const float*)wpar_of(c, oi);
         if (fuse0) {
           const uda_buf_desc_t& gb = c->bufs[o.se_scale];
           if (gb.per_sample && !ob.per_sample) return fail(c, "op %d: per-sample gate on a per-image output", oi);
@@ -1211,7 +1249,7 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
               HIPC(c, hipMalloc((void**)&c->d_w0frag[ln], need * sizeof(uint4)));
               c->w0frag_cap[ln] = need;
             }
-            launch_w0gate(a.gate, a.w0t, a.c0, gate_rows, a.wparts, c->d_w0frag[ln], c->d_oor, v.stream());
+            launch_w0gate(a.gate, a.w0t, a.c0, gate_rows, a.wparts, c->d_w0frag[ln], c->oor_cur + oi, v.stream());
             a.w0frag = c->d_w0frag[ln];
           }
         }
@@ -1228,11 +1266,11 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       SepArgs a{};
       a.in = v.ptr(o.in[0]);
       a.out = v.ptr(o.out);
-      a.wd = c->wpar_off[oi] >= 0 ? (const float*)(c->d_wsplit + c->wpar_off[oi]) : v.wt(o.w2_off);    // (fp16 pieces: pre-scaled taps)
-      a.wsplit = c->d_wsplit + c->wsplit_off[oi];
+      a.wd = has_wpar(c, oi) ? (const float*)wpar_of(c, oi) : v.wt(o.w2_off);    // (fp16 pieces: pre-scaled taps)
+      a.wsplit = wsplit_of(c, oi);
       a.wparts = c->wscheme[oi];
       a.wunscale = c->wunscale[oi];
-      a.oor = c->d_oor;
+      a.oor = c->oor_cur + oi;
       if (a.wparts == UDA_SPLIT_F16X2) c->oor_armed = true;
       a.bias = v.wt(o.bias_off);
       a.bn_scale = v.wt(o.bn_scale_off);
@@ -1318,8 +1356,8 @@ static int run_sep_group(uda_ctx* c, const ChunkView& v, int oi, int n) {
       if (k != j && (c->ops[oi + k].out == o.in[0] || c->ops[oi + k].out == o.out)) return -1;    // not independent
     lv[j].in = v.ptr(o.in[0]);
     lv[j].out = v.ptr(o.out);
-    lv[j].wd = c->wpar_off[oi + j] >= 0 ? (const float*)(c->d_wsplit + c->wpar_off[oi + j]) : v.wt(o.w2_off);
-    lv[j].wsplit = c->d_wsplit + c->wsplit_off[oi + j];
+    lv[j].wd = has_wpar(c, oi + j) ? (const float*)wpar_of(c, oi + j) : v.wt(o.w2_off);
+    lv[j].wsplit = wsplit_of(c, oi + j);
     lv[j].bias = v.wt(o.bias_off);
     lv[j].bn_scale = v.wt(o.bn_scale_off);
     lv[j].bn_shift = v.wt(o.bn_shift_off);
@@ -1353,7 +1391,7 @@ static int run_sep_group(uda_ctx* c, const ChunkView& v, int oi, int n) {
   a.act = o0.act;
   a.wparts = c->wscheme[oi];
   a.wunscale = c->wunscale[oi];
-  a.oor = c->d_oor;
+  a.oor = c->oor_cur + oi;            // (one word for the layer's launch: its levels share the 1x1 kernel and are re-packed together)
   if (a.wparts == UDA_SPLIT_F16X2) c->oor_armed = true;
   launch_sep_multi(a, lv, n, v.rows(ob0), v.stream());
   return 0;
@@ -1715,22 +1753,147 @@ static int run_post(uda_ctx* c, int n, int post_mode) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------ fp16 range: demote and serve again
 // fp16-piece contractions (UDA_SPLIT_F16X2): an activation above 65504 cannot be split and its products are infinite.
-// Every kernel that splits operands reports that through one flag word; every reader of a run's results comes through
-// here first and fails loudly instead of returning them.
+// Every kernel that splits operands reports that through its op's flag word; every reader of a run's results comes
+// through check_split_range first.  A raised flag does not fail the run (the reference computes in float32 and always
+// returns, infer_lib.py:337-343): the FIRST flagged op in op order - everything behind it only saw its infinities - is
+// re-packed with three bf16 pieces (float32 exponent range; its kernels exist per op: `wscheme`), the run is served
+// again from its unchanged inputs on the same handle, and the flags are read again, until the run is clean.  The op
+// stays demoted for the life of the handle (`uda_range_demotions` counts them; one line on stderr each).
+static int current_run_rec(const uda_ctx* c, uda_ctx::RunRec* r, int pm, bool do_post) {
+  r->valid = true; r->pm = pm; r->do_post = do_post;
+  r->have_u8 = c->have_u8; r->cur = c->cur; r->n = c->n_images;
+  r->slot_gen = c->u8[c->cur].gen; r->f32_gen = c->f32_gen;
+  r->masks_injected = c->masks_injected; r->masks_gen = c->masks_gen;
+  r->seed = c->seed; r->image_offset = c->image_offset;
+  return 0;
+}
+
+static bool can_replay(const uda_ctx* c, const uda_ctx::RunRec* r) {
+  if (!r || !r->valid) return false;
+  if (r->have_u8 ? c->u8[r->cur].gen != r->slot_gen : c->f32_gen != r->f32_gen) return false;
+  if (r->masks_injected && c->masks_gen != r->masks_gen) return false;
+  return true;
+}
+
+// Re-pack op `oi` (and the ops that share its launch: the pyramid levels of a head layer) with three bf16 pieces.
+static int demote_ops(uda_ctx* c, int oi) {
+  const int n_ops = (int)c->ops.size();
+  if (oi < 0 || oi >= n_ops) return fail(c, "fp16 range flag outside the op list (word %d): re-create the handle with UDA_PW_SCHEME=bf16x3", oi);
+  int g0 = oi, g1 = oi + 1;
+  for (int i = 0; i < n_ops; ++i) {
+    const int lg = c->ops[i].launch_group;
+    if (lg > 1 && i <= oi && oi < i + lg) { g0 = i; g1 = i + lg; break; }
+  }
+  const float* weights = c->h_weights.data();
+  int done = 0;      // (0: re-packed already - a pipelined run queued before that demotion raised the same flag)
+  for (int i = g0; i < g1 && i < n_ops; ++i) {
+    const uda_op_t& o = c->ops[i];
+    if (c->wscheme[i] != UDA_SPLIT_F16X2 || c->wsplit_off[i] < 0) continue;
+    const int K = c->bufs[o.in[0]].C, Nn = c->bufs[o.out].C;
+    const int sch = UDA_SPLIT_BF16X3;
+    std::vector<uint16_t> packed;
+    int64_t par = -1;
+    size_t lds = 0;
+    if (o.kind == UDA_OP_PW || o.kind == UDA_OP_SEP) {
+      packed.resize((pwb_packed_elems(K, Nn, sch) + 7) / 8 * 8);
+      pwb_pack_weights(weights + o.w_off, K, Nn, sch, packed.data(), 1.0f);
+      if (o.kind == UDA_OP_SEP) {
+        lds = o.fuse_in ? sepf_lds_bytes(K, Nn, sch) : sep_lds_bytes(K, Nn, sch);
+        if (o.fuse_in && !sepf_supported(K, Nn, sch))
+          return fail(c, "op %d raised the fp16 range flag and has no three-piece kernel (fused-input separable conv %d -> %d): "
+                         "re-create the handle with UDA_PW_SCHEME=bf16x3", i, K, Nn);
+      }
+    } else if (o.kind == UDA_OP_MBX) {
+      const bool fuse0 = o.se_scale >= 0;
+      const int Ke = fuse0 ? o.se_mid : K;
+      const size_t we = (mbxb_packed_elems(Ke, Nn, sch) + 7) / 8 * 8;
+      const size_t par_fl = mbx_par_floats(Nn, o.k), proj_fl = fuse0 ? 32 * 32 + 32 : 0;
+      packed.resize(we + 2 * (par_fl + proj_fl));
+      mbxb_pack_weights(weights + o.w_off, weights + o.bn_scale_off, weights + o.bn_shift_off, Ke, Nn, packed.data(), fuse0, sch);
+      std::vector<float> pf(par_fl + proj_fl);
+      mbx_pack_params(weights + o.w2_off, weights + o.bn2_scale_off, weights + o.bn2_shift_off, Nn, o.k, pf.data());
+      if (fuse0) mbxb_pack_proj(weights + o.se_w1_off, weights + o.se_b1_off, weights + o.se_w2_off, K, Ke, pf.data() + par_fl);
+      memcpy(packed.data() + we, pf.data(), pf.size() * sizeof(float));
+      par = (int64_t)we;
+      lds = mbx_lds_bytes(Ke, Nn, o.k, o.stride, sch, c->bufs[o.out].H, c->bufs[o.out].W);
+    } else {
+      continue;
+    }
+    if (lds > (size_t)160 * 1024)
+      return fail(c, "op %d raised the fp16 range flag and its three-piece launch needs %zu bytes of LDS (a CU has 163840): "
+                     "re-create the handle with UDA_PW_SCHEME=bf16x3", i, lds);
+    uint16_t* d = nullptr;
+    HIPC(c, hipMalloc((void**)&d, packed.size() * sizeof(uint16_t)));
+    HIPC(c, hipMemcpy(d, packed.data(), packed.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    if (c->wovr[i]) hipFree(c->wovr[i]);
+    c->wovr[i] = d;
+    c->wovr_par[i] = par;
+    c->wscheme[i] = sch;
+    c->wunscale[i] = 1.0f;
+    ++c->range_demotions;
+    ++done;
+    fprintf(stderr, "[uda] fp16 range: op %d (kind %d, %d -> %d channels) saw an operand above 65504 and now runs on three bf16 pieces "
+                    "(demotion %lld of this handle); the run is served again\n", i, o.kind, K, Nn, (long long)c->range_demotions);
+  }
+  (void)done;      // serving the run again is all that is left to do in that case
+  return 0;
+}
+
+// Serve run `r` again, synchronously, into whatever output set / scales the context currently points at.
+static int replay_run(uda_ctx* c, const uda_ctx::RunRec& r) {
+  const bool have_u8 = c->have_u8, inj = c->masks_injected;
+  const int cur = c->cur, n = c->n_images;
+  const uint64_t seed = c->seed;
+  const int64_t off = c->image_offset;
+  c->have_u8 = r.have_u8; c->cur = r.cur; c->n_images = r.n; c->seed = r.seed; c->image_offset = r.image_offset;
+  c->masks_injected = r.masks_injected;
+  c->pfx_pending.clear();
+  const bool pfx_off = c->pfx_off;
+  c->pfx_off = true;               // full candidate set: nothing is left pending for the host behind the replay
+  int rc = run_network(c, 0, false, nullptr);
+  if (!rc && r.do_post) rc = run_post(c, r.n, r.pm);
+  c->pfx_off = pfx_off;
+  if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, "replay_run: the stream failed");
+  c->have_u8 = have_u8; c->cur = cur; c->n_images = n; c->seed = seed; c->image_offset = off; c->masks_injected = inj;
+  return rc;
+}
+
+// first raised flag word of array `half` (or -1), cleared once read
+static int read_range_flags(uda_ctx* c, int half, int* first) {
+  const size_t nw = c->ops.size() + 1;
+  std::vector<unsigned> f(nw);
+  unsigned* base = c->d_oor + (size_t)half * nw;
+  HIPC(c, hipMemcpy(f.data(), base, nw * sizeof(unsigned), hipMemcpyDeviceToHost));
+  *first = -1;
+  for (size_t i = 0; i < nw; ++i)
+    if (f[i]) { *first = (int)i; break; }
+  if (*first >= 0) HIPC(c, hipMemset(base, 0, nw * sizeof(unsigned)));
+  return 0;
+}
+
 static int check_split_range(uda_ctx* c) {
   if (!c->oor_armed) return 0;
   c->oor_armed = false;
   HIPC(c, hipStreamSynchronize(c->stream));
-  unsigned f = 0;
-  HIPC(c, hipMemcpy(&f, c->d_oor, sizeof(unsigned), hipMemcpyDeviceToHost));
-  if (f) {
-    hipMemset(c->d_oor, 0, sizeof(unsigned));
-    return fail(c, "an activation above 65504 reached a 1x1 contraction that splits its operands into fp16 pieces "
-                   "(UDA_PW_SCHEME=f16x2): the results of this run are invalid.  Re-create the handle with "
-                   "UDA_PW_SCHEME=bf16x3 (three bf16 pieces: float32 exponent range)");
+  for (size_t round = 0; round <= c->ops.size(); ++round) {
+    int first = -1;
+    if (int rc = read_range_flags(c, c->oor_half, &first)) return rc;
+    if (first < 0) return 0;
+    if (int rc = demote_ops(c, first)) return rc;
+    if (!can_replay(c, c->replay_rec))
+      return fail(c, "an activation above 65504 reached op %d, whose operands were split into fp16 pieces: the results of this run are "
+                     "invalid and its inputs have been replaced since, so it cannot be served again here.  The op now runs on three "
+                     "bf16 pieces: run the batch again", first);
+    unsigned* keep = c->oor_cur;
+    c->oor_cur = c->d_oor + (size_t)c->oor_half * (c->ops.size() + 1);
+    const int rc = replay_run(c, *c->replay_rec);
+    c->oor_cur = keep;
+    c->oor_armed = false;
+    if (rc) return rc;
   }
-  return 0;
+  return fail(c, "fp16 range flags persist after every op was re-packed: internal error");
 }
 
 // Every reader of the post-process outputs comes through here: images whose score prefix turned out not to be
@@ -1765,6 +1928,8 @@ static int finish_post(uda_ctx* c) {
         c->last_n = a.n; c->last_post_mode = a.mode;
         c->coop_used = c->coop_used || a.coop_used;
         c->oor_armed = c->oor_armed || a.oor_armed;
+        c->oor_half = s;
+        c->replay_rec = &a.rec;
         c->pfx_pending.insert(c->pfx_pending.end(), a.pending.begin(), a.pending.end());
         a.coop_used = false; a.oor_armed = false; a.pending.clear();
       }
@@ -1838,6 +2003,14 @@ extern "C" int uda_run(uda_ctx_t* c, int32_t post_mode, int32_t do_post) {
   if (c->as_ready) { if (int rc = use_output_set(c, 0)) return rc; }
   c->d_scales_post = nullptr;
   c->pfx_pending.clear();
+  if (c->oor_armed) {       // flags of a run nobody read: they are not this run's
+    hipMemsetAsync(c->d_oor, 0, (c->ops.size() + 1) * sizeof(unsigned), c->stream);
+    c->oor_armed = false;
+  }
+  c->oor_cur = c->d_oor;
+  c->oor_half = 0;
+  current_run_rec(c, &c->last_run, post_mode < 0 ? c->model.post_mode : post_mode, do_post != 0);
+  c->replay_rec = &c->last_run;
   if (do_post && c->post_overlap) {
     const int pm = post_mode < 0 ? c->model.post_mode : post_mode;
     if (pm != UDA_POST_GLOBAL && pm != UDA_POST_PER_CLASS) return fail(c, "unknown post mode %d", pm);
@@ -1886,7 +2059,24 @@ static int resolve_slot_full(uda_ctx* c, int s) {
   use_output_set(c, s);
   c->d_scales_post = a.scales;
   c->last_n = a.n; c->last_post_mode = a.mode;
-  c->coop_used = a.coop_used; c->oor_armed = c->oor_armed || a.oor_armed;
+  c->coop_used = a.coop_used; c->oor_armed = a.oor_armed;
+  c->oor_half = s;
+  c->replay_rec = &a.rec;
+  if (a.cands_lost) {
+    // an older run was served again after this one had been queued: the candidates / NMS state of this run are gone, so a
+    // post-process that would have to be redone from them cannot be - say so instead of redoing it on another batch's data
+    a.cands_lost = false;
+    HIPC(c, hipStreamSynchronize(c->stream));
+    int e = 0;
+    if (a.coop_used) HIPC(c, hipMemcpy(&e, c->d_coop_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (e || !a.pending.empty()) {
+      if (e) { hipMemset(c->d_coop_err, 0, sizeof(int)); c->coop_off = true; ++c->coop_fallbacks; }
+      a.pending.clear(); a.coop_used = false; a.oor_armed = false;
+      return fail(c, "a pipelined run needs its post-process redone, but an older run was served again in between (fp16 range "
+                     "demotion) and replaced its candidates: run the batch again");
+    }
+    c->coop_used = false;
+  }
   c->pfx_pending.swap(a.pending);
   a.pending.clear(); a.coop_used = false; a.oor_armed = false;
   return finish_post(c);         // joins, synchronises the main stream, redoes what has to be redone
@@ -1910,6 +2100,13 @@ extern "C" int uda_run_async(uda_ctx_t* c, int32_t post_mode, int32_t* ticket) {
   if (rc) return rc;
   uda_ctx::AsyncSlot& a = c->as[s];
   use_output_set(c, s);
+  if (c->oor_armed) {       // flags of a synchronous run nobody read: they are not this run's
+    hipMemsetAsync(c->oor_cur, 0, (c->ops.size() + 1) * sizeof(unsigned), c->stream);
+    c->oor_armed = false;
+  }
+  c->oor_cur = c->d_oor + (size_t)s * (c->ops.size() + 1);
+  a.cands_lost = false;
+  current_run_rec(c, &a.rec, pm, true);
   HIPC(c, hipMemcpyAsync(a.scales, c->d_scales, (size_t)c->n_images * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
   c->d_scales_post = a.scales;
   c->pfx_pending.clear();
@@ -1955,15 +2152,36 @@ static int settle_ticket(uda_ctx* c, int ticket, const char* who) {
   // a newer run is queued behind this one: wait for this run's post-process only, check its flags, never touch the streams
   HIPC(c, hipEventSynchronize(a.ev));
   if (a.oor_armed) {
-    unsigned f = 0;
-    HIPC(c, hipMemcpy(&f, c->d_oor, sizeof(unsigned), hipMemcpyDeviceToHost));
-    if (f) {
-      a.open = false;
-      return fail(c, "an activation above 65504 reached a 1x1 contraction that splits its operands into fp16 pieces "
-                     "(UDA_PW_SCHEME=f16x2) in this or the following pipelined run: the results are invalid.  Re-create the "
-                     "handle with UDA_PW_SCHEME=bf16x3");
+    a.oor_armed = false;
+    int first = -1;
+    if (int rc = read_range_flags(c, ticket, &first)) { a.open = false; return rc; }
+    if (first >= 0) {
+      // This run split an operand above 65504.  Everything in flight is let finish (the newer run keeps its own flags and its
+      // own outputs), the op is re-packed and THIS run is served again into its own output set; the newer run's candidates
+      // are overwritten by that (cands_lost: its detections stay valid, a redo of its post-process would not be).
+      if (int rc = join_async(c)) { a.open = false; return rc; }
+      HIPC(c, hipStreamSynchronize(c->stream));
+      c->as[ticket ^ 1].cands_lost = true;
+      use_output_set(c, ticket);
+      c->d_scales_post = a.scales;
+      c->last_n = a.n; c->last_post_mode = a.mode;
+      unsigned* keep = c->oor_cur;
+      c->oor_cur = c->d_oor + (size_t)ticket * (c->ops.size() + 1);
+      int rc = 0;
+      for (size_t round = 0; round <= c->ops.size() && first >= 0 && !rc; ++round) {
+        rc = demote_ops(c, first);
+        if (!rc && !can_replay(c, &a.rec))
+          rc = fail(c, "an activation above 65504 reached op %d (fp16 pieces) in a pipelined run whose inputs have been replaced since: "
+                       "its results are invalid.  The op now runs on three bf16 pieces: run the batch again", first);
+        if (!rc) rc = replay_run(c, a.rec);
+        if (!rc) rc = read_range_flags(c, ticket, &first);
+      }
+      c->oor_cur = keep;
+      c->oor_armed = false;
+      a.coop_used = a.coop_used || c->coop_used;     // (a barrier time-out of the replay's NMS is looked at below)
+      c->coop_used = false;
+      if (rc) { a.open = false; return rc; }
     }
-    c->oor_armed = true;      // (the flag is cumulative: the newest run's readers look again)
   }
   if (a.coop_used) {
     int e = 0;
@@ -2023,6 +2241,38 @@ extern "C" int uda_collect_device(uda_ctx_t* c, int32_t ticket, int32_t rows, in
   return 0;
 }
 
+// Abandon every pipelined run in flight: wait for the device, discard the results, close the tickets, clear what the runs
+// left behind (range flags, a timed-out barrier) - the handle is as after the last collect.  A generator that is dropped
+// half way (ServingDriver.serve_stream) or a collect that failed leaves runs open; every later synchronous entry point
+// would refuse ("a pipelined run is in flight") until they are drained.
+extern "C" int uda_drain(uda_ctx_t* c) {
+  if (!c) return 1;
+  if (!c->as[0].open && !c->as[1].open) return 0;
+  HIPC(c, hipSetDevice(c->device));
+  if (int rc = join_async(c)) return rc;
+  HIPC(c, hipStreamSynchronize(c->stream));
+  const size_t nw = c->ops.size() + 1;
+  for (int s = 0; s < 2; ++s) {
+    uda_ctx::AsyncSlot& a = c->as[s];
+    if (!a.open) continue;
+    if (a.oor_armed && c->d_oor) HIPC(c, hipMemset(c->d_oor + (size_t)s * nw, 0, nw * sizeof(unsigned)));
+    if (a.coop_used) {
+      int e = 0;
+      HIPC(c, hipMemcpy(&e, c->d_coop_err, sizeof(int), hipMemcpyDeviceToHost));
+      if (e) { HIPC(c, hipMemset(c->d_coop_err, 0, sizeof(int))); c->coop_off = true; ++c->coop_fallbacks; }
+    }
+    a.open = false; a.joined = true; a.coop_used = false; a.oor_armed = false; a.cands_lost = false;
+    a.pending.clear();
+  }
+  c->pfx_pending.clear();
+  c->coop_used = false;
+  c->oor_armed = false;
+  c->replay_rec = nullptr;
+  c->d_scales_post = nullptr;
+  return 0;
+}
+
+extern "C" int64_t uda_range_demotions(const uda_ctx_t* c) { return c ? c->range_demotions : -1; }
 extern "C" int64_t uda_nms_prefix_fallbacks(const uda_ctx_t* c) { return c ? c->pfx_fallbacks : -1; }
 extern "C" int64_t uda_nms_coop_fallbacks(const uda_ctx_t* c) { return c ? c->coop_fallbacks : -1; }
 extern "C" int64_t uda_nms_coop_not_launched(const uda_ctx_t* c) { return c ? c->coop_not_launched : -1; }

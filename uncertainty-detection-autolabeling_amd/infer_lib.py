@@ -229,6 +229,17 @@ class ServingDriver:
         self._tickets[t.value] = (self._n_last(), mode)
         return t.value
 
+    def drain(self):
+        """Abandon every pipelined run in flight (`uda_drain`): results discarded, tickets closed."""
+        if getattr(self, "_h", None):
+            self._ck(self._lib.uda_drain(self._h), "uda_drain")
+        if hasattr(self, "_tickets"):
+            self._tickets.clear()
+
+    def range_demotions(self):
+        """Ops re-packed with three bf16 pieces because an operand exceeded fp16's range (`uda_range_demotions`)."""
+        return int(self._lib.uda_range_demotions(self._h))
+
     def collect(self, ticket):
         """The detections of a `run_async` (same tuple as `serve`): waits for that run's post-process only."""
         n, mode = self._tickets.pop(ticket)
@@ -345,17 +356,22 @@ class ServingDriver:
             # queued before batch i's detections are fetched, batch i's post-process runs beside it (uda_run_async)
             self._last_n = n
             t = self.run_async(mode)
-            while True:
-                nxt = next(it, None)
-                if nxt is not None:
-                    n_next = self._feed(nxt, prefetch=True)
-                    self._ck(self._lib.uda_swap_prefetched(self._h), "uda_swap_prefetched")
-                    self._last_n = n_next
-                    t_next = self.run_async(mode)
-                yield self.collect(t)
-                if nxt is None:
-                    return
-                t = t_next
+            try:
+                while True:
+                    nxt = next(it, None)
+                    if nxt is not None:
+                        n_next = self._feed(nxt, prefetch=True)
+                        self._ck(self._lib.uda_swap_prefetched(self._h), "uda_swap_prefetched")
+                        self._last_n = n_next
+                        t_next = self.run_async(mode)
+                    yield self.collect(t)
+                    if nxt is None:
+                        return
+                    t = t_next
+            finally:
+                # the consumer dropped the generator, or a collect / a feed raised: a run may still be queued - abandon it, so
+                # that the handle serves synchronously again (every such entry point refuses beside a run in flight)
+                self.drain()
         while True:
             self._next_seed()
             self._run_id += 1

@@ -564,6 +564,7 @@ class Plan:
             xr, mode = self._resample(feats[-1], th, tw, "resample_p%d" % lvl, "resample_p%d" % lvl)
             if mode == capi.RS_NONE:        # a 1x1 map cannot shrink further: the level repeats (keras :339-342); or pooled + 1x1 already
                 feats.append(xr)
+                self.buffer_names["p%d_in" % lvl] = xr
                 continue
             out = self._buf(th, tw, F, self.bufs[xr].per_sample, name="p%d_in" % lvl)
             feats.append(self._op(capi.OP_POOL, [xr], out, resample=[capi.RS_MAXPOOL, 0, 0], fuse_w=[1.0, 0, 0]))
