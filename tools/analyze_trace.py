@@ -15,13 +15,16 @@ ap.add_argument("--chunk", type=int, default=16)
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--samples", type=int, default=10)
 ap.add_argument("--variant", default="full")
+ap.add_argument("--model", default="efficientdet-d0")
+ap.add_argument("--image-size", default="1280x768")
+ap.add_argument("--classes", type=int, default=7)
 ap.add_argument("--top", type=int, default=40)
 ap.add_argument("--fetch", default="", help="counter_collection.csv of a --pmc FETCH_SIZE run of the same command")
 ap.add_argument("--write", default="", help="counter_collection.csv of a --pmc WRITE_SIZE run")
 a = ap.parse_args()
 
-cfg = hparams_config.get_efficientdet_config("efficientdet-d0")
-over = dict(image_size="1280x768", num_classes=7, mc_dropout=True, mc_dropoutsamp=a.samples, loss_attenuation=True,
+cfg = hparams_config.get_efficientdet_config(a.model)
+over = dict(image_size=a.image_size, num_classes=a.classes, mc_dropout=True, mc_dropoutsamp=a.samples, loss_attenuation=True,
             enable_softmax=True)
 over.update(dict(mc_dropoutrate=0.05) if a.variant == "full" else dict(mc_classheadrate=0.05, mc_boxheadrate=0.05))
 cfg.override(over)

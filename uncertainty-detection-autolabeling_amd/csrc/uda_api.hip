@@ -1852,6 +1852,12 @@ static int replay_run(uda_ctx* c, const uda_ctx::RunRec& r) {
   c->pfx_pending.clear();
   const bool pfx_off = c->pfx_off;
   c->pfx_off = true;               // full candidate set: nothing is left pending for the host behind the replay
+  // The overflowed pass left infinities / NaNs in the arena.  Some kernels read a few floats past the end of their input
+  // (the k-padding of the last pixel's matrix fragment, a dead lane's clamped window) and multiply them by zero weights:
+  // harmless on the finite leftovers of ordinary runs, NaN on these - and one NaN pixel reaches the whole image through
+  // the squeeze-excite mean.  The arenas are cleared before the run is served again (a few ms, once per demotion).
+  for (int l = 0; l < c->n_lanes; ++l)
+    if (c->lane_arena[l]) HIPC(c, hipMemsetAsync(c->lane_arena[l], 0, (size_t)c->model.arena_floats * sizeof(float), c->stream));
   int rc = run_network(c, 0, false, nullptr);
   if (!rc && r.do_post) rc = run_post(c, r.n, r.pm);
   c->pfx_off = pfx_off;
