@@ -117,13 +117,77 @@ def test_oracle_spot_check_one_image_full_resolution(full_run):
     masks = R.make_masks(E.dropout_sites(p), 9, 1, 2)
     rcls, rbox = E.forward(w, p, x, masks)
     from common import check_heads
-    check_heads(cls, rcls)          # max-norm 2e-4 per level AND relative RMS 1e-4 per channel group (deltas | sigmas)
-    check_heads(box, rbox)
+    from uda_amd import plan as plan_mod
+    # float32-class schemes (the default: two fp16 pieces; three bf16 pieces; exact f32): the bars the 192 x 128 test
+    # holds them to (test_gpu_round3: 2e-5 x max / 1e-5 relative RMS per channel group), at FULL size against the float32
+    # CPU oracle - measured 2.4e-7 relative RMS.  Two bf16 pieces (UDA_PW_SCHEME=bf16x2) is the narrow scheme: 2e-4 / 1e-4.
+    tight = plan_mod.pw_scheme() != "bf16x2"
+    check_heads(cls, rcls, tol=2e-5 if tight else 2e-4, tol_rms=5e-6 if tight else 1e-4)
+    check_heads(box, rbox, tol=2e-5 if tight else 2e-4, tol_rms=5e-6 if tight else 1e-4)
     want = P.postprocess_global(p, rcls, rbox, scales)
     got = d.postprocess(rcls, rbox, scales)
     for g, r in zip(got, want):
         np.testing.assert_array_equal(g, r)
     d.close()
+
+
+def test_full_size_serve_equals_the_oracle_chain_end_to_end(capsys):
+    """serve() as a whole - uint8 image, network x T, aggregate, decode, soft-NMS - against the oracle chain
+    post_ref.postprocess_global(effdet_ref.forward(preprocess_ref(...))) on ONE image at 1280 x 768 (the reference runs batch 1,
+    validate_model.py:476-522), T = 2, with spread scores (class-predict kernel x 20: a trained head's score range instead of
+    184 140 near-ties).  Soft-NMS keeps one of several overlapping anchors, so the statement is margin-aware like the
+    scheme-vs-scheme test below: every oracle detection whose selection margin (gap to the best overlapping runner-up on
+    fully updated scores) exceeds twice the measured perturbation of those scores - its own and every earlier one - must
+    come back as the SAME anchor with class equal and score / box / both sigmas within 1e-4; a detection that differs must
+    be explained by such a margin."""
+    from oracle import effdet_ref as E, philox_ref as R, post_ref as P, preprocess_ref as PP
+    from uda_amd import plan as plan_mod
+    p = make_params(**dict(FULL, mc_dropoutsamp=2))
+    w = make_weights(p, seed=0, cls_spread=20.0)
+    imgs = make_images(1, 768, 1280, seed=7)
+    d = _driver(p, w, 1)
+    d.set_dropout_seed(9)
+    det = d.serve(imgs)
+    cand = d.candidates(1)                       # boxes [1,K,4], scores, classes, u_cls, u_al, u_ep of the device run
+    d.close()
+    x, scales = PP.preprocess(imgs, (768, 1280), p["mean_rgb"], p["stddev_rgb"])
+    masks = R.make_masks(E.dropout_sites(p), 9, 1, 2)
+    rcls, rbox = E.forward(w, p, x, masks)
+    ref = P.pre_nms(p, rcls, rbox)
+    want = P.postprocess_global(p, rcls, rbox, scales)
+    sigma2, iou_thr, score_thr = P.nms_params(p)
+    M = p["nms_configs"]["max_output_size"]
+    keep_ref = P.nms_v5(ref["boxes"][0], ref["scores"][0], M, iou_thr, score_thr, sigma2, True)[0]
+    keep_dev = P.nms_v5(cand[0][0], cand[1][0], M, iou_thr, score_thr, sigma2, True)[0]      # (the device's own keep set, re-derived from its candidates)
+    tol = 1e-4 if plan_mod.pw_scheme() != "bf16x2" else 1e-3
+    # candidates: every one of the 184 140 within the tolerance
+    assert np.array_equal(cand[2][0], ref["classes"][0]) or (cand[2][0] != ref["classes"][0]).mean() < 1e-4
+    np.testing.assert_allclose(cand[1][0], ref["scores"][0], rtol=tol, atol=1e-7)
+    top = 40
+    sel = keep_ref[:top]
+    margin, pert, runner = _selection_margins(ref["boxes"][0], ref["scores"][0], cand[0][0], cand[1][0], sel, -0.5 / sigma2)
+    decided = margin > 2.0 * pert
+    rows_dev = {int(a): r for r, a in enumerate(keep_dev)}
+    same = n_checked = 0
+    for k in range(top):
+        a = int(sel[k])
+        if a in rows_dev:
+            same += 1
+        if not decided[:k + 1].all():
+            continue                             # this or an earlier selection was within reach of the perturbation
+        assert a in rows_dev and rows_dev[a] == k, ("a decided detection moved", k, a, margin[:k + 1], pert[:k + 1])
+        n_checked += 1
+        g_b, r_b = det[0][0, k], want[0][0, k]
+        assert det[2][0, k, 0] == want[2][0, k, 0]
+        np.testing.assert_allclose(det[1][0, k], want[1][0, k], rtol=tol, atol=0)
+        scale = max(r_b[2] - r_b[0], r_b[3] - r_b[1], 1.0)
+        assert np.abs(g_b[:4] - r_b[:4]).max() <= tol * scale, (k, g_b, r_b)
+        assert (np.abs(g_b[4:] - r_b[4:]) <= tol * np.maximum(r_b[4:], 1e-2 * scale)).all(), (k, g_b, r_b)
+    with capsys.disabled():
+        print("\n[full-size end-to-end vs oracle] top %d oracle detections: %d same anchors, %d decided by margins > 2 x perturbation "
+              "(all within %.0e); margins median %.2e, perturbation median %.2e" % (top, same, n_checked, tol, float(np.median(margin)), float(np.median(pert))))
+    assert int(keep_dev[0]) == int(sel[0]) and n_checked >= 10 and same >= 30
+    assert det[3][0] == want[3][0]
 
 
 PRECISION_WORKER = r"""

@@ -453,9 +453,12 @@ static void sepf_stamp_dump() {
 #define SEPF_STAMP(i) do { } while (0)
 #endif
 
-// PC = channels per pass: 16 (three blocks per CU) | 32 (two)
+// PC = channels per pass: 16 (three blocks per CU) | 32 (two).  Three and four column tiles (88 / 112 / 128 output channels:
+// D1 ... D3) hold 96 / 128 accumulator registers per lane: at the 168 registers of three blocks per CU the compiler spilled
+// 50-150 of them and the scratch traffic was 3.4-4.5x the kernel's algorithmic bytes (profiles/r05_d2_per_op.txt, round 5:
+// the D2 BiFPN nodes at 1.2 TB/s algorithmic with 5.4 TB/s on the counters) - those shapes take two blocks per CU.
 template <int NT, int PARTS, bool FIN, int PC>
-__global__ __launch_bounds__(256, PC == 16 ? 3 : 2) void sepf_kernel(SepArgs a, FuseArgs f, int sig, int rows) {
+__global__ __launch_bounds__(256, (PC == 16 && NT <= 2) ? 3 : 2) void sepf_kernel(SepArgs a, FuseArgs f, int sig, int rows) {
   extern __shared__ __attribute__((aligned(16))) unsigned char slds[];
   constexpr int NPC = split_np(PARTS);
   constexpr int SF_PC = PC, SF_PITCH = PC + 4;
@@ -522,11 +525,14 @@ __global__ __launch_bounds__(256, PC == 16 ? 3 : 2) void sepf_kernel(SepArgs a, 
     if constexpr (!FIN) {
       sepf_stage<SF_SIG_PLAIN, PC == 16 ? 6 : 11, PC>(a, f, T, inb, b, oy0, ox0, c0, pc4, tid);
     } else if (sig == SF_SIG_NU) {
-      sepf_stage<SF_SIG_NU, PC == 16 ? 6 : 11, PC>(a, f, T, inb, b, oy0, ox0, c0, pc4, tid);
+      // (identity + nearest-up nodes run 16-channel passes, sepf_pc: the 32-channel instance of this branch only exists for
+      // UDA_SEPF_PC=32 A/B runs and must not set the register count of the kernel the pooled nodes use - 11 elements of two
+      // inputs in flight were 88 registers, the pooled nodes' kernel spilled 50-115 of them)
+      sepf_stage<SF_SIG_NU, PC == 16 ? 6 : 2, PC>(a, f, T, inb, b, oy0, ox0, c0, pc4, tid);
     } else if (sig == SF_SIG_NNP) {
-      sepf_stage<SF_SIG_NNP, PC == 16 ? 1 : 3, PC>(a, f, T, inb, b, oy0, ox0, c0, pc4, tid);
+      sepf_stage<SF_SIG_NNP, (PC == 16 || NT > 2) ? 1 : 3, PC>(a, f, T, inb, b, oy0, ox0, c0, pc4, tid);      // (11 loads per element: one element in flight beside 96+ accumulators)
     } else if (sig == SF_SIG_NP) {
-      sepf_stage<SF_SIG_NP, PC == 16 ? 1 : 3, PC>(a, f, T, inb, b, oy0, ox0, c0, pc4, tid);
+      sepf_stage<SF_SIG_NP, (PC == 16 || NT > 2) ? 1 : 3, PC>(a, f, T, inb, b, oy0, ox0, c0, pc4, tid);
     } else {
       for (int e = tid; e < SF_NPX * pc4; e += 256) {
         const int px = e / pc4, q = e - px * pc4;
