@@ -88,7 +88,11 @@ typedef struct uda_op {
   int32_t resample[UDA_MAX_FUSE_INPUTS]; /* FUSE: uda_resample per input */
   float fuse_w[UDA_MAX_FUSE_INPUTS];     /* FUSE: relu(w_i) / (sum relu(w) + 1e-4) */
   int32_t n_in;
-  int32_t drop_site2;              /* MBX: dropout site after the depthwise stage (drop_site = after the expand stage) */
+  int32_t drop_site2;              /* MBX: dropout site after the depthwise stage (drop_site = after the expand stage).
+                                      SEP (plain, not fuse_in): a DEFERRED site of the producing op - keep-scales [sample row][C] of
+                                      this op's INPUT channels, which the producer (a per-image tensor shared by the T samples) did not
+                                      apply: a per-channel factor commutes with the depthwise conv, so the op computes the depthwise
+                                      result once per image and serves the T samples from it.  -1 = none */
   int64_t w2_off;                  /* MBX: depthwise kernel [k*k][Cmid]; SEP: depthwise kernel [9][C] */
   int64_t bn2_scale_off, bn2_shift_off; /* MBX: BN after the depthwise stage */
   int32_t launch_group;            /* SEP: n > 1 on the first of n consecutive, mutually independent ops of one shape class

@@ -136,7 +136,18 @@ def test_sample_axis_propagation():
     assert not head.bufs[hb["blocks_15/out"]].per_sample and not head.bufs[hb["cell2/fnode7/out"]].per_sample
     assert "class-0-3/dw" not in hb                                # the head's separable convs are single fused ops
     assert any(o["kind"] == capi.OP_SEP and head.bufs[o["out"]].name == "class-0-3" for o in head.ops)
-    assert head.bufs[hb["class-0-3"]].per_sample and head.bufs[hb["box-predict-7"]].per_sample
+    # the first head layer reads a per-image tensor: its dropout site is deferred into the layer behind it (round 5) - its own
+    # output stays per image, the second layer applies the site to its input channels and opens the sample axis
+    deferred = head.fuse_sep and plan_mod.sep_tin_supported(64, 64)
+    assert head.bufs[hb["class-0-3"]].per_sample == (not deferred) and head.bufs[hb["box-predict-7"]].per_sample
+    l0 = [o for o in head.ops if head.bufs[o["out"]].name == "class-0-3"][0]
+    l1 = [o for o in head.ops if head.bufs[o["out"]].name == "class-1-3"][0]
+    assert head.bufs[hb["class-1-3"]].per_sample
+    if deferred:
+        assert l0["drop_site"] == -1 and l1["drop_site2"] == head.site_index["class-0-3"] and l1["drop_site"] == head.site_index["class-1-3"]
+    else:
+        assert l0["drop_site"] == head.site_index["class-0-3"] and l1["drop_site2"] == -1
+    assert all(o["drop_site2"] == -1 for o in full.ops if o["kind"] == capi.OP_SEP)       # full MC: the inputs are per sample already
     assert all(o["drop_site"] == -1 for o in head.ops if head.bufs[o["out"]].name.startswith("blocks_"))
     box_only, _ = _plan(BOX_ONLY_MC)
     assert not box_only.cls_stacked_dev and box_only.box_stacked_dev and not box_only.cls_stacked

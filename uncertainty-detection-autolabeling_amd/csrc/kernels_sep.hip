@@ -22,7 +22,13 @@ namespace uda {
 // fragment into its three pieces when it loads them - every wave owns its 32 pixel rows, so an element is still split once.
 constexpr int SEP_TH = 8, SEP_TW = 16;
 
-template <int NT, int PARTS, int OCC>     // NT = 32-column tiles of the 1x1 output handled per block (each wave: all of them)
+// TIN > 0 (round 5): the input is shared by the T = in_div samples of an image and carries a DEFERRED dropout site -
+// keep-scales mask_in[sample row][channel] that the producing op did not apply (plan.py: the first layer of a head under
+// head-only MC dropout).  A per-channel factor commutes with the depthwise conv, so the block computes the depthwise result
+// of its tile ONCE (TIN = units per thread held in registers: 1 up to 64 channels, 2 up to 128), then per sample: scale,
+// split, 1x1 on the matrix cores, epilogue (with this op's own site), store.  The producer's output stays one row per image
+// (1 / T of the bytes), this op reads 1 / T of its input and does the depthwise arithmetic once per image instead of T times.
+template <int NT, int PARTS, int OCC, int TIN = 0>     // NT = 32-column tiles of the 1x1 output handled per block (each wave: all of them)
 __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
   constexpr int BM = SEP_TH * SEP_TW;      // 128 pixels = 4 MFMA row tiles, one per wave
   // the problem of this block (uniform): one conv, or one of the pyramid levels of a head layer launched together
@@ -48,7 +54,7 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
     bx -= m.tile0[l];
     const SepLevel& L = m.lv[l];
     a.in = L.in; a.out = L.out; a.wd = L.wd; a.wsplit = L.wsplit;
-    a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift; a.mask = L.mask;
+    a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift; a.mask = L.mask; a.mask_in = L.mask_in;
     a.H = L.H; a.W = L.W; a.wunscale = L.wunscale;
   }
   extern __shared__ __attribute__((aligned(16))) unsigned char slds[];
@@ -63,7 +69,7 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
   uint4* Bs = (uint4*)(slds + (size_t)(F32A ? 1 : NPC) * BM * arow);   // [KS][NT][NPC][64 lanes] x 16 B
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int b_in = b / a.in_div;
+  const int b_in = TIN ? b : b / a.in_div;       // (TIN: the grid runs over images)
   const int tiles_x = (a.W + SEP_TW - 1) / SEP_TW;
   const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
   const int oy0 = ty * SEP_TH, ox0 = tx * SEP_TW;
@@ -94,7 +100,26 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
 
   // ---- depthwise 3x3: unit = (channel quad q, tile column x); 8 output rows with a 3-row register window
   const float* inb = a.in + (size_t)b_in * a.H * a.W * C;
-  for (int u = tid; u < SEP_TW * C4; u += 256) {
+  // split a depthwise value into its pieces -> A image row m = ry * 16 + x, channels 4q .. 4q + 3
+  auto put_a = [&](float4 acc, int m, int q) {
+    if constexpr (F32A) {
+      *(float4*)(As + (size_t)m * arow + q * 16) = acc;
+    } else {
+      float r0 = acc.x, r1 = acc.y, r2 = acc.z, r3 = acc.w;
+      split_track<PARTS>(amax, r0, r1);
+      split_track<PARTS>(amax, r2, r3);
+#pragma unroll
+      for (int p = 0; p < NPC; ++p) {
+        const unsigned u0 = pack_piece<PARTS>(r0, r1), u1 = pack_piece<PARTS>(r2, r3);
+        *(uint2*)(As + (size_t)(p * BM + m) * arow + q * 8) = make_uint2(u0, u1);
+        if (p + 1 < NPC) {
+          r0 -= piece_lo<PARTS>(u0); r1 -= piece_hi<PARTS>(u0);
+          r2 -= piece_lo<PARTS>(u1); r3 -= piece_hi<PARTS>(u1);
+        }
+      }
+    }
+  };
+  auto dw_unit = [&](int u, auto&& sink) {       // sink(ry, value): the 8 output rows of unit u, one at a time
     const int q = u % C4, x = u / C4;
     float4 wk[9];
 #pragma unroll
@@ -128,22 +153,38 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
           acc.z = fmaf(v.z, w.z, acc.z);
           acc.w = fmaf(v.w, w.w, acc.w);
         }
-      // split into bf16 pieces -> A image row m = ry * 16 + x, channels 4q .. 4q + 3
-      const int m = ry * SEP_TW + x;
-      if constexpr (F32A) {
-        *(float4*)(As + (size_t)m * arow + q * 16) = acc;
-        continue;
-      }
-      float r0 = acc.x, r1 = acc.y, r2 = acc.z, r3 = acc.w;
-      split_track<PARTS>(amax, r0, r1);
-      split_track<PARTS>(amax, r2, r3);
+      sink(ry, acc);
+    }
+  };
+  float4 dwv[TIN ? TIN : 1][SEP_TH];        // TIN: the depthwise result of this thread's units, kept for the T samples
+  if constexpr (TIN) {
 #pragma unroll
-      for (int p = 0; p < NPC; ++p) {
-        const unsigned u0 = pack_piece<PARTS>(r0, r1), u1 = pack_piece<PARTS>(r2, r3);
-        *(uint2*)(As + (size_t)(p * BM + m) * arow + q * 8) = make_uint2(u0, u1);
-        if (p + 1 < NPC) {
-          r0 -= piece_lo<PARTS>(u0); r1 -= piece_hi<PARTS>(u0);
-          r2 -= piece_lo<PARTS>(u1); r3 -= piece_hi<PARTS>(u1);
+    for (int ui = 0; ui < TIN; ++ui) {
+      const int u = tid + 256 * ui;
+      if (u < SEP_TW * C4) dw_unit(u, [&](int ry, float4 v) { dwv[ui][ry] = v; });
+    }
+  } else {
+    for (int u = tid; u < SEP_TW * C4; u += 256) {
+      const int q = u % C4, x = u / C4;
+      dw_unit(u, [&](int ry, float4 v) { put_a(v, ry * SEP_TW + x, q); });      // (split row by row: nothing stays live)
+    }
+  }
+  const int n_samp = TIN ? a.in_div : 1;
+  for (int ts = 0; ts < n_samp; ++ts) {
+  const int bo = TIN ? b * n_samp + ts : b;   // output sample row
+  if constexpr (TIN) {
+    // this sample's A image: the shared depthwise result times the deferred keep-scale of its channels
+#pragma unroll
+    for (int ui = 0; ui < TIN; ++ui) {
+      const int u = tid + 256 * ui;
+      if (u < SEP_TW * C4) {
+        const int q = u % C4, x = u / C4;
+        const float4 mi = *(const float4*)(a.mask_in + (size_t)bo * C + 4 * q);
+#pragma unroll
+        for (int ry = 0; ry < SEP_TH; ++ry) {
+          float4 v = dwv[ui][ry];
+          v.x *= mi.x; v.y *= mi.y; v.z *= mi.z; v.w *= mi.w;
+          put_a(v, ry * SEP_TW + x, q);
         }
       }
     }
@@ -156,7 +197,7 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
       for (int e = tid; e < NPC * BM; e += 256) *(uint4*)(As + (size_t)e * arow + (C >> 3) * 16) = make_uint4(0u, 0u, 0u, 0u);
     }
   }
-  split_report<PARTS>(amax, a.oor);
+  if (ts + 1 == n_samp) split_report<PARTS>(amax, a.oor);
   __syncthreads();
 
   // ---- 1x1 on the matrix cores: wave w owns pixel rows [32 w, 32 w + 32) and all NT column tiles
@@ -184,7 +225,7 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
       acc[n] = mfma_terms<PARTS>(af, bf, acc[n]);
     }
   }
-  __syncthreads();      // the staging tile below aliases the A / B images
+  __syncthreads();      // the staging tile below aliases the A image (TIN: the launcher checked that it ends before the B image)
 
   // tile row m -> output pixel
   auto pixel_of = [&](int m, size_t& pix) -> bool {
@@ -192,7 +233,7 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
     pix = (size_t)y * a.W + x;
     return y < a.H && x < a.W;
   };
-  const size_t out_base = (size_t)b * a.H * a.W;
+  const size_t out_base = (size_t)bo * a.H * a.W;
   const float un = a.wunscale;             // the packed weights carry a power-of-two factor 1 / un (fp16 pieces; else 1)
 
   if ((a.Cout & 3) != 0) {
@@ -211,7 +252,7 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
       const float bias = a.bias ? a.bias[col] : 0.f;
       const float sc = a.bn_scale ? a.bn_scale[col] : 1.f;
       const float sh = a.bn_scale ? a.bn_shift[col] : 0.f;
-      const float mk = a.mask ? a.mask[(size_t)b * a.Cout + col] : 1.f;
+      const float mk = a.mask ? a.mask[(size_t)bo * a.Cout + col] : 1.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = fmaf(fmaf(acc[n][r], un, bias), sc, sh);
@@ -240,7 +281,9 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
         if (pixel_of(wave * 32 + row, pix)) a.out[(out_base + pix) * a.Cout + n0 + cc] = st[i];
       }
     }
-    return;
+    if constexpr (!TIN) return;
+    __syncthreads();          // (the next sample's A image is written over the packed rows)
+    continue;
   }
 
   float* stg = (float*)slds + wave * 32 * PWB_STG;
@@ -269,7 +312,7 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
       sc = *(const float4*)(a.bn_scale + colc);
       sh = *(const float4*)(a.bn_shift + colc);
     }
-    if (a.mask) mk = *(const float4*)(a.mask + (size_t)b * a.Cout + colc);
+    if (a.mask) mk = *(const float4*)(a.mask + (size_t)bo * a.Cout + colc);
     float4 v[8];
 #pragma unroll
     for (int it = 0; it < 8; ++it) v[it] = *(const float4*)(stg + (it * 4 + rrow) * PWB_STG + 4 * c4);
@@ -295,6 +338,7 @@ __global__ __launch_bounds__(256, OCC) void sep_kernel(SepMulti m) {
     }
     __syncthreads();
   }
+  }       // samples
 }
 
 // ---------------------------------------------------------------- separable convolution on an LDS-staged input tile
@@ -731,6 +775,18 @@ void launch_sepf(const SepArgs& a, const FuseArgs* fused, int rows, hipStream_t 
 
 bool sep_supported(int C, int Cout) { return C % 8 == 0 && C >= 16 && C <= 128 && Cout >= 1; }
 
+// Deferred-input mode (sep_kernel TIN): the per-sample epilogue staging must end before the weight image (it may only alias the
+// A image, which is rebuilt per sample), all columns in one block, two to four column tiles.
+bool sep_tin_supported(int C, int Cout, int scheme) {
+  if (scheme == UDA_SPLIT_NONE || !sep_supported(C, Cout) || C < 64) return false;
+  const int KS = (C + 15) / 16, ntl = (Cout + 31) / 32, npc = uda_split_pieces(scheme);
+  if (ntl < 2 || ntl > 4) return false;
+  const size_t a_img = scheme == UDA_SPLIT_BF16X3 ? (size_t)128 * (KS * 64 + 16) : (size_t)npc * 128 * (KS * 32 + 16);
+  const size_t stg = (Cout & 3) ? (size_t)4 * 32 * ntl * 32 * 4 : (size_t)4 * 32 * PWB_STG * 4;
+  if (stg > a_img) return false;
+  return a_img + (size_t)KS * ntl * npc * 1024 <= 120 * 1024;      // (the launcher would split the columns over several blocks otherwise)
+}
+
 static int sep_tiles(int H, int W) { return ((W + SEP_TW - 1) / SEP_TW) * ((H + SEP_TH - 1) / SEP_TH); }
 
 template <int NT>
@@ -745,6 +801,9 @@ static void launch_sep_nt(const SepMulti& m, int rows, int gy, hipStream_t s) {
   SepMulti mm = m;
   mm.tiles = m.n_lv > 0 ? m.tile0[m.n_lv] : sep_tiles(a.H, a.W);
   static const bool remap = !(getenv("UDA_SEP_REMAP") && atoi(getenv("UDA_SEP_REMAP")) == 0);     // (0: plain block order, A/B)
+  // deferred-input mode: one block serves the in_div samples of an image - the grid runs over images
+  const int tin = a.mask_in ? (a.C <= 64 ? 1 : 2) : 0;
+  if (tin) rows /= a.in_div;
   mm.rows = remap ? rows : 0;
   const dim3 grid(mm.tiles * rows, gy);
   auto go = [&](auto kern) {
@@ -757,6 +816,22 @@ static void launch_sep_nt(const SepMulti& m, int rows, int gy, hipStream_t s) {
   };
   static int occ = -1;
   if (occ < 0) { const char* e = getenv("UDA_SEP_OCC"); occ = e ? atoi(e) : 3; }   // 3 blocks per CU: measured 14 % faster than 2
+  if (tin) {
+    // (head layers: C = F, Cout = F | 9 C | 36 / 72: two to four column tiles; 32 / 64 more registers than the plain kernel)
+    if constexpr (NT >= 2) {
+      if (tin == 1) {
+        // (two blocks per CU: the 32 registers of the kept depthwise result spill at the 168 of three)
+        if (a.wparts == UDA_SPLIT_BF16X3) go(sep_kernel<NT, 3, 2, 1>);
+        else if (a.wparts == UDA_SPLIT_F16X2) go(sep_kernel<NT, 4, 2, 1>);
+        else go(sep_kernel<NT, 2, 2, 1>);
+      } else {
+        if (a.wparts == UDA_SPLIT_BF16X3) go(sep_kernel<NT, 3, 2, 2>);
+        else if (a.wparts == UDA_SPLIT_F16X2) go(sep_kernel<NT, 4, 2, 2>);
+        else go(sep_kernel<NT, 2, 2, 2>);
+      }
+    }
+    return;
+  }
   if (a.wparts == UDA_SPLIT_BF16X3) { if (occ >= 3 && NT <= 2) go(sep_kernel<NT, 3, 3>); else go(sep_kernel<NT, 3, 2>); }
   else if (a.wparts == UDA_SPLIT_F16X2) { if (occ >= 3 && NT <= 2) go(sep_kernel<NT, 4, 3>); else go(sep_kernel<NT, 4, 2>); }
   else if (occ >= 3 && NT <= 2) go(sep_kernel<NT, 2, 3>);

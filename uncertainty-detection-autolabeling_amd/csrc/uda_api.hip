@@ -495,7 +495,7 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
     if (!okbuf(o.out)) { fail(nullptr, "op %d: bad out buffer %d", i, o.out); uda_destroy(c); return 1; }
     for (int j = 0; j < o.n_in; ++j)
       if (!okbuf(o.in[j])) { fail(nullptr, "op %d: bad in[%d] buffer %d", i, j, o.in[j]); uda_destroy(c); return 1; }
-    if (o.drop_site >= m.n_drop_sites || (o.kind == UDA_OP_MBX && o.drop_site2 >= m.n_drop_sites)) {
+    if (o.drop_site >= m.n_drop_sites || ((o.kind == UDA_OP_MBX || o.kind == UDA_OP_SEP) && o.drop_site2 >= m.n_drop_sites)) {
       fail(nullptr, "op %d: bad drop site %d", i, o.drop_site);
       uda_destroy(c);
       return 1;
@@ -524,6 +524,17 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
       fail(nullptr, "op %d: the fused MBConv front half is a swish kernel (act %d)", i, o.act);
       uda_destroy(c);
       return 1;
+    }
+    if (o.kind == UDA_OP_SEP && o.drop_site2 >= 0) {
+      // deferred dropout site of the producer (plan.py: first head layer under head-only MC): keep-scales of the INPUT channels
+      const uda_buf_desc_t& ib = bufs[o.in[0]];
+      const uda_buf_desc_t& ob = bufs[o.out];
+      if (o.fuse_in || ib.per_sample || !ob.per_sample || c->sites[o.drop_site2].channels != ib.C) {
+        fail(nullptr, "op %d: a deferred input dropout site needs a plain separable conv with a per-image input of %d channels and a "
+                      "per-sample output", i, c->sites[o.drop_site2].channels);
+        uda_destroy(c);
+        return 1;
+      }
     }
     if (o.fuse_in && o.kind != UDA_OP_SEP) {
       fail(nullptr, "op %d: fuse_in is a separable-conv field (kind %d)", i, o.kind);
@@ -1276,9 +1287,12 @@ static int run_op(uda_ctx* c, const ChunkView& v, int oi) {
       a.bn_scale = v.wt(o.bn_scale_off);
       a.bn_shift = v.wt(o.bn_shift_off);
       a.mask = v.mask(o.drop_site);
+      a.mask_in = (!o.fuse_in && o.drop_site2 >= 0) ? v.mask(o.drop_site2) : nullptr;
       a.H = ob.H; a.W = ob.W; a.C = ib.C; a.Cout = ob.C;
       a.in_div = v.div(ib, ob);
       a.act = o.act;
+      if (a.mask_in && !sep_tin_supported(a.C, a.Cout, a.wparts))
+        return fail(c, "op %d: separable conv %d -> %d has no deferred-input mode (planner: plan.sep_tin_supported)", oi, a.C, a.Cout);
       if (o.fuse_in) {
         // the node's BiFPN fusion is this conv's input, computed on the fly (act_type, or none under conv_bn_act_pattern:
         // efficientdet_keras.py:229-236)
@@ -1362,6 +1376,8 @@ static int run_sep_group(uda_ctx* c, const ChunkView& v, int oi, int n) {
     lv[j].bn_scale = v.wt(o.bn_scale_off);
     lv[j].bn_shift = v.wt(o.bn_shift_off);
     lv[j].mask = v.mask(o.drop_site);
+    lv[j].mask_in = o.drop_site2 >= 0 ? v.mask(o.drop_site2) : nullptr;
+    if ((o.drop_site2 >= 0) != (o0.drop_site2 >= 0)) return -1;
     lv[j].H = ob.H; lv[j].W = ob.W;
     lv[j].wunscale = c->wunscale[oi + j];
     if (c->wscheme[oi + j] != c->wscheme[oi]) return -1;
@@ -1389,6 +1405,9 @@ static int run_sep_group(uda_ctx* c, const ChunkView& v, int oi, int n) {
   a.C = ib0.C; a.Cout = ob0.C;
   a.in_div = v.div(ib0, ob0);
   a.act = o0.act;
+  a.mask_in = o0.drop_site2 >= 0 ? v.mask(o0.drop_site2) : nullptr;     // (non-null = the deferred-input mode; the levels carry their own)
+  if (a.mask_in && !sep_tin_supported(a.C, a.Cout, c->wscheme[oi]))
+    return fail(c, "ops %d..: separable conv %d -> %d has no deferred-input mode (planner: plan.sep_tin_supported)", oi, a.C, a.Cout);
   a.wparts = c->wscheme[oi];
   a.wunscale = c->wunscale[oi];
   a.oor = c->oor_cur + oi;            // (one word for the layer's launch: its levels share the 1x1 kernel and are re-packed together)
@@ -1850,8 +1869,8 @@ static int replay_run(uda_ctx* c, const uda_ctx::RunRec& r) {
   c->have_u8 = r.have_u8; c->cur = r.cur; c->n_images = r.n; c->seed = r.seed; c->image_offset = r.image_offset;
   c->masks_injected = r.masks_injected;
   c->pfx_pending.clear();
-  const bool pfx_off = c->pfx_off;
-  c->pfx_off = true;               // full candidate set: nothing is left pending for the host behind the replay
+  const int pfx_skip = c->pfx_skip;
+  c->pfx_skip = 1 << 20;           // no score-prefix NMS in the replay: nothing is left pending for the host behind it
   // The overflowed pass left infinities / NaNs in the arena.  Some kernels read a few floats past the end of their input
   // (the k-padding of the last pixel's matrix fragment, a dead lane's clamped window) and multiply them by zero weights:
   // harmless on the finite leftovers of ordinary runs, NaN on these - and one NaN pixel reaches the whole image through
@@ -1860,7 +1879,7 @@ static int replay_run(uda_ctx* c, const uda_ctx::RunRec& r) {
     if (c->lane_arena[l]) HIPC(c, hipMemsetAsync(c->lane_arena[l], 0, (size_t)c->model.arena_floats * sizeof(float), c->stream));
   int rc = run_network(c, 0, false, nullptr);
   if (!rc && r.do_post) rc = run_post(c, r.n, r.pm);
-  c->pfx_off = pfx_off;
+  c->pfx_skip = pfx_skip;
   if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, "replay_run: the stream failed");
   c->have_u8 = have_u8; c->cur = cur; c->n_images = n; c->seed = seed; c->image_offset = off; c->masks_injected = inj;
   return rc;

@@ -128,6 +128,8 @@ struct SepArgs {          // fused depthwise 3x3 (stride 1, SAME) + 1x1 (kernels
   const float* bn_scale;  // [Cout] or null
   const float* bn_shift;
   const float* mask;      // [rows, Cout] dropout keep-scale or null
+  const float* mask_in;   // [rows, C] DEFERRED keep-scale of the input channels (the producer left its dropout site to this op:
+                          // input shared by the in_div samples of an image; sep_kernel's TIN mode) or null
   int H, W, C, Cout;
   int in_div;
   int act;
@@ -135,14 +137,16 @@ struct SepArgs {          // fused depthwise 3x3 (stride 1, SAME) + 1x1 (kernels
   float wunscale;         // see PwArgs
   unsigned* oor;
 };
+// rows = sample rows of the output; with mask_in the grid runs over rows / in_div images and each block serves the in_div samples
 void launch_sep(const SepArgs& a, int rows, hipStream_t s);
+bool sep_tin_supported(int C, int Cout, int scheme);      // the deferred-input mode exists for this shape (plan.py mirrors it)
 // Several independent separable convs of ONE shape class (same C, Cout, activation, sample-axis relation, row count) in one
 // launch: the five pyramid levels of a head layer.  The grid covers the tiles of all problems; a block finds its problem
 // from the tile prefix sums.  Everything that differs between the problems lives in SepLevel.
 constexpr int UDA_SEP_MAX_LV = 8;
 struct SepLevel {
   const float* in; float* out; const float* wd; const void* wsplit;
-  const float* bias; const float* bn_scale; const float* bn_shift; const float* mask;
+  const float* bias; const float* bn_scale; const float* bn_shift; const float* mask; const float* mask_in;
   int H, W;
   float wunscale;
 };

@@ -132,6 +132,24 @@ def sepf_supported(C, Cout):
     return C % 8 == 0 and 16 <= C <= 128 and Cout % 4 == 0 and 4 <= Cout <= 128 and lds <= 80 * 1024
 
 
+def sep_tin_supported(C, Cout):
+    """A plain separable conv can take a DEFERRED dropout site of its producer (mirror of sep_tin_supported in
+    csrc/kernels_sep.hip): 64 .. 128 input channels, two to four 32-column tiles in one block, the per-sample epilogue staging
+    inside the A image."""
+    import os
+    sch = pw_scheme()
+    if sch == "f32" or not int(os.environ.get("UDA_DEFER_HEAD", "1")):
+        return False
+    if C % 8 or not 64 <= C <= 128 or Cout < 1:
+        return False
+    ks, ntl, npc = -(-C // 16), -(-Cout // 32), (3 if sch == "bf16x3" else 2)
+    if not 2 <= ntl <= 4:
+        return False
+    a_img = 128 * (ks * 64 + 16) if sch == "bf16x3" else npc * 128 * (ks * 32 + 16)
+    stg = 4 * 32 * ntl * 32 * 4 if Cout % 4 else 4 * 32 * 68 * 4
+    return stg <= a_img and a_img + ks * ntl * npc * 1024 <= 120 * 1024
+
+
 def same_out(n, s):
     return -(-n // s)
 
@@ -389,7 +407,7 @@ class Plan:
         return out, kw.get("se_partial", -1)
 
     def _sepconv(self, x, cout, dw_kernel, pw_kernel, name, bias=None, bn=None, act=capi.ACT_NONE, site=-1,
-                 out_kind=0, level=0, fusion=None):
+                 out_kind=0, level=0, fusion=None, in_site=-1):
         """SeparableConv2D = depthwise 3x3 (no bias / BN / act) -> 1x1 + bias (+BN)(+act)(+dropout).  One fused op
         when the kernel supports the channel count, else the depthwise / pointwise pair.
         fusion = dict(ins, resample, fuse_w, H, W): the conv's input is the BiFPN fusion of `ins` (x is None), computed by
@@ -408,13 +426,14 @@ class Plan:
                 kw["bn_scale_off"], kw["bn_shift_off"] = self._bn(bn)
             return self._op(capi.OP_SEP, list(fusion["ins"]), out, **kw)
         xb = self.bufs[x]
+        assert in_site < 0 or (self.fuse_sep and sep_tin_supported(xb.C, cout) and not xb.per_sample), "deferred site without a taker"
         if not (self.fuse_sep and xb.C % 8 == 0 and 16 <= xb.C <= 128):
             d, _ = self._dw(x, 3, 1, dw_kernel, name + "/dw")
             return self._pw(d, cout, pw_kernel, name, bias=bias, bn=bn, act=act, site=site, out_kind=out_kind, level=level)
-        ps = xb.per_sample or site >= 0
+        ps = xb.per_sample or site >= 0 or in_site >= 0
         out = self._buf(xb.H, xb.W, cout, ps, out_kind, level, name)
         kw = dict(k=3, stride=1, w_off=self._pack(self.w[pw_kernel]), w2_off=self._pack(self.w[dw_kernel]), act=act,
-                  drop_site=site)
+                  drop_site=site, drop_site2=in_site)
         if bias is not None:
             kw["bias_off"] = self._pack(self.w[bias])
         if bn is not None:
@@ -435,7 +454,7 @@ class Plan:
 
         def shape_class(o):
             ib, ob = self.bufs[o["ins"][0]], self.bufs[o["out"]]
-            return (ib.C, ob.C, o["act"], ib.per_sample, ob.per_sample)
+            return (ib.C, ob.C, o["act"], ib.per_sample, ob.per_sample, o["drop_site2"] >= 0)
         if len({shape_class(o) for o in run}) != 1:
             return
         outs = {o["out"] for o in run}
@@ -630,22 +649,35 @@ class Plan:
         # efficientdet_keras.py:470-486; the levels are independent, so the order is free).  The ops of one layer are
         # consecutive and of one shape class: the executor runs them as ONE launch (launch_group), which spares the
         # small levels their launch latency and lets them run in the shadow of the large ones.
+        # Deferred head dropout (round 5): a head layer whose INPUT is still one row per image (head-only MC dropout: the whole
+        # backbone + BiFPN is per image) does not apply its dropout site - its output stays per image, 1 / T of the bytes -
+        # and hands the site to the layer that reads it: the keep-scale is per (sample, channel), a per-channel factor
+        # commutes with that layer's depthwise conv, so its kernel computes the depthwise result once per image and serves the
+        # T samples from it (drop_site2 of a SEP op; sep_kernel's TIN mode).  Same arithmetic up to the position of one multiply.
         for net, tag, outc, kind in (("class_net", "class", cls_ch, 2), ("box_net", "box", box_ch, 3)):
             xs = list(feats)
-            for i in range(cfg["box_class_repeats"]):
+            pending = [-1] * len(feats)              # per level: the deferred site the next layer has to apply to its input
+            nrep = cfg["box_class_repeats"]
+            for i in range(nrep):
                 pre = "%s/%s-%d" % (net, tag, i)
                 first = len(self.ops)
+                next_cout = F if i + 1 < nrep else outc
                 for li in range(len(feats)):
+                    site = self._site("%s-%d-%d" % (tag, i, lo + li))
+                    defer = (site >= 0 and pending[li] < 0 and self.T > 1 and not self.bufs[xs[li]].per_sample
+                             and self.fuse_sep and sep_tin_supported(F, next_cout))
                     xs[li] = self._sepconv(xs[li], F, pre + "/depthwise_kernel", pre + "/pointwise_kernel",
                                            "%s-%d-%d" % (tag, i, lo + li), bias=pre + "/bias",
                                            bn="%s/%s-%d-bn-%d" % (net, tag, i, lo + li), act=self.act,
-                                           site=self._site("%s-%d-%d" % (tag, i, lo + li)))
+                                           site=-1 if defer else site, in_site=pending[li])
+                    pending[li] = site if defer else -1
                 self._mark_launch_group(first)
             pre = "%s/%s-predict" % (net, tag)
             first = len(self.ops)
             for li in range(len(feats)):
                 out = self._sepconv(xs[li], outc, pre + "/depthwise_kernel", pre + "/pointwise_kernel",
-                                    "%s-predict-%d" % (tag, lo + li), bias=pre + "/bias", out_kind=kind, level=li)
+                                    "%s-predict-%d" % (tag, lo + li), bias=pre + "/bias", out_kind=kind, level=li,
+                                    in_site=pending[li])
                 self.head_out[tag].append(out)
             self._mark_launch_group(first)
         # the head buffers must carry the sample axis exactly when the reference stacks them
