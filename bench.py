@@ -404,6 +404,7 @@ def main():
                     "op_kind": KIND_NAMES.get(dominant, str(dominant)),
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "hbm_achieved": round(achieved, 1), "hbm_peak": HBM_PEAK_GBS, "hbm_frac": round(achieved / HBM_PEAK_GBS, 4),
                     "avg_launch_ms": round(avg_ms, 4), "launches": int(dom_launches),
                     "algorithmic_bytes_per_launch": int(per_launch_bytes),
                     "tflops": round(cst["flops"] / cst["launches"] / (avg_ms * 1e-3) / 1e12, 2),
@@ -413,6 +414,30 @@ def main():
                                 "(profiles/r04_sq.txt, this scheme): VALU 75-88 % busy in blocks 1-10 at the 1.8-2.0 GHz the chip holds under them, "
                                 "two transcendentals per swish = 60 % of block 1's vector time, instruction counts at the floor of the algorithm "
                                 "(DESIGN.md 4.5, 4.6); plain streaming kernels reach 4.5-5.7 TB/s on this box (tools/micro/hbm_rates.hip)")
+            # What bounds the dominant family, from the committed counter profile of this command (profiles/roofline_inputs.json,
+            # written by tools/summarize_r05.py from the SQ / FETCH / WRITE passes): the fused MBConv front halves are bound by
+            # vector issue - `bound` = "valu", `achieved` / `frac` = share of the VALU issue cycles that are busy, re-scaled
+            # with THIS run's launch duration (the instruction count of a launch does not change) - and `traffic` = counter
+            # bytes per launch; the HBM view stays beside it (hbm_*).
+            ri = None
+            try:
+                ri = json.load(open(os.path.join(ROOT, "profiles", "roofline_inputs.json")))
+            except Exception:
+                pass
+            kn = KIND_NAMES.get(dominant, "")
+            if ri is not None:
+                tr = ri.get("traffic_bytes_per_launch", {}).get(kn)
+                if tr:
+                    roof["traffic"] = int(tr)
+                    roof["traffic_over_algorithmic"] = round(tr / per_launch_bytes, 3)
+                    roof["traffic_source"] = ri.get("source", "") + ": rocprofv3 --pmc FETCH_SIZE x2 (gfx950) + WRITE_SIZE, separate passes; not measured in this run"
+                fam = ri.get("families", {}).get(kn)
+                if kn == "mbx" and fam and fam.get("valu_busy"):
+                    busy = fam["valu_busy"] * fam["avg_launch_us"] / (avg_ms * 1e3)
+                    roof.update({"bound": "valu", "achieved": round(100.0 * busy, 1), "peak": 100.0, "unit": "% of VALU issue cycles",
+                                 "frac": round(busy, 4), "valu_clock_ghz": round(fam.get("clock_ghz") or 0.0, 2),
+                                 "valu_source": "4 x SQ_ACTIVE_INST_VALU / (32 x SQ_BUSY_CYCLES) over the family's launches in the committed "
+                                                "SQ pass, times committed / live launch duration"})
             # `traffic` (HBM bytes per launch from the PMC counters) cannot be collected inside this process: it comes from
             # separate rocprofv3 --pmc passes.  The figure of the last committed profile of this command is quoted beside it.
             tf = os.path.join(ROOT, "profiles", "traffic.json")
@@ -430,6 +455,26 @@ def main():
                         "note": "bookkeeping against SURVEY 8d's unfused layer-wise byte count, NOT an achieved HBM rate: the fused "
                                 "kernels move far less than that",
                         "gflop_per_unit": 16.97, "tflops": round(16.97 * value / 1e3, 2)}
+        step_block = None
+        try:
+            ri = json.load(open(os.path.join(ROOT, "profiles", "roofline_inputs.json")))
+            tb = ri.get("traffic_bytes_per_launch", {})
+            by = 0.0
+            for k_, cst_ in costs.items():
+                nm = KIND_NAMES.get(k_, "")
+                if nm in tb:
+                    by += tb[nm] * cst_["launches"]
+            pl_ = drv.plan
+            exp_b = 2.0 * sum(4.0 * a.batch * (pl_.T if pl_.bufs[o["out"]].per_sample else 1) * pl_.bufs[o["out"]].H * pl_.bufs[o["out"]].W * pl_.bufs[o["out"]].C
+                              for o in pl_.ops if o["kind"] == 7)
+            ms = elapsed / a.steps * 1e3
+            step_block = {"counter_bytes_per_step": int(by), "GBps": round(by / ms / 1e6, 1), "frac_of_hbm_peak": round(by / ms / 1e6 / HBM_PEAK_GBS, 3),
+                          "expanded_tensor_round_trip_bytes": int(exp_b),
+                          "note": "whole step on the committed FETCH / WRITE counters (bytes per launch and kind x this plan's launches) over THIS run's "
+                                  "ms_per_step; the round trip = the 6x-expanded depthwise outputs written by the fused MBConv kernels and read "
+                                  "back by the 1x1 projections (algorithmic bytes, both directions)"}
+        except Exception:
+            pass
         line = {
             "metric": "images*MC-samples/sec, EfficientDet-D0 MC-dropout serve (preprocess+net xT+decode+NMS)",
             "value": round(value, 2), "unit": "images*MC-samples/s", "n_gpus": world, "steps": a.steps,
@@ -460,6 +505,7 @@ def main():
             "nms_coop_not_launched": coop_nl,
             "ranks": ranks_info,
             "roofline": roof,
+            "step": step_block,
             "pipeline": pipeline,
         }
         if other_protocol is not None:      # both protocols at the top level too

@@ -134,7 +134,7 @@ def test_oracle_spot_check_one_image_full_resolution(full_run):
 def test_full_size_serve_equals_the_oracle_chain_end_to_end(capsys):
     """serve() as a whole - uint8 image, network x T, aggregate, decode, soft-NMS - against the oracle chain
     post_ref.postprocess_global(effdet_ref.forward(preprocess_ref(...))) on ONE image at 1280 x 768 (the reference runs batch 1,
-    validate_model.py:476-522), T = 2, with spread scores (class-predict kernel x 20: a trained head's score range instead of
+    validate_model.py:476-522), T = 2, with spread scores (class-predict kernel x 5: a score range instead of
     184 140 near-ties).  Soft-NMS keeps one of several overlapping anchors, so the statement is margin-aware like the
     scheme-vs-scheme test below: every oracle detection whose selection margin (gap to the best overlapping runner-up on
     fully updated scores) exceeds twice the measured perturbation of those scores - its own and every earlier one - must
@@ -143,7 +143,7 @@ def test_full_size_serve_equals_the_oracle_chain_end_to_end(capsys):
     from oracle import effdet_ref as E, philox_ref as R, post_ref as P, preprocess_ref as PP
     from uda_amd import plan as plan_mod
     p = make_params(**dict(FULL, mc_dropoutsamp=2))
-    w = make_weights(p, seed=0, cls_spread=20.0)
+    w = make_weights(p, seed=0, cls_spread=5.0)       # (x 20 saturates the best scores of a full-size map at 1 - a few ulps: ties again)
     imgs = make_images(1, 768, 1280, seed=7)
     d = _driver(p, w, 1)
     d.set_dropout_seed(9)
