@@ -80,6 +80,25 @@ def test_restore_rules_ema_missing_and_mismatch(tmp_path):
         CR.load_checkpoint(prefix, p, use_ema=True, skip_mismatch=False)
 
 
+def test_mis_shaped_ema_shadow_falls_back_to_the_plain_variable_under_skip_mismatch(tmp_path):
+    """restore_ckpt (utils_keras.py:213-235) assigns the plain variable first and only WARNS when the ExponentialMovingAverage
+    entry has the wrong shape: the variable keeps the checkpoint's plain value - not its random initial one."""
+    p = make_params()
+    w = W.init_weights(p, seed=4)
+    k = "efficientnet-b0/blocks_2/conv2d/kernel"
+    bundle = dict(w)
+    for name in list(w):
+        bundle[name + "/ExponentialMovingAverage"] = w[name] * 2
+    bundle[k + "/ExponentialMovingAverage"] = np.zeros((1, 1, 3, 5), np.float32)       # a shadow of the wrong shape
+    prefix = CR.save_checkpoint(str(tmp_path / "ckpt-5"), bundle, checksum=False)
+    got = CR.load_checkpoint(prefix, p, use_ema=True, skip_mismatch=True)
+    np.testing.assert_array_equal(got[k], w[k])                         # the PLAIN tensor of the checkpoint
+    other = "efficientnet-b0/blocks_3/conv2d/kernel"
+    np.testing.assert_array_equal(got[other], w[other] * 2)             # everything else: its shadow
+    with pytest.raises(ValueError):
+        CR.load_checkpoint(prefix, p, use_ema=True, skip_mismatch=False)
+
+
 def test_checkpoint_without_shadows_is_refused_when_ema_is_on(tmp_path, caplog):
     """With moving_average_decay > 0 the reference's restore map holds the plain AND the shadow name of every variable and
     raises `Not found ...` for a missing shadow (utils_keras.py:176-235): a checkpoint saved without EMA must not load as if it

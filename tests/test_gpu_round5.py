@@ -309,46 +309,3 @@ def test_checkpoint_like_statistics_serve_and_say_how_many_ops_were_repacked(tmp
     for k in sorted(k for k in got if k.startswith("head_")):
         g, r = got[k].astype(np.float64), ref[k].astype(np.float64)
         assert np.sqrt(np.mean((g - r) ** 2)) <= 2e-5 * np.sqrt(np.mean(r * r)) + 1e-7, k
-
-
-# ------------------------------------------------------------------ Infinity-Cache windows
-MALL_WORKER = r"""
-import sys
-sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
-import numpy as np
-from common import FULL_MC, make_images, make_params, make_weights
-from uda_amd.infer_lib import KerasDriver
-p = make_params(**FULL_MC)
-w = make_weights(p, seed=31, cls_spread=20.0)
-d = KerasDriver("_", False, p["name"], 3, False, p, weights=w, chunk_images=3)
-d.set_dropout_seed(23)
-det = d.serve(make_images(3, 128, 192, seed=32))
-cls, box = d.head_outputs(3)
-np.savez(sys.argv[1], *det, *cls, *box)
-d.close()
-print("saved")
-"""
-
-
-def test_infinity_cache_windows_are_bit_identical(tmp_path):
-    """UDA_MALL_MB=<budget>: the (fused MBConv -> SE -> projection) ops of a block run a window of sample rows at a time, so
-    that the expanded tensor is read back out of the Infinity Cache.  Same kernels on the same rows: heads and detections
-    equal the one-launch-per-op run bit for bit, for windows of one row, of a few rows and for a ragged last window."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = {}
-    for tag, env in (("off", {}), ("one_row", dict(UDA_MALL_MB="0.05", UDA_MALL_MIN_BLOCKS="1")),
-                     ("few_rows", dict(UDA_MALL_MB="1.5", UDA_MALL_MIN_BLOCKS="1"))):
-        e = dict(os.environ)
-        e.pop("UDA_MALL_MB", None)
-        e.update(env)
-        out = str(tmp_path / ("mall_%s.npz" % tag))
-        r = subprocess.run([sys.executable, "-c", MALL_WORKER % {"root": root}, out], cwd=root, env=e, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0 and "saved" in r.stdout, (tag, r.stdout[-1500:], r.stderr[-2500:])
-        outs[tag] = dict(np.load(out))
-    for tag in ("one_row", "few_rows"):
-        assert outs[tag].keys() == outs["off"].keys()
-        for k in outs["off"]:
-            np.testing.assert_array_equal(outs[tag][k], outs["off"][k], err_msg="%s %s" % (tag, k))

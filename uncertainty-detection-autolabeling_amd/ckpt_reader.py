@@ -300,6 +300,14 @@ def load_checkpoint(path, config, use_ema=True, skip_mismatch=False, verify_crc=
                 want = tuple(shp) if kind != "wsm" else ()
                 if got != want and not (kind == "wsm" and got in ((), (1,))):
                     problem = ValueError("Shape mismatch: %s, expected %s, but got %s" % (var, want, got))
+                    # restore_ckpt (utils_keras.py:213-235) assigns the plain variable first and only warns when the
+                    # ExponentialMovingAverage shadow has the wrong shape: the variable keeps the checkpoint's PLAIN value
+                    plain = names.get(var)
+                    if use_ema and skip_mismatch and plain is not None and plain != key:
+                        gotp = tuple(reader.entries[plain]["shape"])
+                        if gotp == want or (kind == "wsm" and gotp in ((), (1,))):
+                            logging.getLogger(__name__).warning("skip_mismatch: %s: the plain variable is restored", problem)
+                            key, problem = plain, None
             if problem is not None:
                 if not skip_mismatch:
                     raise problem

@@ -55,8 +55,6 @@ struct uda_ctx {
   std::vector<uint16_t*> wovr;     // per op: device copy of its re-packed weights (null: its slice of d_wsplit)
   std::vector<int64_t> wovr_par;   // per op: uint16 offset of the parameter block inside wovr (-1: none)
   int64_t range_demotions = 0;     // ops re-packed so far (uda_range_demotions)
-  // Infinity-Cache windows (UDA_MALL_MB): op i opens a group of mall_len[i] ops that run mall_rows[i] sample rows at a time
-  std::vector<int> mall_len, mall_rows;
   // What a run read, so that it can be served again: input slot / float image generation, seed, image offset, masks.
   struct RunRec {
     bool valid = false, do_post = false, have_u8 = false, masks_injected = false;
@@ -706,43 +704,6 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
   }
   CK(dalloc(&c->d_arena, (size_t)m.arena_floats));
   {
-    // (fused MBConv front half -> SE -> projection) of one block, window by window: the 6x-expanded tensor is written and read
-    // back inside the Infinity Cache instead of making an HBM round trip.  Only groups whose tensors all carry the sample
-    // axis, whose expanded tensor exceeds the budget for the whole chunk, and whose windows still fill the device.
-    c->mall_len.assign(n_ops, 0);
-    c->mall_rows.assign(n_ops, 0);
-    const char* e = getenv("UDA_MALL_MB");
-    const double budget = (e ? atof(e) : 0.0) * 1048576.0;
-    const char* eb = getenv("UDA_MALL_MIN_BLOCKS");
-    const int64_t min_blocks = eb ? atoll(eb) : 1024;
-    if (budget > 0 && T > 1) {
-      for (int i = 0; i + 2 < n_ops; ++i) {
-        const uda_op_t &o0 = ops[i], &o1 = ops[i + 1], &o2 = ops[i + 2];
-        if (o0.kind != UDA_OP_MBX || o1.kind != UDA_OP_SE || o2.kind != UDA_OP_PW || o0.se_scale >= 0) continue;
-        if (o2.in[0] != o0.out || o1.in[1] != o0.out || o2.se_scale != o1.out) continue;
-        bool all_ps = true;
-        for (const uda_op_t* o : {&o0, &o1, &o2}) {
-          for (int j = 0; j < o->n_in; ++j) all_ps = all_ps && bufs[o->in[j]].per_sample;
-          all_ps = all_ps && bufs[o->out].per_sample;
-          if (o->se_partial >= 0) all_ps = all_ps && bufs[o->se_partial].per_sample;
-          if (o->residual >= 0) all_ps = all_ps && bufs[o->residual].per_sample;
-          if (o->se_scale >= 0) all_ps = all_ps && bufs[o->se_scale].per_sample;
-        }
-        if (!all_ps) continue;
-        const uda_buf_desc_t& eb_ = bufs[o0.out];
-        const double row_bytes = (double)eb_.H * eb_.W * eb_.C * sizeof(float);
-        const int64_t rows_all = (int64_t)m.chunk_images * T;
-        if (row_bytes * rows_all <= budget) continue;            // the whole chunk fits anyway
-        int64_t win = (int64_t)(budget / row_bytes);
-        if (win < 1) win = 1;
-        const int64_t px_blocks = ((int64_t)eb_.H * eb_.W + 127) / 128;      // (projection: 128-pixel tiles)
-        if (win * px_blocks < min_blocks) continue;              // windows that small leave CUs idle
-        c->mall_len[i] = 3;
-        c->mall_rows[i] = (int)win;
-      }
-    }
-  }
-  {
     const char* e = getenv("UDA_LANES");
     c->n_lanes = e ? atoi(e) : 1;   // 2 overlaps consecutive chunks on two streams: +4 % throughput, but per-kernel timings then include the sharing
     if (c->n_lanes < 1) c->n_lanes = 1;
@@ -1079,28 +1040,23 @@ struct ChunkView {
   uda_ctx* c;
   int i0, nc;
   int lane = 0;
-  // A window of sample rows [r0, r0 + nr) of the chunk (nr < 0: all of it): the ops of a group whose tensors ALL carry the
-  // sample axis (run_network checks) can run window by window, so that what one op writes the next reads back while it
-  // still sits in the 256 MB Infinity Cache (UDA_MALL_MB).
-  int r0 = 0, nr = -1;
   hipStream_t stream() const { return c->lane_stream[lane]; }
-  int rows(const uda_buf_desc_t& b) const { return nr >= 0 ? nr : nc * (b.per_sample ? c->model.mc_samples : 1); }
+  int rows(const uda_buf_desc_t& b) const { return nc * (b.per_sample ? c->model.mc_samples : 1); }
   float* ptr(int id) const {
     const uda_buf_desc_t& b = c->bufs[id];
     const size_t per = (size_t)b.H * b.W * b.C;
     const int T = c->model.mc_samples;
-    const size_t w = nr >= 0 ? (size_t)r0 * per : 0;      // (window: per-sample buffers only)
     switch (b.kind) {
       case 1: return c->d_images + (size_t)i0 * per;
-      case 2: return c->d_cls[b.level] + (size_t)i0 * (b.per_sample ? T : 1) * per + w;
-      case 3: return c->d_box[b.level] + (size_t)i0 * (b.per_sample ? T : 1) * per + w;
-      default: return c->lane_arena[lane] + b.offset + w;
+      case 2: return c->d_cls[b.level] + (size_t)i0 * (b.per_sample ? T : 1) * per;
+      case 3: return c->d_box[b.level] + (size_t)i0 * (b.per_sample ? T : 1) * per;
+      default: return c->lane_arena[lane] + b.offset;
     }
   }
   const float* wt(int64_t off) const { return off < 0 ? nullptr : c->d_weights + off; }
   const float* mask(int site) const {
     if (site < 0) return nullptr;
-    return c->d_masks + c->site_off[site] + ((size_t)i0 * c->model.mc_samples + (nr >= 0 ? r0 : 0)) * c->sites[site].channels;
+    return c->d_masks + c->site_off[site] + (size_t)i0 * c->model.mc_samples * c->sites[site].channels;
   }
   int div(const uda_buf_desc_t& in, const uda_buf_desc_t& out) const {
     return (out.per_sample && !in.per_sample) ? c->model.mc_samples : 1;
@@ -1527,24 +1483,6 @@ static int run_network(uda_ctx* c, int post_mode = 0, bool chunk_post = false, h
       if (c->gate_ev && !gated && c->bufs[c->ops[oi].out].kind >= 2) {
         HIPC(c, hipStreamWaitEvent(v.stream(), c->gate_ev, 0));
         gated = true;
-      }
-      if (c->mall_len[oi] > 0) {
-        // an Infinity-Cache group: its ops window by window over the chunk's sample rows
-        const int len = c->mall_len[oi], win = c->mall_rows[oi];
-        const int rows_all = v.nc * T;
-        for (int r0 = 0; r0 < rows_all; r0 += win) {
-          ChunkView vw = v;
-          vw.r0 = r0;
-          vw.nr = rows_all - r0 < win ? rows_all - r0 : win;
-          for (int g = 0; g < len; ++g) {
-            const int rc = run_op(c, vw, oi + g);
-            if (rc) return rc;
-            const hipError_t le = hipGetLastError();
-            if (le != hipSuccess) return fail(c, "op %d (window at row %d): launch failed: %s", oi + g, r0, hipGetErrorString(le));
-          }
-        }
-        oi += len - 1;
-        continue;
       }
       const int grp = c->ops[oi].launch_group;
       static const bool sepf_all_ = getenv("UDA_SEPF_ALL") && atoi(getenv("UDA_SEPF_ALL"));     // A/B: per-level tile-kernel launches

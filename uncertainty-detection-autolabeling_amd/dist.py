@@ -115,12 +115,23 @@ def all_gather_detections_device(driver, n_local, counts, device, group=None, to
         layout = dict(box=det[0].shape[-1], cls=1 if det[2].ndim == 2 else det[2].shape[-1], logits=det[4].shape[-1] if len(det) > 4 else 0)
         cols = layout["box"] + 1 + layout["cls"] + layout["logits"] + 1
         t = torch.zeros((n_max, driver.M, cols), dtype=torch.float32, device=dev)
+    # Two receive tensors per shape, used in turn: with pipelined tickets (or to_host=False) the caller may still hold - and
+    # RCCL may still be filling - the previous call's tensor when the next gather is posted.
     key = (str(dev), world, n_max, driver.M, cols)
-    out = _GATHER_BUF.get(key)
-    if out is None:
-        out = _GATHER_BUF[key] = torch.empty((world, n_max, driver.M, cols), dtype=torch.float32, device=dev)
-    dist.all_gather_into_tensor(out, t, group=group)
+    pair = _GATHER_BUF.get(key)
+    if pair is None:
+        pair = _GATHER_BUF[key] = [[torch.empty((world, n_max, driver.M, cols), dtype=torch.float32, device=dev) for _ in range(2)], 0]
+    out = pair[0][pair[1]]
+    pair[1] ^= 1
+    work = dist.all_gather_into_tensor(out, t, group=group, async_op=True)
+    # the handle's packed-record buffer (`t` aliases it: one per handle) is rewritten by the next detections_device /
+    # collect_device: the collective must have READ it before this returns
+    work.wait()
     if not to_host:
+        # The handle packs its next records on a stream of its own, which nothing orders behind RCCL's: wait for the gather
+        # here (tens of microseconds) - the returned device tensor is complete and stays valid until the second next gather
+        # of this shape.
+        torch.cuda.current_stream(dev).synchronize()
         return out.reshape(world * n_max, driver.M, cols), layout
     host = out.cpu().numpy()             # the one download (synchronises the collective's stream)
     full = host.reshape((world * n_max, driver.M, cols)) if all(c == n_max for c in counts) else \

@@ -76,6 +76,37 @@ class ServingDriver:
         self.weights = weights
         if chunk_images is None:
             chunk_images = min(self._cap, int(self.params.get("uda_chunk_images", 16)))
+        # `uda_pw_scheme` in model_params (f16x2 | bf16x3 | bf16x2 | f32): the split scheme of THIS handle's 1x1 contractions.  The
+        # planner and uda_create both read UDA_PW_SCHEME when they run; the key sets it for exactly that long (a
+        # per-handle choice instead of a process-wide environment variable).
+        import os
+        want = self.params.get("uda_pw_scheme")
+        saved = (os.environ.get("UDA_PW_SCHEME"), os.environ.get("UDA_PW_TERMS"))
+        if want:
+            if want not in plan_mod.PW_SCHEMES:
+                raise ValueError("uda_pw_scheme=%r: expected one of %s" % (want, ", ".join(plan_mod.PW_SCHEMES)))
+            os.environ["UDA_PW_SCHEME"] = want
+            os.environ.pop("UDA_PW_TERMS", None)
+        try:
+            self.pw_scheme = plan_mod.pw_scheme()
+            self._create(weights, chunk_images, post_only, post_mode, device)
+        finally:
+            if want:
+                for k, v in zip(("UDA_PW_SCHEME", "UDA_PW_TERMS"), saved):
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+        self.device = int(device)
+        self.image_size = hparams_config.parse_image_size(self.params["image_size"])
+        self.T = self.plan.T
+        self.M = int(self.params["nms_configs"]["max_output_size"])
+        self.num_classes = int(self.params["num_classes"])
+        self._seed_counter = int(self.params.get("uda_dropout_seed", 0))
+        self._fixed_seed = None
+        self._run_id = 0                              # bumped by every call that rewrites the resident head outputs
+
+    def _create(self, weights, chunk_images, post_only, post_mode, device):
         self.plan = plan_mod.Plan(self.params, weights, chunk_images=chunk_images, max_images=self._cap, post_only=post_only)
         if self.plan.unknown_keys:
             # not one of hparams_config's keys and not a `uda_*` knob: nothing here reads it (plan.MODEL_PARAM_HANDLING)
@@ -90,14 +121,6 @@ class ServingDriver:
         if rc != 0:
             raise capi.UdaError("uda_create failed: %s" % self._lib.uda_last_error(None).decode())
         self._h = handle
-        self.device = int(device)
-        self.image_size = hparams_config.parse_image_size(self.params["image_size"])
-        self.T = self.plan.T
-        self.M = int(self.params["nms_configs"]["max_output_size"])
-        self.num_classes = int(self.params["num_classes"])
-        self._seed_counter = int(self.params.get("uda_dropout_seed", 0))
-        self._fixed_seed = None
-        self._run_id = 0                              # bumped by every call that rewrites the resident head outputs
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
