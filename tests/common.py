@@ -84,3 +84,4 @@ def check_heads(got, want, tol=2e-4, tol_rms=1e-4):
             rms = np.sqrt(np.mean(rr * rr))
             e = np.sqrt(np.mean((gg - rr) ** 2))
             assert e <= tol_rms * rms + 1e-7, "level %d channels %d:%d: relative rms error %g" % (lvl, lo, hi, e / max(rms, 1e-30))
+
