@@ -190,6 +190,11 @@ int uda_set_dropout_seed(uda_ctx_t* ctx, uint64_t seed);
 /* Index of the handle's first image inside the global batch (multi-GPU image shards): the Philox row
  * of image n, sample t is (offset + n) * T + t, so a sharded batch draws the masks of the unsharded one. */
 int uda_set_dropout_image_offset(uda_ctx_t* ctx, int64_t first_image);
+/* MC samples sharded over ranks (north_star: "images (and optionally MC samples) shard"): the handle's T local samples are
+ * samples t_first + j * t_stride (j < T) of a global axis of t_total samples - the Philox row of image n, local sample j is
+ * (offset + n) * t_total + t_first + j * t_stride, so the ranks together draw exactly the masks of one handle that runs all
+ * t_total samples.  t_total = 0 restores "this handle runs every sample".  (dist.serve_sample_sharded) */
+int uda_set_dropout_sample_shard(uda_ctx_t* ctx, int32_t t_first, int32_t t_stride, int32_t t_total);
 int uda_set_dropout_masks(uda_ctx_t* ctx, const float* masks, int64_t n_floats);
 int uda_get_dropout_masks(uda_ctx_t* ctx, float* masks, int64_t n_floats);
 

@@ -146,3 +146,16 @@ def test_ensemble_reshard_world2():
     _run_reshard(5, 3)      # rank 0 owns members 0 and 2, rank 1 member 1; shards of 3 and 2 images
     _run_reshard(4, 1)      # rank 1 owns no member
     _run_reshard(1, 2)      # rank 1 owns no image
+
+
+def test_mc_samples_striped_over_ranks_reshard_like_ensemble_members():
+    """MC-sample sharding (north_star "optionally MC samples"; dist.SampleShardedDriver): rank r runs samples t = r (mod world)
+    of every image, a sample is a "member" of the ensemble exchange - T = 10 over two ranks for ONE image (the reference's
+    batch-1 protocol: rank 1 owns no image and still contributes five samples), T = 5 over two ranks (3 + 2 samples), and a
+    head that carries no sample axis (zero-width payload)."""
+    from uda_amd import dist as udist
+    assert udist.local_samples(10, 1, 4) == [1, 5, 9] and udist.local_samples(5, 0, 2) == [0, 2, 4]
+    assert all(udist.sample_owner(t, 3) == udist.member_owner(t, 3) for t in range(9))
+    _run_reshard(1, 10)
+    _run_reshard(3, 5)
+    _run_reshard(2, 4, world=3)

@@ -81,6 +81,7 @@ _SIGNATURES = {
     "uda_set_images_f32": (C.c_int, [_P, _P, C.c_int32, _P]),
     "uda_set_dropout_seed": (C.c_int, [_P, C.c_uint64]),
     "uda_set_dropout_image_offset": (C.c_int, [_P, C.c_int64]),
+    "uda_set_dropout_sample_shard": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32]),
     "uda_set_dropout_masks": (C.c_int, [_P, _P, C.c_int64]),
     "uda_get_dropout_masks": (C.c_int, [_P, _P, C.c_int64]),
     "uda_run": (C.c_int, [_P, C.c_int32, C.c_int32]),

@@ -793,7 +793,8 @@ void launch_fuse(const FuseArgs& a, hipStream_t s) {
 // u = (word >> 8) * 2^-24; keep iff u >= rate; scale = 1/(1-rate).   (DESIGN.md "dropout stream")
 __global__ __launch_bounds__(256) void philox_kernel(float* masks, const int64_t* site_off,
                                                      const int32_t* site_ch, const float* site_rate,
-                                                     int rows, uint32_t row_base, int max_c4, uint64_t seed) {
+                                                     int rows, uint32_t row_base, int max_c4, uint64_t seed,
+                                                     int t_local, int t_total, int t_first, int t_stride) {
   const int site = blockIdx.y;
   const int C = site_ch[site];
   const int C4 = (C + 3) >> 2;
@@ -803,7 +804,10 @@ __global__ __launch_bounds__(256) void philox_kernel(float* masks, const int64_t
   const int row = (int)(gid / max_c4);
   if (c4 >= C4) return;
   uint32_t w[4];
-  philox4x32_10((uint32_t)c4, row_base + (uint32_t)row, (uint32_t)site, 0u, (uint32_t)seed,
+  // row of the GLOBAL sample axis: local sample j of image n is sample t_first + j * t_stride of t_total (a handle that runs
+  // every sample: t_local = t_total, first 0, stride 1 - the local row itself)
+  const uint32_t grow = row_base + (uint32_t)(row / t_local) * (uint32_t)t_total + (uint32_t)t_first + (uint32_t)(row % t_local) * (uint32_t)t_stride;
+  philox4x32_10((uint32_t)c4, grow, (uint32_t)site, 0u, (uint32_t)seed,
                 (uint32_t)(seed >> 32), w);
   const float rate = site_rate[site];
   const float scale = 1.0f / (1.0f - rate);
@@ -819,11 +823,11 @@ __global__ __launch_bounds__(256) void philox_kernel(float* masks, const int64_t
 
 void launch_philox_masks(float* masks, const int64_t* site_off_dev, const int32_t* site_ch_dev,
                          const float* site_rate_dev, int n_sites, int rows, uint32_t row_base, int max_c4,
-                         uint64_t seed, hipStream_t s) {
+                         uint64_t seed, int t_local, int t_total, int t_first, int t_stride, hipStream_t s) {
   if (n_sites == 0 || rows == 0) return;
   const int64_t per_site = (int64_t)rows * max_c4;
   hipLaunchKernelGGL(philox_kernel, dim3((unsigned)((per_site + 255) / 256), n_sites), dim3(256), 0, s,
-                     masks, site_off_dev, site_ch_dev, site_rate_dev, rows, row_base, max_c4, seed);
+                     masks, site_off_dev, site_ch_dev, site_rate_dev, rows, row_base, max_c4, seed, t_local, t_total, t_first, t_stride);
 }
 
 // ------------------------------------------------------------------------------------ fused MBConv front half

@@ -129,6 +129,7 @@ struct uda_ctx {
   int masks_rows = 0;
   uint64_t seed = 0;
   int64_t image_offset = 0;
+  int t_first = 0, t_stride = 1, t_total = 0;      // this handle's samples inside the global sample axis (0: all of them; uda_set_dropout_sample_shard)
 
   // head outputs [max_images * Tx, hw, ch] per level
   float* d_cls[UDA_MAX_LEVELS] = {};
@@ -1013,6 +1014,16 @@ extern "C" int uda_set_dropout_image_offset(uda_ctx_t* c, int64_t first_image) {
   return 0;
 }
 
+extern "C" int uda_set_dropout_sample_shard(uda_ctx_t* c, int32_t t_first, int32_t t_stride, int32_t t_total) {
+  if (!c) return 1;
+  const int T = c->model.mc_samples;
+  if (t_total == 0) { c->t_first = 0; c->t_stride = 1; c->t_total = 0; return 0; }
+  if (t_first < 0 || t_stride < 1 || t_total < T || t_first + (int64_t)(T - 1) * t_stride >= t_total)
+    return fail(c, "set_dropout_sample_shard: samples %d + j * %d (j < %d) do not lie inside %d", t_first, t_stride, T, t_total);
+  c->t_first = t_first; c->t_stride = t_stride; c->t_total = t_total;
+  return 0;
+}
+
 extern "C" int uda_set_dropout_masks(uda_ctx_t* c, const float* masks, int64_t n_floats) {
   if (!c || !masks) return c ? fail(c, "set_dropout_masks: NULL") : 1;
   if (n_floats > c->mask_cap || (c->sum_site_ch && n_floats % c->sum_site_ch))
@@ -1464,7 +1475,8 @@ static int run_network(uda_ctx* c, int post_mode = 0, bool chunk_post = false, h
       HIPC(c, hipMemcpyAsync(c->d_site_off, c->site_off.data(), c->sites.size() * sizeof(int64_t),
                              hipMemcpyHostToDevice, c->stream));
       launch_philox_masks(c->d_masks, c->d_site_off, c->d_site_ch, c->d_site_rate, (int)c->sites.size(), rows,
-                          (uint32_t)(c->image_offset * T), c->max_c4, c->seed, c->stream);
+                          (uint32_t)(c->image_offset * (c->t_total > 0 ? c->t_total : T)), c->max_c4, c->seed,
+                          T, c->t_total > 0 ? c->t_total : T, c->t_first, c->t_stride, c->stream);
     }
   }
   const int lanes = c->n_lanes;

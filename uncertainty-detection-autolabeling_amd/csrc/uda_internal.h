@@ -282,7 +282,7 @@ void launch_se(const SeArgs& a, int rows, hipStream_t s);
 void launch_fuse(const FuseArgs& a, hipStream_t s);
 void launch_philox_masks(float* masks, const int64_t* site_off_dev, const int32_t* site_ch_dev,
                          const float* site_rate_dev, int n_sites, int rows, uint32_t row_base, int max_c4,
-                         uint64_t seed, hipStream_t s);
+                         uint64_t seed, int t_local, int t_total, int t_first, int t_stride, hipStream_t s);
 
 // ---------------------------------------------------------------- post-process (kernels_post.hip)
 struct LevelTable {

@@ -240,6 +240,81 @@ def reshard_member_heads(owned, n_members, n_total, rank, world, device=None, gr
     return outs[:n_cls], outs[n_cls:]
 
 
+# ---------------------------------------------------------------------------------------------- MC-sample sharding
+def sample_owner(t, world):
+    """Rank that runs MC sample t (samples striped round-robin: rank r owns t = r, r + world, ...)."""
+    return t % world
+
+
+def local_samples(T, rank, world):
+    """The global sample indices rank `rank` runs."""
+    return list(range(rank, T, world))
+
+
+class SampleShardedDriver:
+    """north_star: "images (and optionally MC samples) shard".  The reference's own callers serve ONE image per call
+    (validate_model.py:476-522, infer_model.py:554-581): image sharding then uses one GPU of the node.  Here the T MC samples of
+    a batch are striped over the ranks instead - rank r runs the network for samples t = r (mod world) of EVERY image (its
+    handle is built for T_r = |{t}| samples and told which global samples they are: `set_sample_shard`, so the ranks together
+    draw exactly the dropout masks of one handle that runs all T) - and the head outputs are then re-sharded by image with the
+    ensemble's all-to-all-v (`reshard_member_heads`: a sample is a "member"), so that the owner of an image holds its T rows in
+    order t = 0 ... T - 1 and aggregates them with the same sequential float32 sums as a single process: detections are
+    bit-identical to one GPU.  One more exchange than image sharding (the head outputs: 11 MB per image and sample at
+    D0 / 1280 x 768) in return for 1 / world of the network time per image."""
+
+    def __init__(self, model_name, batch_size, model_params, weights, rank, world, device=0, post_mode="global"):
+        from . import infer_lib
+        p = dict(model_params)
+        self.T = int(p["mc_dropoutsamp"]) if p.get("mc_dropout") else 1
+        if self.T < world:
+            raise ValueError("%d MC samples cannot be striped over %d ranks" % (self.T, world))
+        self.rank, self.world = rank, world
+        self.mine = local_samples(self.T, rank, world)
+        pn = dict(p, mc_dropoutsamp=len(self.mine))
+        self.net = infer_lib.ServingDriver(model_name, batch_size, True, pn, weights=weights, device=device)
+        self.net.set_sample_shard(rank, world, self.T)
+        self.post = infer_lib.ServingDriver(model_name, batch_size, False, p, device=device, post_only=True, post_mode=post_mode)
+        self.stacked = (bool(self.post.plan.cls_stacked), bool(self.post.plan.box_stacked))      # the reference's stacking rule, full T
+
+    def set_dropout_seed(self, seed):
+        self.net.set_dropout_seed(seed)
+
+    def close(self):
+        self.net.close()
+        self.post.close()
+
+    def serve(self, images, device=None, group=None, post_mode=None):
+        """uint8 images (every rank passes the SAME batch) -> the full batch's detections on every rank."""
+        n_total = len(images)
+        self.net.set_image_offset(0)
+        n = self.net.run_network(images)
+        cls, box = self.net.head_outputs(n)                  # stacked heads: [T_r, n, ...] per level; the others [n, ...]
+        _, scales = self.net.preprocessed_scales(n)
+        a, b = shard_range(n_total, self.rank, self.world)
+        # stacked heads come back [T_r, n, ...] (a rank with ONE sample: [n, ...], the driver drops a sample axis of one)
+        cls = [c[None] if (self.stacked[0] and c.ndim == 4) else c for c in cls]
+        box = [x[None] if (self.stacked[1] and x.ndim == 4) else x for x in box]
+        owned = {}
+        for j, t in enumerate(self.mine):
+            owned[t] = ([np.ascontiguousarray(c[j]) if self.stacked[0] else np.zeros((n, 0), np.float32) for c in cls],
+                        [np.ascontiguousarray(x[j]) if self.stacked[1] else np.zeros((n, 0), np.float32) for x in box])
+        rc, rb = reshard_member_heads(owned, self.T, n_total, self.rank, self.world, device=device, group=group)
+        counts = [shard_range(n_total, r, self.world)[1] - shard_range(n_total, r, self.world)[0] for r in range(self.world)]
+        if b > a:
+            # a head that is not stacked is deterministic: every rank computed the same tensor - take this rank's own copy
+            cls_in = [rc[l] if self.stacked[0] else cls[l][a:b] for l in range(len(cls))]
+            box_in = [rb[l] if self.stacked[1] else box[l][a:b] for l in range(len(box))]
+            det = self.post.postprocess(cls_in, box_in, np.asarray(scales[a:b], np.float32), post_mode=post_mode)
+        else:
+            det = self.post.empty_detections()
+        return all_gather_detections(det, device=device, group=group, counts=counts)
+
+
+def serve_sample_sharded(driver, images, device=None, group=None):
+    """`SampleShardedDriver.serve` under the name the other sharded entry points use."""
+    return driver.serve(images, device=device, group=group)
+
+
 class DevArray:
     """Zero-copy view of a device buffer owned by a HIP handle for torch (`torch.as_tensor(DevArray(...), device=...)`):
     float32, C-contiguous, exposed through `__cuda_array_interface__` (version 2)."""

@@ -329,6 +329,21 @@ class ServingDriver:
         Philox dropout rows those of the unsharded batch."""
         self._ck(self._lib.uda_set_dropout_image_offset(self._h, int(first_image)), "uda_set_dropout_image_offset")
 
+    def set_sample_shard(self, first, stride, total):
+        """This driver's T samples are samples first + j * stride of a global axis of `total` MC samples (sample sharding over
+        ranks, `dist.serve_sample_sharded`): its dropout rows are those of one driver that runs all of them.  total = 0: off."""
+        self._ck(self._lib.uda_set_dropout_sample_shard(self._h, int(first), int(stride), int(total)), "uda_set_dropout_sample_shard")
+
+    def run_network(self, image_arrays):
+        """uint8 images -> preprocess + network for this driver's samples, no post-process: the head outputs stay in the handle
+        (`head_outputs`, `head_outputs_device`).  Returns the image count."""
+        n = self._feed(image_arrays)
+        self._next_seed()
+        self._run_id += 1
+        self._ck(self._lib.uda_run(self._h, -1, 0), "uda_run")
+        self._last_n = n
+        return n
+
     def serve(self, image_arrays, post_mode=None):
         """uint8 [N,h,w,3] -> (boxes, scores, classes, valid_len[, logits]).
 
