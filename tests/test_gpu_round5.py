@@ -257,14 +257,15 @@ w = dict(make_weights(p, seed=21, cls_spread=20.0))
 rng = np.random.default_rng(77)
 # what trained checkpoints look like and the initialisers do not: batch-norm scales spread over orders of magnitude
 # (gamma / sqrt(var) log-uniform in [0.05, 30]), depthwise taps up to +-8, BiFPN activations small
-# (per channel, in every fifth batch norm - a spread like that in EVERY layer of a random network compounds to float32
-# overflow, which no trained network does - and the batch norm behind it divides the layer's mean scale back out)
-for k in sorted(w):
-    if k.endswith("/gamma") and rng.integers(0, 5) == 0:
-        f = np.exp(rng.uniform(np.log(0.05), np.log(30.0), w[k].shape))
-        w[k] = (w[k] * f / np.exp(np.mean(np.log(f)))).astype(np.float32)
-    elif k.endswith("depthwise_kernel") and "blocks_" in k and rng.integers(0, 3) == 0:
-        w[k] = (w[k] * rng.uniform(1.0, 8.0 / max(1e-6, float(np.abs(w[k]).max())), w[k].shape)).astype(np.float32)
+# (per channel, in six batch norms and three depthwise kernels picked at random - a spread like that in EVERY layer of a random
+# network compounds to float32 overflow, which no trained network does; the layer's geometric-mean scale is divided back out)
+gam = sorted(k for k in w if k.endswith("/gamma"))
+dws = sorted(k for k in w if k.endswith("depthwise_kernel") and "blocks_" in k)
+for k in rng.choice(gam, 6, replace=False):
+    f = np.exp(rng.uniform(np.log(0.05), np.log(30.0), w[k].shape))
+    w[k] = (w[k] * f / np.exp(np.mean(np.log(f)))).astype(np.float32)
+for k in rng.choice(dws, 3, replace=False):
+    w[k] = (w[k] * rng.uniform(1.0, 8.0 / max(1e-6, float(np.abs(w[k]).max())), w[k].shape)).astype(np.float32)
 d = KerasDriver("_", False, p["name"], 2, False, p, weights=w)
 d.set_dropout_seed(9)
 imgs = make_images(2, 128, 192, seed=5)

@@ -530,7 +530,7 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
       // deferred dropout site of the producer (plan.py: first head layer under head-only MC): keep-scales of the INPUT channels
       const uda_buf_desc_t& ib = bufs[o.in[0]];
       const uda_buf_desc_t& ob = bufs[o.out];
-      if (o.fuse_in || ib.per_sample || !ob.per_sample || c->sites[o.drop_site2].channels != ib.C) {
+      if (o.fuse_in || ib.per_sample || (!ob.per_sample && T > 1) || c->sites[o.drop_site2].channels != ib.C) {
         fail(nullptr, "op %d: a deferred input dropout site needs a plain separable conv with a per-image input of %d channels and a "
                       "per-sample output", i, c->sites[o.drop_site2].channels);
         uda_destroy(c);

@@ -664,7 +664,9 @@ class Plan:
                 next_cout = F if i + 1 < nrep else outc
                 for li in range(len(feats)):
                     site = self._site("%s-%d-%d" % (tag, i, lo + li))
-                    defer = (site >= 0 and pending[li] < 0 and self.T > 1 and not self.bufs[xs[li]].per_sample
+                    # (T == 1 included - a rank of a sample-sharded serve may run ONE sample: the position of the multiply
+                    # must not depend on how many samples a handle runs, or the shards would differ in the last bit)
+                    defer = (site >= 0 and pending[li] < 0 and not self.bufs[xs[li]].per_sample
                              and self.fuse_sep and sep_tin_supported(F, next_cout))
                     xs[li] = self._sepconv(xs[li], F, pre + "/depthwise_kernel", pre + "/pointwise_kernel",
                                            "%s-%d-%d" % (tag, i, lo + li), bias=pre + "/bias",
