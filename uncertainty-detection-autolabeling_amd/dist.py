@@ -270,7 +270,7 @@ class SampleShardedDriver:
             raise ValueError("%d MC samples cannot be striped over %d ranks" % (self.T, world))
         self.rank, self.world = rank, world
         self.mine = local_samples(self.T, rank, world)
-        pn = dict(p, mc_dropoutsamp=len(self.mine))
+        pn = dict(p, mc_dropoutsamp=len(self.mine), uda_force_sample_axis=True)      # (one sample on a rank: same lowering as several)
         self.net = infer_lib.ServingDriver(model_name, batch_size, True, pn, weights=weights, device=device)
         self.net.set_sample_shard(rank, world, self.T)
         self.post = infer_lib.ServingDriver(model_name, batch_size, False, p, device=device, post_only=True, post_mode=post_mode)

@@ -284,6 +284,10 @@ class Plan:
         self.w = weights
         self.T = arch.mc_flags(self.cfg)[2]
         self.cls_stacked, self.box_stacked, _ = arch.mc_flags(self.cfg)
+        # The sample axis exists when there is more than one sample - or when the caller says so (`uda_force_sample_axis`: a rank
+        # of a sample-sharded serve that runs ONE of the T samples must lower the network exactly like a handle that runs
+        # several, or its heads differ from theirs in the last bit: which kernel variant an op takes follows the axis)
+        self.sample_axis = self.T > 1 or bool(self.cfg.get("uda_force_sample_axis"))
         self.chunk_images = int(chunk_images)
         self.max_images = int(max_images)
         self.bufs, self.ops, self.blob, self.blob_len = [], [], [], 0
@@ -309,8 +313,8 @@ class Plan:
         cfg = self.cfg
         fs = get_feat_sizes(cfg["image_size"], cfg["max_level"])
         self.level_hw = [tuple(fs[l]) for l in range(cfg["min_level"], cfg["max_level"] + 1)]
-        self.cls_stacked_dev = bool(self.cls_stacked and self.T > 1)
-        self.box_stacked_dev = bool(self.box_stacked and self.T > 1)
+        self.cls_stacked_dev = bool(self.cls_stacked and self.sample_axis)
+        self.box_stacked_dev = bool(self.box_stacked and self.sample_axis)
         self._buf(1, 1, 4, False, name="unused")
         self.arena_floats = ALIGN
         self.fpn_out, self.head_out = [], {"class": [], "box": []}
@@ -360,7 +364,7 @@ class Plan:
 
     # ------------------------------------------------------------------ graph building
     def _buf(self, H, W, C, per_sample, kind=0, level=0, name=""):
-        self.bufs.append(_Buf(H, W, C, per_sample and self.T > 1, kind, level, name))
+        self.bufs.append(_Buf(H, W, C, per_sample and self.sample_axis, kind, level, name))
         if name:
             self.buffer_names[name] = len(self.bufs) - 1
         return len(self.bufs) - 1
@@ -685,7 +689,7 @@ class Plan:
         # the head buffers must carry the sample axis exactly when the reference stacks them
         for tag, stacked in (("class", self.cls_stacked), ("box", self.box_stacked)):
             for o in self.head_out[tag]:
-                want = bool(stacked and self.T > 1)
+                want = bool(stacked and self.sample_axis)
                 if self.bufs[o].per_sample != want:
                     # stacked in the reference but every sample identical here (all rates zero):
                     # keep one copy; the driver broadcasts when it returns `predict` outputs.
