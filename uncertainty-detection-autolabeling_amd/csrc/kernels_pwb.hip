@@ -33,7 +33,12 @@
 
 namespace uda {
 
-template <int MT, int NT, int WM, int WN, int PARTS, int OCC>
+// DEEP (round 5): K-heavy contractions (1152 -> 192 / 320 at 24 x 40: 36 chunks per block) ran one 16 KB chunk per block on its
+// way - a chunk costs a memory latency, not its matrix time.  The chunk loop is unrolled by two with TWO register sets, so that
+// the chunk after next is requested before the current one is multiplied: the order of the outstanding loads is the same at the
+// loop header from the prologue and from the back edge (set 0 older, set 1 younger), which is what lets the compiler wait for
+// a set with vmcnt(loads of the other set) instead of vmcnt(0).
+template <int MT, int NT, int WM, int WN, int PARTS, int OCC, bool DEEP = false>
 __global__ __launch_bounds__(256, OCC) void pwb_kernel(PwArgs a) {
   static_assert(WM * WN == 4, "four waves per block");
   constexpr int NPC = split_np(PARTS);     // pieces per operand (PARTS names the scheme: UDA_SPLIT_*)
@@ -71,23 +76,34 @@ __global__ __launch_bounds__(256, OCC) void pwb_kernel(PwArgs a) {
   constexpr int A_ITERS = BM * 8 / 256;
   constexpr int B_TOTAL = 2 * NTB * NPC * 64;
   constexpr int B_ITERS = (B_TOTAL + 255) / 256;
-  float4 ra[A_ITERS];
-  uint4 rb[B_ITERS];
-  float4 rg = make_float4(1.f, 1.f, 1.f, 1.f);
+  struct ChunkRegs { float4 ra[A_ITERS]; uint4 rb[B_ITERS]; float4 rg; };       // one chunk's operands on their way
+  ChunkRegs c0, c1;
+  c0.rg = make_float4(1.f, 1.f, 1.f, 1.f);
+  c1.rg = c0.rg;
   float amax = 0.f;                        // fp16 pieces: largest operand magnitude this lane has split
 
-  auto load_chunk = [&](int k0) {
+  auto load_chunk = [&](int k0, ChunkRegs& cr) {
+    float4* ra = cr.ra; uint4* rb = cr.rb; float4& rg = cr.rg;
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
       const int f = tid + 256 * i;
       const int m = f >> 3, k = k0 + 4 * (f & 7);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m0 + m < a.HW && k < a.Cin) v = *(const float4*)(A + (size_t)(m0 + m) * a.Cin + k);
-      ra[i] = v;
+      if constexpr (DEEP) {
+        // branch-free (the launcher checked Cin % 32 == 0 and whole column tiles): a load under a lane condition sits in a
+        // basic block of its own and the compiler then waits for EVERYTHING at the first use (vmcnt(0)).  Rows past the map
+        // read the last row: row m of A only reaches row m of the result, which is never stored.
+        const int mr = m0 + m < a.HW ? m0 + m : a.HW - 1;
+        ra[i] = *(const float4*)(A + (size_t)mr * a.Cin + k);
+      } else {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m0 + m < a.HW && k < a.Cin) v = *(const float4*)(A + (size_t)(m0 + m) * a.Cin + k);
+        ra[i] = v;
+      }
     }
     if (se) {
       const int k = k0 + 4 * (tid & 7);
-      rg = (k < a.Cin) ? *(const float4*)(se + k) : make_float4(1.f, 1.f, 1.f, 1.f);
+      if constexpr (DEEP) rg = *(const float4*)(se + k);
+      else rg = (k < a.Cin) ? *(const float4*)(se + k) : make_float4(1.f, 1.f, 1.f, 1.f);
     }
     const int ks0 = k0 >> 4;
 #pragma unroll
@@ -96,13 +112,18 @@ __global__ __launch_bounds__(256, OCC) void pwb_kernel(PwArgs a) {
       int q = f >> 6;
       const int part = q % NPC; q /= NPC;
       const int nt = q % NTB, ks = q / NTB;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (f < B_TOTAL && ks0 + ks < KS && nt0 + nt < NTL)
-        v = Wp[(((size_t)(ks0 + ks) * NTL + (nt0 + nt)) * NPC + part) * 64 + (f & 63)];
-      rb[i] = v;
+      if constexpr (DEEP && B_TOTAL % 256 == 0) {
+        rb[i] = Wp[(((size_t)(ks0 + ks) * NTL + (nt0 + nt)) * NPC + part) * 64 + (f & 63)];
+      } else {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (f < B_TOTAL && ks0 + ks < KS && nt0 + nt < NTL)
+          v = Wp[(((size_t)(ks0 + ks) * NTL + (nt0 + nt)) * NPC + part) * 64 + (f & 63)];
+        rb[i] = v;
+      }
     }
   };
-  auto store_chunk = [&]() {
+  auto store_chunk = [&](const ChunkRegs& cr) {
+    const float4* ra = cr.ra; const uint4* rb = cr.rb; const float4 rg = cr.rg;
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
       const int f = tid + 256 * i;
@@ -127,11 +148,7 @@ __global__ __launch_bounds__(256, OCC) void pwb_kernel(PwArgs a) {
     }
   };
 
-  load_chunk(0);
-  for (int k0 = 0; k0 < a.Cin; k0 += PWB_BK) {
-    store_chunk();
-    __syncthreads();
-    if (k0 + PWB_BK < a.Cin) load_chunk(k0 + PWB_BK);   // in flight during the MFMAs below
+  auto mma_chunk = [&](int k0) {
     const int nks = (a.Cin - k0 > 16) ? 2 : 1;
     for (int ks = 0; ks < nks; ++ks) {
       bf16x8 af[MT][NPC];
@@ -150,7 +167,33 @@ __global__ __launch_bounds__(256, OCC) void pwb_kernel(PwArgs a) {
         for (int m = 0; m < MT; ++m) acc[m][n] = mfma_terms<PARTS>(af[m], bf, acc[m][n]);
       }
     }
-    __syncthreads();
+  };
+  if constexpr (DEEP) {
+    load_chunk(0, c0);
+    if (PWB_BK < a.Cin) load_chunk(PWB_BK, c1);
+    for (int k0 = 0; k0 < a.Cin; k0 += 2 * PWB_BK) {
+      store_chunk(c0);
+      __syncthreads();
+      if (k0 + 2 * PWB_BK < a.Cin) load_chunk(k0 + 2 * PWB_BK, c0);     // two chunks ahead
+      mma_chunk(k0);
+      __syncthreads();
+      if (k0 + PWB_BK < a.Cin) {
+        store_chunk(c1);
+        __syncthreads();
+        if (k0 + 3 * PWB_BK < a.Cin) load_chunk(k0 + 3 * PWB_BK, c1);
+        mma_chunk(k0 + PWB_BK);
+        __syncthreads();
+      }
+    }
+  } else {
+    load_chunk(0, c0);
+    for (int k0 = 0; k0 < a.Cin; k0 += PWB_BK) {
+      store_chunk(c0);
+      __syncthreads();
+      if (k0 + PWB_BK < a.Cin) load_chunk(k0 + PWB_BK, c0);   // in flight during the MFMAs below
+      mma_chunk(k0);
+      __syncthreads();
+    }
   }
   split_report<PARTS>(amax, a.oor);
 
@@ -371,7 +414,14 @@ static void launch_pwb_cfg(const PwArgs& a, int rows, hipStream_t s) {
   const dim3 grid((a.HW + BM - 1) / BM, (a.Cout + BN - 1) / BN, rows), block(256);
   // three blocks per CU (<= 168 registers): measured 10-20 % faster than the unconstrained allocation (2 per CU)
   if (a.wparts == UDA_SPLIT_BF16X3) hipLaunchKernelGGL((pwb_kernel<MT, NT, WM, WN, 3, 2>), grid, block, 0, s, a);
-  else if (a.wparts == UDA_SPLIT_F16X2) hipLaunchKernelGGL((pwb_kernel<MT, NT, WM, WN, 4, (MT * NT > 4 ? 2 : 3)>), grid, block, 0, s, a);
+  else if (a.wparts == UDA_SPLIT_F16X2) {
+    // (K-heavy projections on the big tiles - two blocks per CU by registers anyway: two chunks in flight per block)
+    static const bool deep_on = !(getenv("UDA_PWB_DEEP") && atoi(getenv("UDA_PWB_DEEP")) == 0);
+    if constexpr (MT * NT > 4) {
+      if (deep_on && a.Cin >= 384 && a.Cin % PWB_BK == 0 && a.Cout % BN == 0 && (2 * NT * WN * 2 * 64) % 256 == 0) { hipLaunchKernelGGL((pwb_kernel<MT, NT, WM, WN, 4, 2, true>), grid, block, 0, s, a); return; }
+    }
+    hipLaunchKernelGGL((pwb_kernel<MT, NT, WM, WN, 4, (MT * NT > 4 ? 2 : 3)>), grid, block, 0, s, a);
+  }
   else hipLaunchKernelGGL((pwb_kernel<MT, NT, WM, WN, 2, (MT * NT > 4 ? 2 : 3)>), grid, block, 0, s, a);   // (5-6 accumulator tiles per wave: 168 registers spill)
 }
 
