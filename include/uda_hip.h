@@ -64,9 +64,9 @@ enum uda_op_kind {
                        (+bias)(+BN)(+swish)(+dropout); the depthwise result never leaves the CU
                        (efficientdet_keras.py:207-227,421-446,584-626) */
 };
-/* utils.activation_fn (reference utils.py:42-59): swish / silu / swish_native are one function; mish and srelu are refused
- * by the planner (ValueError, as the reference raises for an unknown act_type) */
-enum uda_act { UDA_ACT_NONE = 0, UDA_ACT_SWISH = 1, UDA_ACT_RELU = 2, UDA_ACT_RELU6 = 3, UDA_ACT_HSWISH = 4 };
+/* utils.activation_fn (reference utils.py:42-59): swish / silu / swish_native are one function; srelu (it carries a trainable
+ * beta) is refused by the planner (ValueError, as the reference raises for an unknown act_type) */
+enum uda_act { UDA_ACT_NONE = 0, UDA_ACT_SWISH = 1, UDA_ACT_RELU = 2, UDA_ACT_RELU6 = 3, UDA_ACT_HSWISH = 4, UDA_ACT_MISH = 5 };
 enum uda_resample { UDA_RS_NONE = 0, UDA_RS_NEAREST_UP = 1, UDA_RS_MAXPOOL = 2 };
 
 typedef struct uda_op {

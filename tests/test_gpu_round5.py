@@ -32,6 +32,7 @@ SWITCH_CASES = [
     ("relu6", dict(act_type="relu6", **HEAD_MC)),
     ("hswish", dict(act_type="hswish", **FULL_MC)),
     ("swish_native", dict(act_type="swish_native", **LOSS_ATT)),
+    ("mish", dict(act_type="mish", **HEAD_MC)),
     ("conv_bn_act", dict(conv_bn_act_pattern=True, **FULL_MC)),
     ("conv_bn_act_relu6", dict(conv_bn_act_pattern=True, act_type="relu6", **LOSS_ATT)),
     ("conv_after_downsample", dict(conv_after_downsample=True, **HEAD_MC)),
@@ -116,7 +117,7 @@ def test_relu_network_serves_the_oracle_detections_on_a_u8_batch():
 
 def test_refused_switches_fail_before_anything_is_created():
     from uda_amd import plan as plan_mod
-    for over in (dict(act_type="mish"), dict(separable_conv=False), dict(fpn_weight_method="channel_attn"),
+    for over in (dict(act_type="srelu"), dict(separable_conv=False), dict(fpn_weight_method="channel_attn"),
                  dict(data_format="channels_first"), dict(fpn_name="qufpn")):
         p = make_params(**over)
         with pytest.raises(ValueError):

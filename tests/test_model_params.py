@@ -38,7 +38,7 @@ def test_every_default_key_has_a_stated_handling():
 # that differs from the default.  "changes": the plan must differ; an exception class: the planner must raise it.
 SWITCHES = [
     ("act_type", "relu", "changes"), ("act_type", "relu6", "changes"), ("act_type", "hswish", "changes"),
-    ("act_type", "mish", ValueError), ("act_type", "srelu", ValueError), ("act_type", "gelu", ValueError),
+    ("act_type", "mish", "changes"), ("act_type", "srelu", ValueError), ("act_type", "gelu", ValueError),
     ("separable_conv", False, ValueError),
     ("conv_bn_act_pattern", True, "changes"),
     ("conv_after_downsample", True, "changes"),
@@ -73,7 +73,7 @@ def test_switch_is_honoured_or_refused(key, value, expect):
 def test_activation_reaches_every_layer_that_applies_relu_fn():
     """act_type is ONE function for the stem, expand, depthwise and SE reduce layers (efficientdet_keras.py:864-868 ->
     efficientnet_model.py relu_fn), the BiFPN nodes (:229-236) and the head layers (:458-459,638-639)."""
-    for name, code in (("relu", capi.ACT_RELU), ("relu6", capi.ACT_RELU6), ("hswish", capi.ACT_HSWISH), ("silu", capi.ACT_SWISH),
+    for name, code in (("relu", capi.ACT_RELU), ("relu6", capi.ACT_RELU6), ("hswish", capi.ACT_HSWISH), ("mish", capi.ACT_MISH), ("silu", capi.ACT_SWISH),
                        ("swish_native", capi.ACT_SWISH)):
         pl, p = _plan(act_type=name, **FULL_MC)
         kinds = {}

@@ -19,7 +19,7 @@ MAX_LEVELS = 8
 MAX_FUSE = 3
 
 OP_STEM, OP_PW, OP_DW, OP_SE, OP_FUSE, OP_POOL, OP_MBX, OP_SEP = 1, 2, 3, 4, 5, 6, 7, 8
-ACT_NONE, ACT_SWISH, ACT_RELU, ACT_RELU6, ACT_HSWISH = 0, 1, 2, 3, 4
+ACT_NONE, ACT_SWISH, ACT_RELU, ACT_RELU6, ACT_HSWISH, ACT_MISH = 0, 1, 2, 3, 4, 5
 RS_NONE, RS_NEAREST_UP, RS_MAXPOOL = 0, 1, 2
 DECODE_PLAIN, DECODE_LNORM, DECODE_FALSEDEC, DECODE_SAMPLE = 0, 1, 2, 3
 POST_GLOBAL, POST_PER_CLASS = 0, 1

@@ -514,7 +514,7 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
       uda_destroy(c);
       return 1;
     }
-    if (o.act < UDA_ACT_NONE || o.act > UDA_ACT_HSWISH || o.fuse_act < UDA_ACT_NONE || o.fuse_act > UDA_ACT_HSWISH) {
+    if (o.act < UDA_ACT_NONE || o.act > UDA_ACT_MISH || o.fuse_act < UDA_ACT_NONE || o.fuse_act > UDA_ACT_MISH) {
       fail(nullptr, "op %d: unknown activation %d / %d", i, o.act, o.fuse_act);
       uda_destroy(c);
       return 1;
@@ -703,7 +703,13 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
         CK(hipMemcpy(c->d_wsplit, packed.data(), packed.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
   }
-  CK(dalloc(&c->d_arena, (size_t)m.arena_floats));
+  // The arena starts out as zeros and ends in a guard: some kernels read a few floats past the end of their input (the
+  // k-padding of the last pixel's matrix fragment, a dead lane's clamped window) and multiply them by zero weights - that must
+  // never meet a NaN pattern in fresh memory (one NaN pixel reaches a whole image through the squeeze-excite mean: round 5,
+  // DESIGN 4.1) nor the end of the allocation.
+  constexpr size_t ARENA_GUARD = 4096;      // floats
+  CK(dalloc(&c->d_arena, (size_t)m.arena_floats + ARENA_GUARD));
+  CK(hipMemset(c->d_arena, 0, ((size_t)m.arena_floats + ARENA_GUARD) * sizeof(float)));
   {
     const char* e = getenv("UDA_LANES");
     c->n_lanes = e ? atoi(e) : 1;   // 2 overlaps consecutive chunks on two streams: +4 % throughput, but per-kernel timings then include the sharing
@@ -727,7 +733,8 @@ extern "C" int uda_create(const uda_model_t* model, const uda_buf_desc_t* bufs, 
     for (int l = 0; l < c->n_lanes; ++l) CK(hipEventCreateWithFlags(&c->ev_done[l], hipEventDisableTiming));
     for (int l = 1; l < c->n_lanes; ++l) {
       CK(hipStreamCreateWithFlags(&c->lane_stream[l], hipStreamNonBlocking));
-      CK(dalloc(&c->lane_arena[l], (size_t)m.arena_floats));
+      CK(dalloc(&c->lane_arena[l], (size_t)m.arena_floats + ARENA_GUARD));
+      CK(hipMemset(c->lane_arena[l], 0, ((size_t)m.arena_floats + ARENA_GUARD) * sizeof(float)));
     }
   }
 

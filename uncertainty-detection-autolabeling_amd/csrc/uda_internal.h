@@ -54,6 +54,13 @@ __device__ __forceinline__ void philox_normal2(uint64_t seed, uint32_t i0, uint3
 // float32 reciprocal, 1 ulp like the hardware rcp / exp2 of the swish path): four vector instructions and no live register
 // beyond the value, so the epilogues of the tuned kernels keep their register counts (tools/codeobj.py resources).
 __device__ __forceinline__ float act_relu_family(float v, int act) {
+  if (act == UDA_ACT_MISH) {
+    // x tanh(softplus(x)) = x n / (n + 2) with n = e^x (e^x + 2): one exp, one rcp (the hardware ones, as in the swish path);
+    // beyond x = 20 the quotient is 1 to float32 and e^2x would overflow
+    const float e = __expf(fminf(v, 20.0f));
+    const float n = e * (e + 2.0f);
+    return v * (n * __builtin_amdgcn_rcpf(n + 2.0f));
+  }
   const float off = act == UDA_ACT_HSWISH ? 3.0f : 0.0f;
   const float hi = act == UDA_ACT_RELU ? __builtin_inff() : 6.0f;
   const float r = __builtin_amdgcn_fmed3f(v + off, 0.0f, hi);

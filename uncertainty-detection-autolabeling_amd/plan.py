@@ -161,7 +161,7 @@ def same_out(n, s):
 # training=True), or checked by `check_model_params`, which raises the reference's kind of ValueError for a value the
 # path does not implement - never a silently different network (tests/test_plan_host.py walks this table).
 ACT_CODES = {"swish": capi.ACT_SWISH, "silu": capi.ACT_SWISH, "swish_native": capi.ACT_SWISH,
-             "relu": capi.ACT_RELU, "relu6": capi.ACT_RELU6, "hswish": capi.ACT_HSWISH}
+             "relu": capi.ACT_RELU, "relu6": capi.ACT_RELU6, "hswish": capi.ACT_HSWISH, "mish": capi.ACT_MISH}
 MODEL_PARAM_HANDLING = {
     # --- network structure (efficientdet_keras.py:850-970, efficientnet_model.py:731-834)
     "name": "inert: a label (the structure comes from the keys below)",
@@ -171,7 +171,7 @@ MODEL_PARAM_HANDLING = {
     "num_scales": "consumed", "aspect_ratios": "consumed", "anchor_scale": "consumed",
     "mean_rgb": "consumed", "stddev_rgb": "consumed",
     "box_class_repeats": "consumed", "fpn_cell_repeats": "consumed", "fpn_num_filters": "consumed",
-    "act_type": "consumed: swish | silu | swish_native | relu | relu6 | hswish; mish / srelu raise (utils.py:42-59)",
+    "act_type": "consumed: swish | silu | swish_native | relu | relu6 | hswish | mish; srelu raises (utils.py:42-59)",
     "separable_conv": "checked: False (dense 3x3 convs in BiFPN and heads) raises",
     "apply_bn_for_resampling": "consumed (efficientdet_keras.py:313-318)",
     "conv_after_downsample": "consumed (efficientdet_keras.py:331-338)",
@@ -207,12 +207,12 @@ MODEL_PARAM_HANDLING = {
 
 
 def act_code(cfg):
-    """uda_act of config.act_type; the reference's ValueError for anything utils.activation_fn does not know, and for the two
-    it knows that have no kernel here (mish, srelu - the latter carries a trainable beta)."""
+    """uda_act of config.act_type; the reference's ValueError for anything utils.activation_fn does not know, and for the one
+    it knows that has no kernel here (srelu: it carries a trainable beta)."""
     name = cfg.get("act_type", "swish")
     if name in ACT_CODES:
         return ACT_CODES[name]
-    if name in ("mish", "srelu"):
+    if name == "srelu":
         raise ValueError("act_type %r is not available on the HIP path (implemented: %s)" % (name, ", ".join(sorted(ACT_CODES))))
     raise ValueError("Unsupported act_type {}".format(name))
 
