@@ -411,9 +411,10 @@ def main():
                     "share_of_step": round(dom_ms / a.steps / (elapsed / a.steps * 1e3), 3)}
             if KIND_NAMES.get(dominant, "") == "mbx":
                 roof["note"] = ("fused MBConv front halves: bound by vector issue, not by HBM - SQ counters of the committed profile "
-                                "(profiles/r04_sq.txt, this scheme): VALU 75-88 % busy in blocks 1-10 at the 1.8-2.0 GHz the chip holds under them, "
-                                "two transcendentals per swish = 60 % of block 1's vector time, instruction counts at the floor of the algorithm "
-                                "(DESIGN.md 4.5, 4.6); plain streaming kernels reach 4.5-5.7 TB/s on this box (tools/micro/hbm_rates.hip)")
+                                "(profiles/r05_sq.txt, this scheme): VALU 73 % busy over the family, 75-88 % in blocks 1-10, at the 1.8-2.0 GHz the "
+                                "chip holds under them; two transcendentals per swish = 60 % of block 1's vector time, instruction counts at the "
+                                "floor of the algorithm (DESIGN.md 4.5-4.7); plain streaming kernels reach 4.5-5.7 TB/s on this box "
+                                "(tools/micro/hbm_rates.hip)")
             # What bounds the dominant family, from the committed counter profile of this command (profiles/roofline_inputs.json,
             # written by tools/summarize_r05.py from the SQ / FETCH / WRITE passes): the fused MBConv front halves are bound by
             # vector issue - `bound` = "valu", `achieved` / `frac` = share of the VALU issue cycles that are busy, re-scaled
@@ -459,12 +460,20 @@ def main():
         try:
             ri = json.load(open(os.path.join(ROOT, "profiles", "roofline_inputs.json")))
             tb = ri.get("traffic_bytes_per_launch", {})
+            pl_ = drv.plan
+            units, i_ = {}, 0          # launches per kind and chunk: the ops of a head layer share ONE launch (launch_group)
+            while i_ < len(pl_.ops):
+                o_ = pl_.ops[i_]
+                units[o_["kind"]] = units.get(o_["kind"], 0) + 1
+                i_ += max(1, o_.get("launch_group", 0))
+            chunks = -(-a.batch // pl_.chunk_images)
             by = 0.0
-            for k_, cst_ in costs.items():
+            for k_, n_ in units.items():
                 nm = KIND_NAMES.get(k_, "")
                 if nm in tb:
-                    by += tb[nm] * cst_["launches"]
-            pl_ = drv.plan
+                    by += tb[nm] * n_ * chunks
+            for nm in ("aggregate", "nms"):
+                by += tb.get(nm, 0.0)
             exp_b = 2.0 * sum(4.0 * a.batch * (pl_.T if pl_.bufs[o["out"]].per_sample else 1) * pl_.bufs[o["out"]].H * pl_.bufs[o["out"]].W * pl_.bufs[o["out"]].C
                               for o in pl_.ops if o["kind"] == 7)
             ms = elapsed / a.steps * 1e3
