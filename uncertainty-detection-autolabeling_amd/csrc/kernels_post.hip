@@ -75,6 +75,36 @@ void launch_preprocess(const PreprocArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------ aggregate + decode
 __device__ __forceinline__ float exp32(float x) { return (float)exp((double)x); }
 
+// The soft-NMS weight exp(e), e = scale * iou^2 <= 0, rounded to float from a double-precision value as the oracle does
+// (postprocess oracle: float32(exp(float64))).  The library's exp(double) is ~2 KB of code at EVERY inlined site - nine of them
+// in the cooperative NMS kernel, whose epoch loop then no longer sat in the instruction cache (52 KB; phase A of an epoch went
+// from 2.2 to 4.3 us when one more site was added) - and most of it is special-case handling this argument never needs.  Here:
+// k = rint(x log2 e), r = x - k ln 2 (two-part constant), Taylor polynomial of degree 13 on |r| <= 0.347 (truncation 2^-57),
+// ldexp: 17 double-precision instructions, at most 1 ulp from the library's value (tools/micro/exp_check.c: 200 M arguments
+// over the scales in use, no float result differs from glibc's).
+__device__ __forceinline__ float nms_expw(float e) {
+  if (e != e) return e;
+  const double x = fmax((double)e, -800.0);
+  const double k = rint(x * 1.4426950408889634074);
+  double r = fma(-k, 6.93147180369123816490e-01, x);
+  r = fma(-k, 1.90821492927058770002e-10, r);
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return (float)ldexp(p, (int)k);
+}
+
 struct Dec {
   float box[4];
   float sig[4];
@@ -910,7 +940,7 @@ __device__ __forceinline__ float nms_chain_eval(const NmsArgs& a, const NmsLds& 
     float w;
     if (a.soft || sim <= a.iou_thr) {
       const float e = a.scale * sim * sim;
-      w = (e == 0.0f) ? 1.0f : (float)exp((double)e);
+      w = (e == 0.0f) ? 1.0f : nms_expw(e);
     } else {
       w = 0.0f;
     }
@@ -942,7 +972,7 @@ __device__ __forceinline__ float nms_chain_eval_wave(const NmsArgs& a, NmsLds& L
       float w;
       if (a.soft || sim <= a.iou_thr) {
         const float e = a.scale * sim * sim;
-        w = (e == 0.0f) ? 1.0f : (float)exp((double)e);
+        w = (e == 0.0f) ? 1.0f : nms_expw(e);
       } else {
         w = 0.0f;
       }
@@ -1225,7 +1255,7 @@ __device__ __forceinline__ float solo_chain(const NmsArgs& a, const SoloLds& S, 
     float w;
     if (a.soft || sim <= a.iou_thr) {
       const float e = a.scale * sim * sim;
-      w = (e == 0.0f) ? 1.0f : (float)exp((double)e);
+      w = (e == 0.0f) ? 1.0f : nms_expw(e);
     } else {
       w = 0.0f;
     }
@@ -1315,7 +1345,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_solo_kernel(NmsArgs a, const float
             float w;
             if (a.soft || sim <= a.iou_thr) {
               const float e = a.scale * sim * sim;
-              w = (e == 0.0f) ? 1.0f : (float)exp((double)e);
+              w = (e == 0.0f) ? 1.0f : nms_expw(e);
             } else {
               w = 0.0f;
             }
@@ -1518,7 +1548,7 @@ __device__ __forceinline__ float chain_product(const NmsArgs& a, const RegLds& S
       float w;
       if (a.soft || sim <= a.iou_thr) {
         const float e = a.scale * sim * sim;
-        w = (e == 0.0f) ? 1.0f : (float)exp((double)e);
+        w = (e == 0.0f) ? 1.0f : nms_expw(e);
       } else {
         w = 0.0f;
       }
@@ -1561,7 +1591,7 @@ __device__ __forceinline__ float chain_wave(const NmsArgs& a, const RegLds& S, f
         const float sim = nms_iou(pb, sb);
         if (a.soft || sim <= a.iou_thr) {
           const float e = a.scale * sim * sim;
-          w = (e == 0.0f) ? 1.0f : (float)exp((double)e);
+          w = (e == 0.0f) ? 1.0f : nms_expw(e);
         } else {
           w = 0.0f;
         }
@@ -1783,6 +1813,7 @@ __device__ unsigned long long g_nms_dbg2[2];
 __device__ unsigned long long g_nms_dbg3[8];
 __device__ unsigned long long g_nms_hist[16];
 __device__ unsigned long long g_nms_win[10];     // steps that settled 1, 2, ... winners (UDA_NMS_STATS)
+__device__ unsigned long long g_nms_stepmax[128][4];   // per grid-wide step: the slowest block's A / B / C+D compute, ticks (UDA_NMS_STATS)
 #ifdef UDA_NMS_STATS
 #define NMS_STAT(slot, v) atomicAdd(&g_nms_dbg[slot], (unsigned long long)(v))
 #else
@@ -1881,7 +1912,7 @@ __device__ __forceinline__ bool coop_strict_overlap(const float* p, const float*
 template <int IPT>
 __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float* scores, unsigned long long* slots_all, int* err, int bpi, int n0, unsigned spin_max,
                                                            int wcfg) {
-  // Per candidate: the stale score in a register of its thread (scanned every epoch, candidate i0 + j * 1024 + tid), the
+  // Per candidate: the stale score in a register of its thread (scanned every epoch, candidate i0 + j * 1024 of its thread), the
   // cached exact score / upper bound in LDS (scanned every epoch, 128 KB), begin / epoch / a copy of the stale score in
   // the workspace arrays in memory (touched only when a chain is evaluated, together with the candidate's box).
   extern __shared__ float U[];                    // [IPT * 1024] | work list [COOP_LIST] | heavy list | "exact this epoch" bits | key list
@@ -1894,12 +1925,38 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
   __shared__ int wcount, hcount;
   const int n = n0 + blockIdx.x / bpi, blk = blockIdx.x % bpi, tid = threadIdx.x;   // n0: first problem of this launch
   const size_t bbase = (size_t)n * a.K;           // one problem per image (segs == 1)
-  const int i0 = blk * IPT * SOLO_T;
+  // Candidate <-> (block, slot rel = j * 1024 + tid).  Large batches (IPT > 8, a few blocks per problem): one contiguous range of
+  // IPT * 1024 candidates per block.  Small batches (IPT <= 8: tens of blocks per problem): stripes of 64 candidates (one wave)
+  // dealt round-robin to the blocks of the problem, so that the spatial neighbours of a winner - the candidates that take
+  // exact scores in phase B and are popped in phase D - are spread over all blocks and every block finishes its entries in
+  // one eight-lane pass (run_balanced).  Measured, round 5: batch 1 / 45 blocks 1.47 -> 1.36 ms with stripes; batch 32 / 8 blocks
+  // 3.5 -> 4.3 ms (every block then has entries in every phase), hence the switch on IPT.
+#ifndef UDA_NMS_STRIPE_IPT
+#define UDA_NMS_STRIPE_IPT 8
+#endif
+  constexpr bool STRIPE = IPT <= UDA_NMS_STRIPE_IPT;
+  const int istride = STRIPE ? SOLO_T * bpi : SOLO_T;
+  const int cbase = STRIPE ? 0 : blk * IPT * SOLO_T;
+  auto gidx = [&](int rel) {
+    if constexpr (STRIPE) { const int t = rel & (SOLO_T - 1); return (rel >> 10) * istride + ((t >> 6) * bpi + blk) * 64 + (t & 63); }
+    else return cbase + rel;
+  };
+  auto rel_of = [&](int i) {                    // (STRIPE: -1 = not this block's candidate)
+    if constexpr (STRIPE) {
+      const int st = i >> 6, q = st / bpi;
+      if (st - q * bpi != blk) return -1;
+      return (q >> 4) * SOLO_T + (q & 15) * 64 + (i & 63);
+    } else {
+      return i - cbase;
+    }
+  };
+  static_assert(SOLO_T == 1024, "the stripe mapping is written for 16 waves per block");
+  const int i0 = gidx(tid);                     // this thread's first candidate; slot j: i0 + j * istride
   unsigned long long* slots = slots_all + (size_t)n * a.M * (1 + COOP_W) * bpi;      // [step][bound: bpi | winners: bpi x COOP_W]
   float st[IPT];
 #pragma unroll
   for (int j = 0; j < IPT; ++j) {
-    const int i = i0 + j * SOLO_T + tid;
+    const int i = i0 + j * istride;
     float v = -INFINITY;
     if (i < a.K) {
       const float s = scores[bbase + i];
@@ -1960,7 +2017,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
       int b = k + t;
       if (POPS) {
         for (int u = t + 1; u < nw && v != -INFINITY; ++u) {
-          if (nms_key(v, i0 + rel) > X.top[u]) {
+          if (nms_key(v, gidx(rel)) > X.top[u]) {
             v = reg_chain(a, S, v, b, bx, k + u);
             b = k + u;
           }
@@ -1974,12 +2031,13 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
     auto one = [&](int rel) {
       const bool cached = (ebits[rel >> 5] >> (rel & 31)) & 1u;
       if (!POPS && cached) { fn(rel, U[rel]); return; }
-      const size_t g = bbase + i0 + rel;
+      const int gi = gidx(rel);
+      const size_t g = bbase + gi;
       const int begin = a.begin[g];
       const float stale = a.stale[g];
       const float4 b4 = *(const float4*)(a.boxes + g * 4);
       const float bx[4] = {b4.x, b4.y, b4.z, b4.w};
-      const int t = POPS ? first_pop(stale, i0 + rel) : 0;
+      const int t = POPS ? first_pop(stale, gi) : 0;
       const int kk = k + t;
       float v = stale;
       if (POPS && t == 0 && cached) {
@@ -1997,11 +2055,105 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
       if (!POPS) atomicOr(&ebits[rel >> 5], 1u << (rel & 31));
       fn(rel, v);
     };
-    for (int e = tid; e < cnt; e += SOLO_T) one(wlist[e]);
-    while (left) {
-      const int j = __ffs((int)left) - 1;
-      left &= left - 1u;
-      one(j * SOLO_T + tid);
+    // Few entries (the usual case: a handful per block and phase): EIGHT lanes per entry.  The interval test over the links
+    // begin .. kk-1 - up to 100 LDS reads and compares in a row for a candidate that was never evaluated, the longest
+    // single-thread stretch of an epoch (slowest block of a step 7-8 us in B and in D at batch 1, mean 3) - is spread over
+    // the lanes of the group, eight links per pass; a wave ballot hands every group its byte of overlap bits.  The rest of
+    // the entry (product over the few overlapping links, stores) is done by the group's first lane, exactly as below.
+    // (The product spread over the group's lanes as well - a weight per lane, then the product in link order, no heavy list -
+    // was measured in the same job: batch 1 / 4 / 8 1.42 / 1.42 / 1.58 ms against 1.40 / 1.40 / 1.59 without; not kept.)
+    // Many entries (pops with short chains): one thread per entry as before - the same arithmetic either way.
+    constexpr int GL = 8;
+    if (cnt <= 2 * (SOLO_T / GL)) {
+      const int lane = tid & 63, sub = tid & (GL - 1);
+      const bool sparse = a.soft || a.iou_thr >= 0.f;
+      for (int e0 = 0; e0 < cnt; e0 += SOLO_T / GL) {
+        const int e = e0 + tid / GL;
+        const bool valid = e < cnt;
+        const int rel = valid ? wlist[e] : 0;
+        bool cached = false, domask = false, plain = false;
+        int gi = 0, begin = 0, t = 0, kk = 0;
+        size_t g = 0;
+        float stale = 0.f, bx[4] = {0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+          cached = (ebits[rel >> 5] >> (rel & 31)) & 1u;
+          plain = !POPS && cached;
+          if (!plain) {
+            gi = gidx(rel);
+            g = bbase + gi;
+            begin = a.begin[g];
+            stale = a.stale[g];
+            const float4 b4 = *(const float4*)(a.boxes + g * 4);
+            bx[0] = b4.x; bx[1] = b4.y; bx[2] = b4.z; bx[3] = b4.w;
+            t = POPS ? first_pop(stale, gi) : 0;
+            kk = k + t;
+            domask = !(POPS && t == 0 && cached) && kk > begin;
+          }
+        }
+        unsigned long long m[2] = {0ull, 0ull};
+        {
+          const float y0 = fminf(bx[0], bx[2]), x0 = fminf(bx[1], bx[3]), y1 = fmaxf(bx[0], bx[2]), x1 = fmaxf(bx[1], bx[3]);
+          const int npass = domask ? (kk - begin + GL - 1) / GL : 0;
+          for (int it = 0; __ballot(it < npass) != 0ull; ++it) {       // (wave-uniform trip count: the longest chain of the wave)
+            const int j = begin + it * GL + sub;
+            bool ov = false;
+            if (it < npass && j < kk) {
+              if (sparse) {
+                const float4 sb = *(const float4*)(S.sel + 4 * j);
+                const float sy0 = fminf(sb.x, sb.z), sx0 = fminf(sb.y, sb.w), sy1 = fmaxf(sb.x, sb.z), sx1 = fmaxf(sb.y, sb.w);
+                ov = (fminf(y1, sy1) > fmaxf(y0, sy0)) && (fminf(x1, sx1) > fmaxf(x0, sx0));
+              } else {
+                ov = true;
+              }
+            }
+            const unsigned long long bal = __ballot(ov);
+            const unsigned long long byte = (bal >> (lane & ~(GL - 1))) & 0xffull;     // this group's links begin + 8 it .. + 7
+            if (byte) {
+              const int pos = begin + it * GL;                       // < 128 (M <= 128)
+              if (pos < 64) {
+                m[0] |= byte << pos;
+                if (pos > 56) m[1] |= byte >> (64 - pos);
+              } else {
+                m[1] |= byte << (pos - 64);
+              }
+            }
+          }
+        }
+        if (valid && sub == 0) {
+          if (plain) {
+            fn(rel, U[rel]);
+          } else {
+            float v = stale;
+            bool heavy = false;
+            if (POPS && t == 0 && cached) {
+              v = U[rel];
+            } else if (kk > begin) {
+              if (__popcll(m[0]) + __popcll(m[1]) > COOP_HEAVY_LINKS) {
+                const int pos = atomicAdd(&hcount, 1);
+                if (pos < COOP_HEAVY) { hlist[pos] = rel; heavy = true; }
+              }
+              if (!heavy) v = chain_product(a, S, stale, bx, m);
+            }
+            if (!heavy) {
+              v = later_pops(rel, g, v, t, bx);
+              if (!POPS) atomicOr(&ebits[rel >> 5], 1u << (rel & 31));
+              fn(rel, v);
+            }
+          }
+        }
+      }
+    }
+    // one thread per entry: long lists, and the entries that did not fit the list (they stay with their owners).  (ONE loop, so
+    // that the entry code exists once per phase: the epoch loop is 50 KB of instructions as it is.)
+    {
+      int e = (cnt <= 2 * (SOLO_T / GL)) ? cnt : tid;
+      for (;;) {
+        int rel;
+        if (e < cnt) { rel = wlist[e]; e += SOLO_T; }
+        else if (left) { const int j = __ffs((int)left) - 1; left &= left - 1u; rel = j * SOLO_T + tid; }
+        else break;
+        one(rel);
+      }
     }
     __syncthreads();
 #ifdef UDA_NMS_STATS
@@ -2016,11 +2168,12 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
     }
     for (int e = tid >> 6; e < hc; e += SOLO_T / 64) {
       const int rel = hlist[e];
-      const size_t g = bbase + i0 + rel;
+      const int gi = gidx(rel);
+      const size_t g = bbase + gi;
       const float4 b4 = *(const float4*)(a.boxes + g * 4);
       const float bx[4] = {b4.x, b4.y, b4.z, b4.w};
       const float stale = a.stale[g];
-      const int t = POPS ? first_pop(stale, i0 + rel) : 0;
+      const int t = POPS ? first_pop(stale, gi) : 0;
       float v = chain_wave(a, S, stale, a.begin[g], bx, k + t);
       if ((tid & 63) == 0) {
         v = later_pops(rel, g, v, t, bx);
@@ -2039,7 +2192,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
   for (int step = 0; k < a.M; ++step) {
     // (the candidate index is rebuilt from an opaque base in every epoch: otherwise the per-candidate index words and
     // addresses of all IPT candidates are hoisted out of the epoch loop and spill)
-    int ib = i0 + tid;
+    int ib = i0;
     asm volatile("" : "+v"(ib));
     unsigned long long* sslots = slots + (size_t)step * (1 + COOP_W) * bpi;
 #ifdef UDA_NMS_STATS
@@ -2059,7 +2212,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
           if (o >= bo) { bo = o; bj = j; }      // descending j with >=: the smallest index wins a tie
         }
       }
-      if (bo != 0u) bk = ((unsigned long long)bo << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)(ib + bj * SOLO_T));
+      if (bo != 0u) bk = ((unsigned long long)bo << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)(ib + bj * istride));
     }
     bk = reg_max(S, bk);
 
@@ -2072,8 +2225,9 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
       const float pb[4] = {b4.x, b4.y, b4.z, b4.w};
       const float score = chain_wave(a, S, stale0, begin, pb, k);
       if (tid == 0) {
-        U[bi - i0] = score;
-        atomicOr(&ebits[(bi - i0) >> 5], 1u << ((bi - i0) & 31));
+        const int br = rel_of(bi);
+        U[br] = score;
+        atomicOr(&ebits[br >> 5], 1u << (br & 31));
         X.mine[0] = (score != -INFINITY) ? nms_key(score, bi) : 0ull;
       }
     }
@@ -2108,13 +2262,13 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
         const float u = U[j * SOLO_T + tid];
         if (st[j] != -INFINITY && u != -INFINITY) {
           const uint32_t o = ord32(u);
-          if (o > bdo || (o == bdo && 0xFFFFFFFFu - (uint32_t)(ib + j * SOLO_T) >= bdl)) need |= 1u << j;
+          if (o > bdo || (o == bdo && 0xFFFFFFFFu - (uint32_t)(ib + j * istride) >= bdl)) need |= 1u << j;
         }
       }
     }
     run_balanced(need, k, 1, std::false_type{}, [&](int rel, float v) {
       if (v != -INFINITY) {
-        const unsigned long long key = nms_key(v, i0 + rel);
+        const unsigned long long key = nms_key(v, gidx(rel));
         ke = key > ke ? key : ke;
         if (weff > 1 && key >= bd) {         // ranked below for this block's contribution
           const int pos = atomicAdd(&X.kcount, 1);
@@ -2184,7 +2338,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
       unsigned wmask = 0u;                  // this thread's candidates among the winners
       for (int t = 0; t < nw; ++t) {
         const int widx = (int)(0xFFFFFFFFu - (uint32_t)X.top[t]);
-        const int rel = widx - i0;
+        const int rel = rel_of(widx);
         if (rel >= 0 && rel < IPT * SOLO_T && (rel % SOLO_T) == tid) {
           const size_t o = (size_t)n * a.M + k + t;
           a.sel_idx[o] = widx;
@@ -2202,7 +2356,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
         if ((wmask >> j) & 1u) st[j] = -INFINITY;
         if (st[j] != -INFINITY) {
           const uint32_t o = ord32(st[j]);
-          if (o > wo || (o == wo && 0xFFFFFFFFu - (uint32_t)(ib + j * SOLO_T) > wl)) pops |= 1u << j;
+          if (o > wo || (o == wo && 0xFFFFFFFFu - (uint32_t)(ib + j * istride) > wl)) pops |= 1u << j;
         }
       }
     }
@@ -2219,6 +2373,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
       const unsigned long long t5 = wall_clock64();
       NMS_STAT(4, t1 - t0); NMS_STAT(5, t2 - t1); NMS_STAT(6, t3 - t2); NMS_STAT(7, t4 - t3);
       atomicAdd(&g_nms_dbg2[0], t5 - t4); atomicAdd(&g_nms_dbg2[1], 1ull);
+      if (step < 128) { atomicMax(&g_nms_stepmax[step][0], t1 - t0); atomicMax(&g_nms_stepmax[step][1], t3 - t2); atomicMax(&g_nms_stepmax[step][2], t5 - t4); }
       {
         const unsigned long long te = t5 - t0;        // whole step of this block, 10 ns ticks
         int bkt = 0;
@@ -2377,6 +2532,15 @@ int launch_nms_coop(const NmsArgs& a, const float* scores, unsigned long long* s
     hipMemcpyFromSymbol(h3, HIP_SYMBOL(g_nms_dbg3), sizeof(h3));
     if (h2[1]) fprintf(stderr, "[uda] nms lists per block-phase: entries mean %.1f max %llu, heavy mean %.1f max %llu; stage1 mean %.1f max %llu, stage2 mean %.1f max %llu ticks\n",
                        (double)h3[0] / (2 * h2[1]), h3[1], (double)h3[2] / (2 * h2[1]), h3[3], (double)h3[4] / (2 * h2[1]), h3[5], (double)h3[6] / (2 * h2[1]), h3[7]);
+    {
+      static unsigned long long sm[128][4];
+      hipMemcpyFromSymbol(sm, HIP_SYMBOL(g_nms_stepmax), sizeof(sm));
+      double sa = 0, sb = 0, sc = 0; int ns = 0;
+      for (int i = 0; i < 128; ++i) if (sm[i][0] | sm[i][1] | sm[i][2]) { sa += sm[i][0]; sb += sm[i][1]; sc += sm[i][2]; ++ns; }
+      if (ns) fprintf(stderr, "[uda] nms slowest block per step (this launch and earlier ones, max), mean over %d steps in 10 ns ticks: A %.1f B %.1f C+D %.1f\n", ns, sa / ns, sb / ns, sc / ns);
+      static unsigned long long zero[128][4];
+      hipMemcpyToSymbol(HIP_SYMBOL(g_nms_stepmax), zero, sizeof(zero));
+    }
     if (h2[1]) fprintf(stderr, "[uda] nms phases, mean per block-epoch in 10 ns ticks: A %.1f bar1 %.1f B %.1f bar2 %.1f C %.1f (%llu block-epochs)\n",
                        (double)h[4] / h2[1], (double)h[5] / h2[1], (double)h[6] / h2[1], (double)h[7] / h2[1], (double)h2[0] / h2[1], h2[1]);
   }
