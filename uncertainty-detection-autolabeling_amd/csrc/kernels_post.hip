@@ -75,36 +75,6 @@ void launch_preprocess(const PreprocArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------ aggregate + decode
 __device__ __forceinline__ float exp32(float x) { return (float)exp((double)x); }
 
-// The soft-NMS weight exp(e), e = scale * iou^2 <= 0, rounded to float from a double-precision value as the oracle does
-// (postprocess oracle: float32(exp(float64))).  The library's exp(double) is ~2 KB of code at EVERY inlined site - nine of them
-// in the cooperative NMS kernel, whose epoch loop then no longer sat in the instruction cache (52 KB; phase A of an epoch went
-// from 2.2 to 4.3 us when one more site was added) - and most of it is special-case handling this argument never needs.  Here:
-// k = rint(x log2 e), r = x - k ln 2 (two-part constant), Taylor polynomial of degree 13 on |r| <= 0.347 (truncation 2^-57),
-// ldexp: 17 double-precision instructions, at most 1 ulp from the library's value (tools/micro/exp_check.c: 200 M arguments
-// over the scales in use, no float result differs from glibc's).
-__device__ __forceinline__ float nms_expw(float e) {
-  if (e != e) return e;
-  const double x = fmax((double)e, -800.0);
-  const double k = rint(x * 1.4426950408889634074);
-  double r = fma(-k, 6.93147180369123816490e-01, x);
-  r = fma(-k, 1.90821492927058770002e-10, r);
-  double p = 1.0 / 6227020800.0;
-  p = fma(p, r, 1.0 / 479001600.0);
-  p = fma(p, r, 1.0 / 39916800.0);
-  p = fma(p, r, 1.0 / 3628800.0);
-  p = fma(p, r, 1.0 / 362880.0);
-  p = fma(p, r, 1.0 / 40320.0);
-  p = fma(p, r, 1.0 / 5040.0);
-  p = fma(p, r, 1.0 / 720.0);
-  p = fma(p, r, 1.0 / 120.0);
-  p = fma(p, r, 1.0 / 24.0);
-  p = fma(p, r, 1.0 / 6.0);
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  return (float)ldexp(p, (int)k);
-}
-
 struct Dec {
   float box[4];
   float sig[4];
@@ -940,7 +910,7 @@ __device__ __forceinline__ float nms_chain_eval(const NmsArgs& a, const NmsLds& 
     float w;
     if (a.soft || sim <= a.iou_thr) {
       const float e = a.scale * sim * sim;
-      w = (e == 0.0f) ? 1.0f : nms_expw(e);
+      w = (e == 0.0f) ? 1.0f : (float)exp((double)e);
     } else {
       w = 0.0f;
     }
@@ -972,7 +942,7 @@ __device__ __forceinline__ float nms_chain_eval_wave(const NmsArgs& a, NmsLds& L
       float w;
       if (a.soft || sim <= a.iou_thr) {
         const float e = a.scale * sim * sim;
-        w = (e == 0.0f) ? 1.0f : nms_expw(e);
+        w = (e == 0.0f) ? 1.0f : (float)exp((double)e);
       } else {
         w = 0.0f;
       }
@@ -1255,7 +1225,7 @@ __device__ __forceinline__ float solo_chain(const NmsArgs& a, const SoloLds& S, 
     float w;
     if (a.soft || sim <= a.iou_thr) {
       const float e = a.scale * sim * sim;
-      w = (e == 0.0f) ? 1.0f : nms_expw(e);
+      w = (e == 0.0f) ? 1.0f : (float)exp((double)e);
     } else {
       w = 0.0f;
     }
@@ -1345,7 +1315,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_solo_kernel(NmsArgs a, const float
             float w;
             if (a.soft || sim <= a.iou_thr) {
               const float e = a.scale * sim * sim;
-              w = (e == 0.0f) ? 1.0f : nms_expw(e);
+              w = (e == 0.0f) ? 1.0f : (float)exp((double)e);
             } else {
               w = 0.0f;
             }
@@ -1548,7 +1518,7 @@ __device__ __forceinline__ float chain_product(const NmsArgs& a, const RegLds& S
       float w;
       if (a.soft || sim <= a.iou_thr) {
         const float e = a.scale * sim * sim;
-        w = (e == 0.0f) ? 1.0f : nms_expw(e);
+        w = (e == 0.0f) ? 1.0f : (float)exp((double)e);
       } else {
         w = 0.0f;
       }
@@ -1591,7 +1561,7 @@ __device__ __forceinline__ float chain_wave(const NmsArgs& a, const RegLds& S, f
         const float sim = nms_iou(pb, sb);
         if (a.soft || sim <= a.iou_thr) {
           const float e = a.scale * sim * sim;
-          w = (e == 0.0f) ? 1.0f : nms_expw(e);
+          w = (e == 0.0f) ? 1.0f : (float)exp((double)e);
         } else {
           w = 0.0f;
         }
@@ -2055,15 +2025,18 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
       if (!POPS) atomicOr(&ebits[rel >> 5], 1u << (rel & 31));
       fn(rel, v);
     };
-    // Few entries (the usual case: a handful per block and phase): EIGHT lanes per entry.  The interval test over the links
+    // Few entries (the usual case: a handful per block and phase): GL = SIXTEEN lanes per entry.  The interval test over the links
     // begin .. kk-1 - up to 100 LDS reads and compares in a row for a candidate that was never evaluated, the longest
     // single-thread stretch of an epoch (slowest block of a step 7-8 us in B and in D at batch 1, mean 3) - is spread over
-    // the lanes of the group, eight links per pass; a wave ballot hands every group its byte of overlap bits.  The rest of
+    // the lanes of the group, GL links per pass; a wave ballot hands every group its GL overlap bits.  The rest of
     // the entry (product over the few overlapping links, stores) is done by the group's first lane, exactly as below.
     // (The product spread over the group's lanes as well - a weight per lane, then the product in link order, no heavy list -
     // was measured in the same job: batch 1 / 4 / 8 1.42 / 1.42 / 1.58 ms against 1.40 / 1.40 / 1.59 without; not kept.)
     // Many entries (pops with short chains): one thread per entry as before - the same arithmetic either way.
-    constexpr int GL = 8;
+#ifndef UDA_NMS_GL
+#define UDA_NMS_GL 16     // (A/B in one job, batch 1 / 4 / 8 NMS ms: 4 lanes 1.49 / 1.50 / 1.59, 8: 1.40 / 1.39 / 1.51, 16: 1.36 / 1.35 / 1.45, 32: 1.34 / 1.34 / 1.47)
+#endif
+    constexpr int GL = UDA_NMS_GL;          // lanes per entry (a power of two <= 32)
     if (cnt <= 2 * (SOLO_T / GL)) {
       const int lane = tid & 63, sub = tid & (GL - 1);
       const bool sparse = a.soft || a.iou_thr >= 0.f;
@@ -2107,12 +2080,12 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
               }
             }
             const unsigned long long bal = __ballot(ov);
-            const unsigned long long byte = (bal >> (lane & ~(GL - 1))) & 0xffull;     // this group's links begin + 8 it .. + 7
+            const unsigned long long byte = (bal >> (lane & ~(GL - 1))) & ((1ull << GL) - 1ull);     // this group's links begin + GL it .. + GL - 1
             if (byte) {
               const int pos = begin + it * GL;                       // < 128 (M <= 128)
               if (pos < 64) {
                 m[0] |= byte << pos;
-                if (pos > 56) m[1] |= byte >> (64 - pos);
+                if (pos > 64 - GL) m[1] |= byte >> (64 - pos);
               } else {
                 m[1] |= byte << (pos - 64);
               }
