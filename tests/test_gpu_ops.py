@@ -143,3 +143,60 @@ def test_fp16_pieces_report_an_operand_above_65504():
     got, _ = _run(x, w, None, None, None, None, None, None, 1, 0, 6)          # three bf16 pieces: float32's exponent range
     want = _ref(x, w, None, None, None, None, None, None, 1, False)
     assert np.abs(got - want).max() <= TOL[6] * np.abs(want).max()
+
+
+# ---- few pixels x many input channels: pws_kernel (one wave per tile, operands straight into registers) must be the SAME
+# function as pwb_kernel bit for bit - a serve of one image equals the same image inside a batch of 32 because of it
+SKINNY_WORKER = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import test_gpu_ops as T
+out = {}
+for i, (rows_in, in_div, hw, cin, cout, flags, terms) in enumerate(%(cases)r):
+    f = set(flags.split(",")) if flags else set()
+    rng = np.random.default_rng(100 + i)
+    rows = rows_in * in_div
+    x = rng.normal(0, 1, (rows_in, hw, cin)).astype(np.float32)
+    w = (rng.normal(0, 1, (cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    bias = rng.normal(0, 0.5, cout).astype(np.float32) if "bias" in f else None
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32) if "bn" in f else None
+    sh = rng.normal(0, 0.3, cout).astype(np.float32) if "bn" in f else None
+    se = rng.uniform(0.1, 1.0, (rows_in, cin)).astype(np.float32) if "se" in f else None
+    mask = ((rng.uniform(0, 1, (rows, cout)) >= 0.1) / 0.9).astype(np.float32) if "mask" in f else None
+    res = rng.normal(0, 1, (rows, hw, cout)).astype(np.float32) if "res" in f else None
+    got, ms = T._run(x, w, bias, sc, sh, se, mask, res, in_div, int("act" in f), terms, reps=20)
+    out["y%%d" %% i] = got
+    out["ms%%d" %% i] = np.float32(ms)
+np.savez(%(dst)r, **out)
+"""
+
+SKINNY_CASES = [
+    (1, 1, 960, 1152, 192, "bn,se,res", 16),      # blocks 12-14 projection of ONE image (24 x 40), head-only MC: rows = 1
+    (1, 1, 960, 1152, 320, "bn,se", 16),          # block 15
+    (1, 1, 960, 672, 192, "bn,se", 16),           # block 11: 42 k-steps = 10 groups + 2
+    (1, 1, 3840, 672, 112, "bn,se,res", 16),      # blocks 9-10 (48 x 80): two column tiles per wave
+    (1, 1, 3840, 480, 80, "bn,se,res,mask", 16),
+    (2, 2, 333, 288, 63, "bias,act,mask", 16),    # ragged rows / columns, shared input rows
+    (1, 1, 960, 1152, 192, "bn,se,res", 6),
+    (1, 1, 960, 1152, 192, "bn,se,res", 3),
+    (1, 3, 100, 256, 40, "bn,res", 16),           # KS = 16: four whole groups, none left
+    (1, 1, 64, 272, 24, "bn", 16),                # KS = 17: four groups + 1
+]
+
+
+def test_skinny_pointwise_kernel_is_bit_identical_to_the_tiled_one(tmp_path):
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("60000", "0"):
+        dst = str(tmp_path / ("pw_%s.npz" % mode))
+        env = dict(os.environ, UDA_PW_SKINNY=mode)
+        r = subprocess.run([sys.executable, "-c", SKINNY_WORKER % dict(root=root, cases=SKINNY_CASES, dst=dst)], env=env, cwd=root,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[mode] = np.load(dst)
+    for i, c in enumerate(SKINNY_CASES):
+        a, b = res["60000"]["y%d" % i], res["0"]["y%d" % i]
+        assert np.isfinite(a).all()
+        np.testing.assert_array_equal(a, b, err_msg=str(c))
+        print("case %s: skinny %.1f us, tiled %.1f us" % (c, 1e3 * float(res["60000"]["ms%d" % i]), 1e3 * float(res["0"]["ms%d" % i])))

@@ -408,6 +408,151 @@ __global__ __launch_bounds__(256, 3) void pwb_shared_kernel(PwArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- 1x1 convolution, few pixels x many input channels
+// A projection at the bottom of the backbone in a serve of ONE image under head-only MC dropout (the reference's shipped
+// inference configuration): 960 pixels x 1152 -> 192 channels.  pwb_kernel covers that with 16 blocks that each walk 36 chunks,
+// one (DEEP: two) memory round trips at a time - 55 us for 0.4 GFLOP, a chain of latencies on an empty device
+// (profiles/r05_batch1_headonly_per_op.txt).  A split over K would fill the device but change the float32 summation order with
+// the number of rows; this kernel keeps the order - the same cross terms, k-step after k-step, into the same accumulator
+// layout, hence results bit-identical to pwb_kernel's - and shortens the chain instead: one WAVE per 32-pixel x (32 NT)-channel
+// tile, no LDS, no barrier; the wave reads its operand fragments straight into registers (lane = pixel, 8 consecutive
+// channels; weight fragments as packed on the host) and keeps PWS_D k-steps on their way while it multiplies the PWS_D before.
+// The input tile is re-read by every column tile (through the L2): only for launches of a few thousand pixels (launch_pws).
+#ifndef UDA_PWS_D
+#define UDA_PWS_D 4
+#endif
+constexpr int PWS_D = UDA_PWS_D;
+template <int PARTS, int NT, bool GATE>
+__global__ __launch_bounds__(64) void pws_kernel(PwArgs a) {
+  constexpr int NPC = split_np(PARTS);
+  const int lane = threadIdx.x, li = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * 32, nt0 = blockIdx.y * NT;
+  const int b = blockIdx.z, b_in = b / a.in_div;
+  const int KS = a.Cin >> 4;                 // (launcher: Cin % 16 == 0, KS >= PWS_D)
+  const int NTL = (a.Cout + 31) >> 5;
+  const int mr = m0 + li < a.HW ? m0 + li : a.HW - 1;       // (rows past the map: row m of A only reaches row m of the result, never stored)
+  const float* arow = a.in + ((size_t)b_in * a.HW + mr) * a.Cin + 8 * lh;
+  const float* se = GATE ? a.se + (size_t)(b / a.se_div) * a.Cin + 8 * lh : nullptr;
+  const uint4* Wp = (const uint4*)a.wsplit + lane;
+  size_t woff[NT];                           // (a column tile past the end repeats the last one; not stored)
+#pragma unroll
+  for (int n = 0; n < NT; ++n) woff[n] = (size_t)(nt0 + n < NTL ? nt0 + n : NTL - 1) * NPC * 64;
+  const size_t wks = (size_t)NTL * NPC * 64;       // uint4 per k-step of the packed weights
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+  float amax = 0.f;
+
+  struct Step { float4 a0, a1, g0, g1; uint4 w[NT][NPC]; };
+  struct Group { Step s[PWS_D]; };
+  // plain, unconditional loads (a load under a condition gets a basic block of its own and a vmcnt(0) at its first use)
+  auto load_step = [&](int ks, Step& t) {
+    t.a0 = *(const float4*)(arow + 16 * ks);
+    t.a1 = *(const float4*)(arow + 16 * ks + 4);
+    if constexpr (GATE) {
+      t.g0 = *(const float4*)(se + 16 * ks);
+      t.g1 = *(const float4*)(se + 16 * ks + 4);
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int p = 0; p < NPC; ++p) t.w[n][p] = Wp[(size_t)ks * wks + woff[n] + p * 64];
+  };
+  auto mma_step = [&](const Step& t) {
+    float4 v0 = t.a0, v1 = t.a1;
+    if constexpr (GATE) {
+      v0.x *= t.g0.x; v0.y *= t.g0.y; v0.z *= t.g0.z; v0.w *= t.g0.w;
+      v1.x *= t.g1.x; v1.y *= t.g1.y; v1.z *= t.g1.z; v1.w *= t.g1.w;
+    }
+    bf16x8 af[NPC];
+    split_parts<PARTS>(v0, v1, af, amax);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      bf16x8 bf[NPC];
+#pragma unroll
+      for (int p = 0; p < NPC; ++p) bf[p] = __builtin_bit_cast(bf16x8, t.w[n][p]);
+      acc[n] = mfma_terms<PARTS>(af, bf, acc[n]);
+    }
+  };
+  auto load_group = [&](int g, Group& G) {
+#pragma unroll
+    for (int d = 0; d < PWS_D; ++d) load_step(g * PWS_D + d, G.s[d]);
+  };
+  auto mma_group = [&](const Group& G) {
+#pragma unroll
+    for (int d = 0; d < PWS_D; ++d) mma_step(G.s[d]);
+  };
+  // whole groups of PWS_D k-steps, two sets of registers: the group after next is requested before the current one is
+  // multiplied (a group index past the end reloads the last whole group - never multiplied); then the k-steps that are left
+  const int ng = KS / PWS_D;
+  Group c0, c1;
+  load_group(0, c0);
+  load_group(ng > 1 ? 1 : 0, c1);
+#pragma unroll 1
+  for (int g = 0; g < ng; g += 2) {
+    mma_group(c0);
+    load_group(g + 2 < ng ? g + 2 : ng - 1, c0);
+    if (g + 1 < ng) mma_group(c1);          // (uniform)
+    load_group(g + 3 < ng ? g + 3 : ng - 1, c1);
+  }
+#pragma unroll 1
+  for (int ks = ng * PWS_D; ks < KS; ++ks) {
+    Step t;
+    load_step(ks, t);
+    mma_step(t);
+  }
+  split_report<PARTS>(amax, a.oor);
+
+  // epilogue: lane holds column li of 16 rows (the arithmetic of pwb_kernel's epilogues, element by element)
+  const size_t out_base = (size_t)b * a.HW;
+  const float un = a.wunscale;
+  const size_t res_base = a.res ? (size_t)(b / a.res_div) * a.HW : 0;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int col = (nt0 + n) * 32 + li;
+    if (nt0 + n >= NTL || col >= a.Cout) continue;
+    const float bias = a.bias ? a.bias[col] : 0.f;
+    const float sc = a.bn_scale ? a.bn_scale[col] : 1.f;
+    const float sh = a.bn_scale ? a.bn_shift[col] : 0.f;
+    const float mk = a.mask ? a.mask[(size_t)b * a.Cout + col] : 1.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= a.HW) continue;
+      float v = fmaf(acc[n][r], un, bias);
+      v = fmaf(v, sc, sh);
+      if (a.act == UDA_ACT_SWISH) v = swishf_b(v);
+      else if (a.act >= UDA_ACT_RELU) v = act_relu_family(v, a.act);
+      v *= mk;
+      if (a.res) v += a.res[(res_base + m) * a.Cout + col];
+      a.out[(out_base + m) * a.Cout + col] = v;
+    }
+  }
+}
+
+// few pixels x many input channels -> pws_kernel (see there); 0 = not its case
+static int launch_pws(const PwArgs& a, int rows, hipStream_t s) {
+  // Where it pays (tools/debug/pw_skinny_sweep.py, us, skinny / tiled): 960 px 1152 -> 192: 17 / 52; 3840 px 672 -> 112: 16 / 32;
+  // 9600 px 1152 -> 192: 48 / 56; 9600 px 1152 -> 320: 90 / 56; 38400 px 672 -> 112: 88 / 44 - every column tile re-reads the
+  // input tile, so the measure is pixels x column tiles.  UDA_PW_SKINNY = that product up to which it is used (0 = never).
+  static long long max_work = -1;
+  if (max_work < 0) { const char* e = getenv("UDA_PW_SKINNY"); max_work = e ? atoll(e) : 60000; }
+  if ((long long)rows * a.HW * ((a.Cout + 31) / 32) > max_work || a.Cin < 256 || (a.Cin & 15) || !a.wsplit || a.wparts == UDA_SPLIT_NONE) return 0;
+  const int row_tiles = (a.HW + 31) / 32, NTL = (a.Cout + 31) / 32;
+  // one column tile per wave while that still leaves fewer waves than the device has SIMDs, two otherwise
+  const int nt = ((long long)row_tiles * rows * NTL <= 1024) ? 1 : 2;
+  const dim3 grid(row_tiles, (NTL + nt - 1) / nt, rows), block(64);
+  auto go = [&](auto k1, auto k2) { if (nt == 1) hipLaunchKernelGGL(k1, grid, block, 0, s, a); else hipLaunchKernelGGL(k2, grid, block, 0, s, a); };
+  if (a.wparts == UDA_SPLIT_F16X2) { if (a.se) go(pws_kernel<4, 1, true>, pws_kernel<4, 2, true>); else go(pws_kernel<4, 1, false>, pws_kernel<4, 2, false>); }
+  else if (a.wparts == UDA_SPLIT_BF16X3) { if (a.se) go(pws_kernel<3, 1, true>, pws_kernel<3, 2, true>); else go(pws_kernel<3, 1, false>, pws_kernel<3, 2, false>); }
+  else if (a.wparts == UDA_SPLIT_BF16X2) { if (a.se) go(pws_kernel<2, 1, true>, pws_kernel<2, 2, true>); else go(pws_kernel<2, 1, false>, pws_kernel<2, 2, false>); }
+  else return 0;
+  return 1;
+}
+
 template <int MT, int NT, int WM, int WN>
 static void launch_pwb_cfg(const PwArgs& a, int rows, hipStream_t s) {
   constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
@@ -435,6 +580,7 @@ void launch_pwb(const PwArgs& a, int rows, hipStream_t s) {
     hipLaunchKernelGGL(pwb_shared_kernel, grid, dim3(256), 0, s, a);
     return;
   }
+  if (launch_pws(a, rows, s)) return;
   static int force = -1;
   if (force < 0) { const char* e = getenv("UDA_PWB_CFG"); force = e ? atoi(e) : 0; }
   static int wide = -1;
