@@ -1469,12 +1469,28 @@ struct RegLds {
   int pbegin;
 };
 
+// Maximum of a 64-bit key over the 64 lanes of a wave, in every lane: two 32-bit DPP reductions (row_shr 1 / 2 / 4 / 8, row_bcast
+// 15 / 31 - seven instructions each, no LDS traffic; a __shfl_xor ladder is six dependent ds_bpermute round trips per word):
+// the high word (ordered score) first, then the low word (~index) among the lanes that hold the maximal high word.
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  unsigned t;
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); v = t > v ? t : v;   // row_shr:1
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); v = t > v ? t : v;   // row_shr:2
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, false); v = t > v ? t : v;   // row_shr:4, banks 1-3
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, false); v = t > v ? t : v;   // row_shr:8, banks 2-3
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); v = t > v ? t : v;   // row_bcast:15, rows 1 and 3
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); v = t > v ? t : v;   // row_bcast:31, rows 2 and 3
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned long long wave_max_key(unsigned long long k) {
+  const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
+  const unsigned mh = wave_max_u32(hi);
+  const unsigned ml = wave_max_u32(hi == mh ? lo : 0u);
+  return ((unsigned long long)mh << 32) | ml;
+}
+
 __device__ __forceinline__ unsigned long long reg_max(RegLds& S, unsigned long long v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const unsigned long long o = __shfl_xor(v, off, 64);
-    v = o > v ? o : v;
-  }
+  v = wave_max_key(v);          // (DPP: 14 instructions; the __shfl_xor ladder was 12 dependent ds_bpermute round trips, twice per epoch)
   __syncthreads();
   if ((threadIdx.x & 63) == 0) S.red[threadIdx.x >> 6] = v;
   __syncthreads();
@@ -1758,26 +1774,6 @@ void launch_nms_reg(const NmsArgs& a, const float* scores, hipStream_t s) {
 // after a fenced barrier missed).  The spin is bounded: a time-out raises *err and every later step falls through.
 constexpr int COOP_MAX_BPI = 64;     // blocks per problem: one exchange slot per lane of the polling wave
 
-// Maximum of a 64-bit key over the 64 lanes of a wave, in every lane: two 32-bit DPP reductions (row_shr 1 / 2 / 4 / 8, row_bcast
-// 15 / 31 - seven instructions each, no LDS traffic; a __shfl_xor ladder is six dependent ds_bpermute round trips per word):
-// the high word (ordered score) first, then the low word (~index) among the lanes that hold the maximal high word.
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-  unsigned t;
-  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); v = t > v ? t : v;   // row_shr:1
-  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); v = t > v ? t : v;   // row_shr:2
-  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, false); v = t > v ? t : v;   // row_shr:4, banks 1-3
-  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, false); v = t > v ? t : v;   // row_shr:8, banks 2-3
-  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); v = t > v ? t : v;   // row_bcast:15, rows 1 and 3
-  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); v = t > v ? t : v;   // row_bcast:31, rows 2 and 3
-  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-__device__ __forceinline__ unsigned long long wave_max_key(unsigned long long k) {
-  const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
-  const unsigned mh = wave_max_u32(hi);
-  const unsigned ml = wave_max_u32(hi == mh ? lo : 0u);
-  return ((unsigned long long)mh << 32) | ml;
-}
-
 __device__ unsigned long long g_nms_dbg[8];
 __device__ unsigned long long g_nms_dbg2[2];
 __device__ unsigned long long g_nms_dbg3[8];
@@ -1798,6 +1794,10 @@ __device__ __forceinline__ float coop_chain(const NmsArgs& a, const RegLds& S, f
   return reg_chain(a, S, score, begin, bx, k);
 }
 
+#ifndef UDA_NMS_LDS_STATE_IPT
+#define UDA_NMS_LDS_STATE_IPT 4
+#endif
+constexpr bool coop_lds_state(int ipt) { return ipt <= UDA_NMS_LDS_STATE_IPT; }     // per-candidate state of the block in LDS (nms_coop_kernel)
 constexpr int COOP_LIST = 3072;      // entries of the block-wide work list
 constexpr int COOP_HEAVY = 1024;     // entries of the list of chains handed to whole waves
 constexpr int COOP_HEAVY_LINKS = 6;  // overlapping links above which a chain is evaluated by a wave
@@ -1890,6 +1890,16 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
   int* hlist = wlist + COOP_LIST;
   unsigned* ebits = (unsigned*)(hlist + COOP_HEAVY);  // [IPT * 1024 / 32]
   unsigned long long* klist = (unsigned long long*)(ebits + IPT * 32);     // [COOP_KL] (8-byte aligned: every part above is a multiple of 8 bytes)
+  // Small batches (IPT <= 4: tens of blocks per problem, 4096 candidates per block): box, stale score and begin of the block's
+  // candidates live in LDS (24 B each, 96 KB) instead of the workspace arrays in memory - a chain evaluation then starts without
+  // a memory round trip, in each of the three phases of an epoch.
+  constexpr bool LST = coop_lds_state(IPT);
+  float4* lbox = (float4*)(klist + COOP_KL);                               // [IPT * 1024] (16-byte aligned: 16 K + 12 K + 4 K + 128 IPT + 4 K bytes above)
+  float* lstale = (float*)(lbox + (LST ? IPT * SOLO_T : 0));
+  int* lbegin = (int*)(lstale + (LST ? IPT * SOLO_T : 0));
+  auto st_begin = [&](int rel, size_t g) -> int { if constexpr (LST) return lbegin[rel]; else return a.begin[g]; };
+  auto st_stale = [&](int rel, size_t g) -> float { if constexpr (LST) return lstale[rel]; else return a.stale[g]; };
+  auto st_box = [&](int rel, size_t g) -> float4 { if constexpr (LST) return lbox[rel]; else return *(const float4*)(a.boxes + g * 4); };
   __shared__ RegLds S;
   __shared__ CoopLds X;
   __shared__ int wcount, hcount;
@@ -1931,9 +1941,10 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
     if (i < a.K) {
       const float s = scores[bbase + i];
       if (s > a.score_thr) v = s;
-      a.stale[bbase + i] = v;
-      a.begin[bbase + i] = 0;
+      if constexpr (LST) lbox[j * SOLO_T + tid] = *(const float4*)(a.boxes + (bbase + i) * 4);
+      else { a.stale[bbase + i] = v; a.begin[bbase + i] = 0; }
     }
+    if constexpr (LST) { lstale[j * SOLO_T + tid] = v; lbegin[j * SOLO_T + tid] = 0; }
     st[j] = v;
     U[j * SOLO_T + tid] = v;
   }
@@ -1992,8 +2003,8 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
             b = k + u;
           }
         }
-        a.stale[g] = v;
-        a.begin[g] = b;
+        if constexpr (LST) { lstale[rel] = v; lbegin[rel] = b; }
+        else { a.stale[g] = v; a.begin[g] = b; }
       }
       U[rel] = v;
       return v;
@@ -2003,9 +2014,9 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
       if (!POPS && cached) { fn(rel, U[rel]); return; }
       const int gi = gidx(rel);
       const size_t g = bbase + gi;
-      const int begin = a.begin[g];
-      const float stale = a.stale[g];
-      const float4 b4 = *(const float4*)(a.boxes + g * 4);
+      const int begin = st_begin(rel, g);
+      const float stale = st_stale(rel, g);
+      const float4 b4 = st_box(rel, g);
       const float bx[4] = {b4.x, b4.y, b4.z, b4.w};
       const int t = POPS ? first_pop(stale, gi) : 0;
       const int kk = k + t;
@@ -2054,9 +2065,9 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
           if (!plain) {
             gi = gidx(rel);
             g = bbase + gi;
-            begin = a.begin[g];
-            stale = a.stale[g];
-            const float4 b4 = *(const float4*)(a.boxes + g * 4);
+            begin = st_begin(rel, g);
+            stale = st_stale(rel, g);
+            const float4 b4 = st_box(rel, g);
             bx[0] = b4.x; bx[1] = b4.y; bx[2] = b4.z; bx[3] = b4.w;
             t = POPS ? first_pop(stale, gi) : 0;
             kk = k + t;
@@ -2143,11 +2154,11 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
       const int rel = hlist[e];
       const int gi = gidx(rel);
       const size_t g = bbase + gi;
-      const float4 b4 = *(const float4*)(a.boxes + g * 4);
+      const float4 b4 = st_box(rel, g);
       const float bx[4] = {b4.x, b4.y, b4.z, b4.w};
-      const float stale = a.stale[g];
+      const float stale = st_stale(rel, g);
       const int t = POPS ? first_pop(stale, gi) : 0;
-      float v = chain_wave(a, S, stale, a.begin[g], bx, k + t);
+      float v = chain_wave(a, S, stale, st_begin(rel, g), bx, k + t);
       if ((tid & 63) == 0) {
         v = later_pops(rel, g, v, t, bx);
         if (!POPS) atomicOr(&ebits[rel >> 5], 1u << (rel & 31));
@@ -2192,13 +2203,13 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
     if (bk != 0ull && tid < 64) {
       const int bi = (int)(0xFFFFFFFFu - (uint32_t)bk);
       const size_t g = bbase + bi;
-      const int begin = a.begin[g];
-      const float stale0 = a.stale[g];
-      const float4 b4 = *(const float4*)(a.boxes + g * 4);
+      const int br = rel_of(bi);
+      const int begin = st_begin(br, g);
+      const float stale0 = st_stale(br, g);
+      const float4 b4 = st_box(br, g);
       const float pb[4] = {b4.x, b4.y, b4.z, b4.w};
       const float score = chain_wave(a, S, stale0, begin, pb, k);
       if (tid == 0) {
-        const int br = rel_of(bi);
         U[br] = score;
         atomicOr(&ebits[br >> 5], 1u << (br & 31));
         X.mine[0] = (score != -INFINITY) ? nms_key(score, bi) : 0ull;
@@ -2316,8 +2327,8 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
           const size_t o = (size_t)n * a.M + k + t;
           a.sel_idx[o] = widx;
           a.sel_score[o] = U[rel];          // exact in epoch k = exact in epoch k + t (no link of the step touches it)
-          *(float4*)(a.sel_box + o * 4) = *(const float4*)(a.boxes + (bbase + widx) * 4);
-          a.stale[bbase + widx] = -INFINITY;
+          *(float4*)(a.sel_box + o * 4) = st_box(rel, bbase + widx);
+          if constexpr (LST) lstale[rel] = -INFINITY; else a.stale[bbase + widx] = -INFINITY;
           wmask |= 1u << (rel / SOLO_T);
         }
       }
@@ -2366,7 +2377,7 @@ size_t nms_coop_slot_words(int M) { return (size_t)M * (1 + COOP_W) * COOP_MAX_B
 template <int IPT>
 constexpr size_t coop_lds_bytes() {
   return (size_t)IPT * SOLO_T * sizeof(float) + (size_t)(COOP_LIST + COOP_HEAVY) * sizeof(int) + (size_t)IPT * 32 * sizeof(unsigned) +
-         (size_t)COOP_KL * sizeof(unsigned long long);
+         (size_t)COOP_KL * sizeof(unsigned long long) + (coop_lds_state(IPT) ? (size_t)IPT * SOLO_T * 24 : 0);
 }
 
 // co-resident blocks of nms_coop_kernel<IPT> on the current device (occupancy x CUs; 0 = cannot run), cached per HIP device
