@@ -1462,6 +1462,7 @@ void launch_nms_solo(const NmsArgs& a, const float* scores, hipStream_t s) {
 struct RegLds {
   alignas(16) float sel[4 * 128];
   unsigned long long red[SOLO_T / 64];
+  unsigned long long red2[2][SOLO_T / 64];     // reg_max2: alternating halves
   float wgt[128];
   unsigned long long L;
   float pbox[4];
@@ -1487,6 +1488,21 @@ __device__ __forceinline__ unsigned long long wave_max_key(unsigned long long k)
   const unsigned mh = wave_max_u32(hi);
   const unsigned ml = wave_max_u32(hi == mh ? lo : 0u);
   return ((unsigned long long)mh << 32) | ml;
+}
+
+// the same with ONE barrier: the waves' maxima go to alternating halves of red2 (par = 0, 1, 0, ... - uniform over the block), so a
+// call never overwrites what a slower wave may still be reading from the call before (it read that before it arrived at THIS call's
+// barrier).  The caller must not rely on a barrier in front of the reduction.
+__device__ __forceinline__ unsigned long long reg_max2(RegLds& S, unsigned long long v, int& par) {
+  v = wave_max_key(v);
+  unsigned long long* red = S.red2[par];
+  par ^= 1;
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  v = red[0];
+#pragma unroll
+  for (int w = 1; w < SOLO_T / 64; ++w) v = red[w] > v ? red[w] : v;
+  return v;
 }
 
 __device__ __forceinline__ unsigned long long reg_max(RegLds& S, unsigned long long v) {
@@ -1588,7 +1604,7 @@ __device__ __forceinline__ float chain_wave(const NmsArgs& a, const RegLds& S, f
     while (mm) {
       const int ln = __ffsll((long long)mm) - 1;
       mm &= mm - 1ull;
-      const float wl = __shfl(w, ln, 64);
+      const float wl = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(w), ln));      // (ln is wave-uniform: v_readlane, not a ds_bpermute round trip per link)
       if (wl == -2.0f) { score = -INFINITY; break; }
       score *= wl;
       if (score <= a.score_thr) { score = -INFINITY; break; }
@@ -1827,7 +1843,8 @@ struct CoopLds {
 // one word each, as in coop_exchange; wave 0 polls the problem's bpi x nm words (bpi <= 64: at most COOP_W per lane) and
 // leaves the nt largest keys in X.top[0 .. nt) (keys are unique: the candidate index is part of them), 0 behind them.
 __device__ __forceinline__ void coop_exchange_top(unsigned long long* slots, int blk, int bpi, int nm, int nt, CoopLds& X, int* err, unsigned spin_max) {
-  __syncthreads();                           // X.mine is complete
+  // (no barrier in front: X.mine is written by wave 0 and sent by wave 0; everybody else waits at the barrier behind the poll)
+  __builtin_amdgcn_wave_barrier();
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     if (lane < nm) {
@@ -2172,7 +2189,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
     if (tid == 0) { wcount = 0; hcount = 0; }
   };
 
-  int k = 0;
+  int k = 0, rpar = 0;
   for (int step = 0; k < a.M; ++step) {
     // (the candidate index is rebuilt from an opaque base in every epoch: otherwise the per-candidate index words and
     // addresses of all IPT candidates are hoisted out of the epoch loop and spill)
@@ -2198,7 +2215,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
       }
       if (bo != 0u) bk = ((unsigned long long)bo << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)(ib + bj * istride));
     }
-    bk = reg_max(S, bk);
+    bk = reg_max2(S, bk, rpar);
 
     if (bk != 0ull && tid < 64) {
       const int bi = (int)(0xFFFFFFFFu - (uint32_t)bk);
@@ -2260,7 +2277,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
         }
       }
     });
-    ke = reg_max(S, ke);
+    ke = reg_max2(S, ke, rpar);
     // this block's weff best exact keys (wave 0; the list is complete: run_balanced ends with a barrier)
     if (tid < 64) {
       const int cnt = X.kcount;
@@ -2297,22 +2314,26 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
       const unsigned long long key = X.top[t];
       if (t < weff && key != 0ull) S.sel[4 * (k + t) + (tid & 3)] = a.boxes[(bbase + (size_t)(0xFFFFFFFFu - (uint32_t)key)) * 4 + (tid & 3)];
     }
-    __syncthreads();
-    if (tid == 0) {
-      int nw = 1;
-      if (!X.ovf && (a.soft || a.iou_thr >= 0.f)) {
-        for (; nw < weff; ++nw) {
-          const unsigned long long key = X.top[nw];
-          if (key == 0ull || key < bd) break;
-          bool ov = false;
-          for (int p = 0; p < nw; ++p) ov = ov || coop_strict_overlap(S.sel + 4 * (k + nw), S.sel + 4 * (k + p));
-          if (ov) break;
+    // (one winner per step, the default: nothing reads this epoch's S.sel before the barrier inside run_balanced below)
+    int nw = 1;
+    if (weff > 1) {                         // (uniform)
+      __syncthreads();
+      if (tid == 0) {
+        int nw_ = 1;
+        if (!X.ovf && (a.soft || a.iou_thr >= 0.f)) {
+          for (; nw_ < weff; ++nw_) {
+            const unsigned long long key = X.top[nw_];
+            if (key == 0ull || key < bd) break;
+            bool ov = false;
+            for (int p = 0; p < nw_; ++p) ov = ov || coop_strict_overlap(S.sel + 4 * (k + nw_), S.sel + 4 * (k + p));
+            if (ov) break;
+          }
         }
+        X.nwin = nw_;
       }
-      X.nwin = nw;
+      __syncthreads();
+      nw = X.nwin;
     }
-    __syncthreads();
-    const int nw = X.nwin;
 #ifdef UDA_NMS_STATS
     if (tid == 0 && blk == 0) atomicAdd(&g_nms_win[nw < 9 ? nw : 9], 1ull);
 #endif
@@ -2351,7 +2372,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_coop_kernel(NmsArgs a, const float
     k += nw;
     nsel = k;
     for (int f = tid; f < IPT * 32; f += SOLO_T) ebits[f] = 0u;      // "exact in this epoch" bits of the next step
-    __syncthreads();
+    // (no barrier here: the next step touches ebits, U[] and the list counters only behind the barrier of its first block maximum)
 #ifdef UDA_NMS_STATS
     if (tid == 0) {
       const unsigned long long t5 = wall_clock64();
