@@ -42,7 +42,7 @@ def pmc_per_op(path, counter, scale):
 
 
 rows = list(csv.DictReader(open(a.trace)))
-names = ("stem_kernel", "stem16_kernel", "stem_u8_kernel", "sepf_kernel", "pw_kernel", "pwb_kernel", "pwb_shared_kernel", "dw_kernel", "se_kernel", "fuse_kernel", "mbx_kernel", "mbxb_kernel", "mbxd_kernel", "mbxp_kernel", "sep_kernel")
+names = ("stem_kernel", "stem16_kernel", "stem_u8_kernel", "sepf_kernel", "pw_kernel", "pwb_kernel", "pws_kernel", "pwb_shared_kernel", "dw_kernel", "se_kernel", "fuse_kernel", "mbx_kernel", "mbxb_kernel", "mbxd_kernel", "mbxp_kernel", "sep_kernel")
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "::stem" in r["Kernel_Name"]]      # the stem opens a chunk's op list (last chunk of the last step)
 rows = rows[idx[-1]:]

@@ -12,7 +12,7 @@ import sys
 
 
 # op kind of each kernel (bench.py KIND_KERNELS): traffic is reported per kind, like bench.py's roofline
-KIND_OF = {"pwb_kernel": "pw", "pwb_shared_kernel": "pw", "pw_kernel": "pw", "mbxb_kernel": "mbx", "mbxd_kernel": "mbx", "mbxp_kernel": "mbx", "mbx_kernel": "mbx",
+KIND_OF = {"pwb_kernel": "pw", "pws_kernel": "pw", "pwb_shared_kernel": "pw", "pw_kernel": "pw", "mbxb_kernel": "mbx", "mbxd_kernel": "mbx", "mbxp_kernel": "mbx", "mbx_kernel": "mbx",
            "sep_kernel": "sep", "sepf_kernel": "sep", "dw_kernel": "dw", "se_kernel": "se", "fuse_kernel": "fuse", "stem_kernel": "stem", "stem16_kernel": "stem", "stem_u8_kernel": "stem",
            "aggregate_kernel": "aggregate", "aggregate_reg_kernel": "aggregate", "preprocess_kernel": "preprocess",
            "nms_eval_kernel": "nms", "nms_commit_kernel": "nms", "nms_bound_kernel": "nms", "nms_init_kernel": "nms",

@@ -1787,22 +1787,29 @@ __global__ __launch_bounds__(512, 2) void mbxp_kernel(MbxArgs a) {
 }
 
 // Slab groups of a deep fused MBConv launch: a launch of `blocks` blocks on a device that holds per_cu of them per CU is
-// split along the channels until it fills the device (at most 4 ways, at least 4 slabs per block).  A batch of 32 images never
-// splits; one image with T = 10 has 60-90 blocks of 36 slabs each in the last blocks.  UDA_MBX_SPLIT=0: never.
+// split along the channels until it fills the device (at most 16 ways, at least 2 slabs per block: every group re-reads and re-splits
+// the input tile, which is what bounds the split).  A batch of 32 images never splits; one image with T = 10 has 60-90 blocks of 36
+// slabs each in the last blocks (4 groups), one image under head-only MC 9 blocks (16 groups: fused MBConv time of a one-image serve
+// 0.47 -> 0.37 ms against the 4-way limit of round 4; UDA_MBX_SPLIT_MAX / UDA_MBX_SPLIT_SLABS, A/B in one job).  UDA_MBX_SPLIT=0: never.
+// The slabs of a tile are independent: the result does not depend on the split.
 static int mbx_ch_groups(long long blocks, int per_cu, int n_slabs) {
-  static int on = -1, n_cu = 0;
+  static int on = -1, n_cu = 0, gmax = 16, smin = 2;
   if (on < 0) {
     const char* e = getenv("UDA_MBX_SPLIT");
     on = e ? atoi(e) : 1;
+    if (const char* m = getenv("UDA_MBX_SPLIT_MAX")) gmax = atoi(m) > 0 ? atoi(m) : 16;
+    if (const char* m = getenv("UDA_MBX_SPLIT_SLABS")) smin = atoi(m) > 0 ? atoi(m) : 2;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 0;
     (void)hipGetLastError();
   }
   if (!on || n_cu <= 0 || blocks <= 0) return 1;
   long long g = (long long)n_cu * per_cu / blocks;
-  if (g > 4) g = 4;
-  if (g > n_slabs / 4) g = n_slabs / 4;
-  return g < 1 ? 1 : (int)g;
+  if (g > gmax) g = gmax;
+  if (g > n_slabs / smin) g = n_slabs / smin;
+  if (g < 1) g = 1;
+  const long long per = (n_slabs + g - 1) / g;          // slabs per group -> no empty group at the end
+  return (int)((n_slabs + per - 1) / per);
 }
 
 template <int K, int KSF, bool WIDE, int SCH>
