@@ -1461,7 +1461,6 @@ void launch_nms_solo(const NmsArgs& a, const float* scores, hipStream_t s) {
 // Bit-identical selections and scores to the grid version and to the reference's heap.
 struct RegLds {
   alignas(16) float sel[4 * 128];
-  unsigned long long red[SOLO_T / 64];
   unsigned long long red2[2][SOLO_T / 64];     // reg_max2: alternating halves
   float wgt[128];
   unsigned long long L;
@@ -1490,9 +1489,10 @@ __device__ __forceinline__ unsigned long long wave_max_key(unsigned long long k)
   return ((unsigned long long)mh << 32) | ml;
 }
 
-// the same with ONE barrier: the waves' maxima go to alternating halves of red2 (par = 0, 1, 0, ... - uniform over the block), so a
-// call never overwrites what a slower wave may still be reading from the call before (it read that before it arrived at THIS call's
-// barrier).  The caller must not rely on a barrier in front of the reduction.
+// Block-wide maximum of a 64-bit key with ONE barrier: per wave by DPP (wave_max_key: 14 instructions; a __shfl_xor ladder was 12
+// dependent ds_bpermute round trips), the waves' maxima to alternating halves of red2 (par = 0, 1, 0, ... - uniform over the block),
+// so a call never overwrites what a slower wave may still be reading from the call before (it read that before it arrived at THIS
+// call's barrier).  The caller must not rely on a barrier in front of the reduction.
 __device__ __forceinline__ unsigned long long reg_max2(RegLds& S, unsigned long long v, int& par) {
   v = wave_max_key(v);
   unsigned long long* red = S.red2[par];
@@ -1505,16 +1505,6 @@ __device__ __forceinline__ unsigned long long reg_max2(RegLds& S, unsigned long 
   return v;
 }
 
-__device__ __forceinline__ unsigned long long reg_max(RegLds& S, unsigned long long v) {
-  v = wave_max_key(v);          // (DPP: 14 instructions; the __shfl_xor ladder was 12 dependent ds_bpermute round trips, twice per epoch)
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) S.red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  v = S.red[0];
-#pragma unroll
-  for (int w = 1; w < SOLO_T / 64; ++w) v = S.red[w] > v ? S.red[w] : v;
-  return v;
-}
 
 // Pending chain of one candidate: links k-1 .. begin, newest first.  Most links are no-ops - a selected box that does not
 // strictly overlap the candidate has IoU 0, weight exactly 1.0f - so the chain runs in two passes: a cheap interval test
@@ -1655,7 +1645,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_reg_kernel(NmsArgs a, const float*
     a.sel_idx[(size_t)n * a.M + tid] = 0;
     a.sel_score[(size_t)n * a.M + tid] = 0.f;
   }
-  int nsel = 0;
+  int nsel = 0, rpar = 0;
 
   for (int k = 0; k < a.M; ++k) {
     // ---- 1. exact score of the candidate with the largest upper bound
@@ -1666,7 +1656,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_reg_kernel(NmsArgs a, const float*
         const unsigned long long key = nms_key(ub[j], j * SOLO_T + tid);
         bk = key > bk ? key : bk;
       }
-    bk = reg_max(S, bk);
+    bk = reg_max2(S, bk, rpar);
     if (bk == 0ull) break;                 // nothing alive
     const int bi = (int)(0xFFFFFFFFu - (uint32_t)bk);
     const bool own = (bi % SOLO_T) == tid;
@@ -1711,7 +1701,7 @@ __global__ __launch_bounds__(SOLO_T) void nms_reg_kernel(NmsArgs a, const float*
         }
       }
     }
-    const unsigned long long wk = reg_max(S, ke);
+    const unsigned long long wk = reg_max2(S, ke, rpar);
     if (wk == 0ull) break;                 // no live candidate left: the remaining slots stay padded
     const int widx = (int)(0xFFFFFFFFu - (uint32_t)wk);
     // ---- 3. pops and the winner
@@ -1739,7 +1729,8 @@ __global__ __launch_bounds__(SOLO_T) void nms_reg_kernel(NmsArgs a, const float*
       }
     }
     nsel = k + 1;
-    __syncthreads();
+    // (no barrier at the end of an epoch: the winner's S.sel entry and the per-epoch words of S are next touched behind the
+    // barrier of the following block maximum; four block barriers per epoch instead of seven)
   }
   if (tid == 0) a.nsel[n] = nsel;
 }
