@@ -1516,12 +1516,20 @@ __device__ __forceinline__ void chain_mask(const NmsArgs& a, const RegLds& S, in
   m[0] = 0ull; m[1] = 0ull;                      // links 0..63 / 64..127
   if (a.soft || a.iou_thr >= 0.f) {
     const float y0 = fminf(bx[0], bx[2]), x0 = fminf(bx[1], bx[3]), y1 = fmaxf(bx[0], bx[2]), x1 = fmaxf(bx[1], bx[3]);
-    for (int j = begin; j < k; ++j) {
-      const float4 sb = *(const float4*)(S.sel + 4 * j);
+    auto test = [&](const float4& sb, int j) {
       const float sy0 = fminf(sb.x, sb.z), sx0 = fminf(sb.y, sb.w), sy1 = fmaxf(sb.x, sb.z), sx1 = fmaxf(sb.y, sb.w);
       const bool ov = (fminf(y1, sy1) > fmaxf(y0, sy0)) && (fminf(x1, sx1) > fmaxf(x0, sx0));
       if (ov) m[j >> 6] |= 1ull << (j & 63);
+    };
+    int j = begin;
+    // four selected boxes on their way at a time: one LDS round trip per link otherwise (up to 100 in a row for a candidate that was
+    // never evaluated - the longest single-thread stretch of an epoch of the one-block kernel)
+    for (; j + 4 <= k; j += 4) {
+      const float4 s0 = *(const float4*)(S.sel + 4 * j), s1 = *(const float4*)(S.sel + 4 * j + 4);
+      const float4 s2 = *(const float4*)(S.sel + 4 * j + 8), s3 = *(const float4*)(S.sel + 4 * j + 12);
+      test(s0, j); test(s1, j + 1); test(s2, j + 2); test(s3, j + 3);
     }
+    for (; j < k; ++j) test(*(const float4*)(S.sel + 4 * j), j);
   } else {                                        // (negative hard threshold: IoU 0 suppresses too - no link can be skipped)
     for (int j = begin; j < k; ++j) m[j >> 6] |= 1ull << (j & 63);
   }
