@@ -747,16 +747,23 @@ __global__ __launch_bounds__(SE_THREADS) void se_kernel(SeArgs a) {
     const int j = tid % a.mid, part = tid / a.mid;
     float s = 0.f;
     if (part < P) {
-      // (eight weights in flight per step, summed in channel order: left as a plain loop this was one load - wait - fma round
+      // (sixteen weights in flight per step, summed in channel order: left as a plain loop this was one load - wait - fma round
       // trip per channel, 55 in a row for C = 1152, and the whole kernel 38 us at batch 1)
       const float* wp = a.w1 + j;
       int c = part;
-      for (; c + 7 * P < a.C; c += 8 * P) {
-        float w[8];
+      for (; c + 15 * P < a.C; c += 16 * P) {
+        float w[16];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) w[q] = wp[(size_t)(c + q * P) * a.mid];
+        for (int q = 0; q < 16; ++q) w[q] = wp[(size_t)(c + q * P) * a.mid];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) s = fmaf(mean[c + q * P], w[q], s);
+        for (int q = 0; q < 16; ++q) s = fmaf(mean[c + q * P], w[q], s);
+      }
+      for (; c + 3 * P < a.C; c += 4 * P) {
+        float w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = wp[(size_t)(c + q * P) * a.mid];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s = fmaf(mean[c + q * P], w[q], s);
       }
       for (; c < a.C; c += P) s = fmaf(mean[c], wp[(size_t)c * a.mid], s);
     }
@@ -774,12 +781,19 @@ __global__ __launch_bounds__(SE_THREADS) void se_kernel(SeArgs a) {
     float s = 0.f;
     const float* wp = a.w2 + c;
     int j = 0;
-    for (; j + 8 <= a.mid; j += 8) {
-      float w[8];
+    for (; j + 16 <= a.mid; j += 16) {
+      float w[16];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) w[q] = wp[(size_t)(j + q) * a.C];
+      for (int q = 0; q < 16; ++q) w[q] = wp[(size_t)(j + q) * a.C];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) s = fmaf(mid[j + q], w[q], s);
+      for (int q = 0; q < 16; ++q) s = fmaf(mid[j + q], w[q], s);
+    }
+    for (; j + 4 <= a.mid; j += 4) {
+      float w[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[q] = wp[(size_t)(j + q) * a.C];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s = fmaf(mid[j + q], w[q], s);
     }
     for (; j < a.mid; ++j) s = fmaf(mid[j], wp[(size_t)j * a.C], s);
     a.scale[(size_t)b * a.C + c] = sigmoidf_(s + a.b2[c]) * (dm ? dm[c] : 1.f);
